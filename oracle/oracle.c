@@ -1,0 +1,295 @@
+/*
+ * oracle.c -- CPU restatement of the reference's INT8 inference path.  TEST INFRASTRUCTURE ONLY
+ * (see oracle.h for the rules and the pinning status).  Build: oracle/Makefile, -O2, strict IEEE
+ * (no -ffast-math, -ffp-contract=off) so that every float/double step is the one written here.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ im2col: src/im2col.c:4-13, 26-50 */
+static uint8_t im2col_get_pixel(const uint8_t *im, int height, int width, int row, int col, int channel, int pad,
+                                uint8_t pad_value)
+{
+    row -= pad;
+    col -= pad;
+    if (row < 0 || col < 0 || row >= height || col >= width) return pad_value; /* :10-11 pad = input zero point */
+    return im[col + width * (row + height * channel)];
+}
+
+void orc_im2col_u8(const uint8_t *im, int channels, int height, int width, int ksize, int stride, int pad,
+                   uint8_t *col, uint8_t pad_value)
+{
+    int height_col = (height + 2 * pad - ksize) / stride + 1; /* :30 */
+    int width_col = (width + 2 * pad - ksize) / stride + 1;   /* :31 */
+    int channels_col = channels * ksize * ksize;              /* :33 row index = (ci*k + ky)*k + kx */
+    for (int c = 0; c < channels_col; ++c) {
+        int w_offset = c % ksize;
+        int h_offset = (c / ksize) % ksize;
+        int c_im = c / ksize / ksize;
+        for (int h = 0; h < height_col; ++h) {
+            for (int w = 0; w < width_col; ++w) {
+                int im_row = h_offset + h * stride;
+                int im_col = w_offset + w * stride;
+                col[(c * height_col + h) * width_col + w] =
+                    im2col_get_pixel(im, height, width, im_row, im_col, c_im, pad, pad_value);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ GEMM: src/gemm.c:279-299
+ * `C[i*ldc+j] += ALPHA*A[i*lda+k]*B[k*ldb+j]` with float ALPHA and int32_t C: each step is
+ * C = (int32)((float)C + (ALPHA*(float)A)*(float)B), loops i,k,j.  The product is exact in fp32
+ * (<= 65025); the int32->fp32 conversion and the add round to nearest-even once |C| > 2^24. */
+void orc_gemm_nn_u8_i32_te(int M, int N, int K, float ALPHA, const uint8_t *A, int lda, const uint8_t *B, int ldb,
+                           int BETA, int32_t *C, int ldc)
+{
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < N; ++j) C[i * ldc + j] *= BETA; /* :286-290 */
+    for (int i = 0; i < M; ++i) {
+        for (int k = 0; k < K; ++k) {
+            float a = ALPHA * (float)A[i * lda + k];
+            for (int j = 0; j < N; ++j) {
+                float p = a * (float)B[k * ldb + j];
+                float s = (float)C[i * ldc + j] + p;
+                C[i * ldc + j] = (int32_t)s; /* fp32 -> int32 truncation (value is already integral) */
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ conv accumulators
+ * src/convolutional_layer.c:699-723 for one image, groups == 1. */
+void orc_conv_acc(const uint8_t *x, int c, int h, int w, const uint8_t *wq, const uint8_t *zp_w, int n, int ksize,
+                  int stride, int pad, uint8_t zp_in, int accum_mode, int32_t *acc, int64_t *s1)
+{
+    int oh = (h + 2 * pad - ksize) / stride + 1;
+    int ow = (w + 2 * pad - ksize) / stride + 1;
+    int K = ksize * ksize * c; /* :700 */
+    int N = oh * ow;           /* :701 */
+    const uint8_t *b;
+    uint8_t *col = NULL;
+    if (ksize == 1) {
+        b = x; /* :712-713 (the reference ignores stride/pad for 1x1; so do we) */
+    } else {
+        col = (uint8_t *)malloc((size_t)K * N); /* :702-705: workspace pre-filled with zp_in, then im2col */
+        memset(col, zp_in, (size_t)K * N);
+        orc_im2col_u8(x, c, h, w, ksize, stride, pad, col, zp_in); /* :715 */
+        b = col;
+    }
+    if (accum_mode == ORC_ACC_REF_F32) {
+        /* :718 / :721 two GEMM passes; the second uses the [n][K] table whose row oc is all zp_w[oc]
+         * (src/blas.c:290-300) */
+        uint8_t *zpt = (uint8_t *)malloc((size_t)n * K);
+        for (int oc = 0; oc < n; ++oc) memset(zpt + (size_t)oc * K, zp_w[oc], (size_t)K);
+        orc_gemm_nn_u8_i32_te(n, N, K, 1.0f, wq, K, b, N, 0, acc, N);
+        orc_gemm_nn_u8_i32_te(n, N, K, -1.0f, zpt, K, b, N, 1, acc, N);
+        free(zpt);
+        if (s1) {
+            for (int oc = 0; oc < n; ++oc)
+                for (int j = 0; j < N; ++j) {
+                    int64_t s = 0;
+                    for (int k = 0; k < K; ++k) s += (int64_t)wq[(size_t)oc * K + k] * b[(size_t)k * N + j];
+                    s1[(size_t)oc * N + j] = s;
+                }
+        }
+    } else {
+        int64_t *row = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)N);
+        int64_t *rs1 = row + N;
+        for (int oc = 0; oc < n; ++oc) {
+            memset(row, 0, sizeof(int64_t) * 2 * (size_t)N);
+            int zw = zp_w[oc];
+            for (int k = 0; k < K; ++k) {
+                int wv = wq[(size_t)oc * K + k];
+                const uint8_t *bk = b + (size_t)k * N;
+                for (int j = 0; j < N; ++j) {
+                    row[j] += (int64_t)(wv - zw) * bk[j];
+                    rs1[j] += (int64_t)wv * bk[j];
+                }
+            }
+            for (int j = 0; j < N; ++j) {
+                acc[(size_t)oc * N + j] = (int32_t)row[j];
+                if (s1) s1[(size_t)oc * N + j] = rs1[j];
+            }
+        }
+        free(row);
+    }
+    free(col);
+}
+
+/* ------------------------------------------------------------------ requant epilogue
+ * src/convolutional_layer.c:726-751.  Double precision with two truncations:
+ *   int64_t t = (acc + biases_int32[oc]) * M_value[oc];       :732
+ *   int32_t q = t * M0_right_shift_value[oc];                 :733
+ * then the activation switch :734-748 whose result is stored to a uint8_t *before* clamp() :749, i.e. it wraps
+ * mod 256 (the reference relies on x86 double->uint8 conversion = truncate to int32, keep the low byte). */
+void orc_requant(const int32_t *acc, int n, int spatial, const int32_t *biases_int32, const double *M_value,
+                 const double *shift_value, uint8_t zp_act, int activation, int store_mode, uint8_t *out_u8)
+{
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < spatial; ++j) {
+            size_t idx = (size_t)i * spatial + j;
+            int32_t q = acc[idx];
+            int64_t t = (int64_t)((double)(q + biases_int32[i]) * M_value[i]);
+            q = (int32_t)((double)t * shift_value[i]);
+            int32_t v;
+            switch (activation) {
+            case ORC_LEAKY: {
+                /* :737 the conditional expression has type double on both arms */
+                double d = q < 0 ? (round((double)q * 0.1) + (double)zp_act) : (double)(q + (int)zp_act);
+                v = (int32_t)d;
+                break;
+            }
+            case ORC_LINEAR:
+            case ORC_RELU: /* :740-742: RELU falls through to the LINEAR arm in the default path */
+                v = q + (int)zp_act;
+                break;
+            case ORC_RELU6: /* :743-745 */
+                v = q <= 0 ? (int)zp_act : q + (int)zp_act;
+                break;
+            default: /* :746-747: no store; output keeps its previous content. Not reachable from our cfgs. */
+                continue;
+            }
+            if (store_mode == ORC_STORE_SATURATE) {
+                v = v < 0 ? 0 : (v > 255 ? 255 : v); /* src/blas.c:443-452 applied before the store (:594) */
+            }
+            out_u8[idx] = (uint8_t)v; /* modular */
+        }
+    }
+}
+
+void orc_dequant(const uint8_t *u8, int count, uint8_t zp_act, float s_act, float *out)
+{
+    /* :757  l.output = (u8 - zp) * s_act : int -> float multiply */
+    for (int i = 0; i < count; ++i) out[i] = (float)((int)u8[i] - (int)zp_act) * s_act;
+}
+
+/* ------------------------------------------------------------------ maxpool: src/maxpool_layer.c:109-172
+ * window offset -pad/2 (:112-113), out dims (w + pad - size)/stride + 1 (:31-32), `max` starts at 0 (:134) and
+ * out-of-image taps yield (uint8_t)(-FLT_MAX) which is 0 on x86 (:143) -> OOB taps never win. */
+void orc_maxpool_u8(const uint8_t *x, int c, int h, int w, int size, int stride, int pad, uint8_t *out)
+{
+    int w_offset = -pad / 2, h_offset = -pad / 2;
+    int oh = (h + pad - size) / stride + 1;
+    int ow = (w + pad - size) / stride + 1;
+    for (int k = 0; k < c; ++k)
+        for (int i = 0; i < oh; ++i)
+            for (int j = 0; j < ow; ++j) {
+                uint8_t mx = 0;
+                for (int n = 0; n < size; ++n)
+                    for (int m = 0; m < size; ++m) {
+                        int cur_h = h_offset + i * stride + n;
+                        int cur_w = w_offset + j * stride + m;
+                        int valid = (cur_h >= 0 && cur_h < h && cur_w >= 0 && cur_w < w);
+                        uint8_t val = valid ? x[cur_w + w * (cur_h + h * k)] : 0;
+                        if (val > mx) mx = val;
+                    }
+                out[j + ow * (i + oh * k)] = mx;
+            }
+}
+
+/* ------------------------------------------------------------------ upsample: src/blas.c:781-803 forward */
+void orc_upsample_u8(const uint8_t *x, int c, int h, int w, int stride, uint8_t *out)
+{
+    for (int k = 0; k < c; ++k)
+        for (int j = 0; j < h * stride; ++j)
+            for (int i = 0; i < w * stride; ++i)
+                out[k * w * h * stride * stride + j * w * stride + i] = x[k * w * h + (j / stride) * w + i / stride];
+}
+
+/* ------------------------------------------------------------------ src/blas.c:387-418 */
+int orc_quant_multiplier(float real_multiplier, int32_t *M0, int *right_shift)
+{
+    if (!(real_multiplier > 0.f) || !(real_multiplier < 1.f)) return -1; /* :391-392 asserts */
+    int s = 0;
+    while (real_multiplier < 0.5f) { /* :398-401 float loop */
+        real_multiplier *= 2.0f;
+        s++;
+    }
+    /* :404  round(real_multiplier * (1ll << 31)): float * (float)2^31, then round() in double */
+    int64_t q = (int64_t)round((double)(real_multiplier * (float)(1ll << 31)));
+    if (q == (1ll << 31)) { /* :410-413 */
+        q /= 2;
+        s--;
+    }
+    if (s < 0) return -1;
+    *M0 = (int32_t)q;
+    *right_shift = s;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ host prep, src/blas.c:285-334 */
+int orc_prep_conv(int n, int c, int ksize, const uint8_t *wq, const uint8_t *zp_w, const float *s_w, float s_in,
+                  uint8_t zp_in, float s_act, const float *biases, const float *scales, const float *mean,
+                  const float *var, int32_t *biases_int32, double *M_value, double *shift_value, int32_t *M0,
+                  int *shift)
+{
+    int K = c * ksize * ksize; /* :306 note: ignores groups, as upstream */
+    for (int ii = 0; ii < n; ++ii) {
+        /* :286 -> :594-600 batch_normalize_bias: b - scale*mean/(sqrt(var) + 1e-6f).
+         * sqrt() is the double function applied to a float; the sum with the float literal is done in double,
+         * the quotient in double, then the subtraction rounds to float on the store. */
+        float b = biases[ii];
+        if (scales) b = (float)((double)b - (double)(scales[ii] * mean[ii]) / (sqrt((double)var[ii]) + (double).000001f));
+        /* :306-311 */
+        uint32_t mult_zero_point = (uint32_t)(K * (int)zp_in * (int)zp_w[ii]);
+        int32_t wsum = 0;
+        for (int jj = 0; jj < K; ++jj) wsum += wq[(size_t)ii * K + jj];
+        int32_t weights_sum_int = (int32_t)(mult_zero_point - (uint32_t)(wsum * (int)zp_in));
+        /* :313-316 */
+        float M = s_in * s_w[ii] / s_act;
+        if (orc_quant_multiplier(M, &M0[ii], &shift[ii])) return -1;
+        shift_value[ii] = pow(2, -shift[ii]);
+        M_value[ii] = pow(2, -31) * M0[ii];
+        /* :333  biases_int32 = biases / (s_in * s_w) + weights_sum_int   (float expression -> int32 trunc) */
+        float t = b / (s_in * s_w[ii]) + (float)weights_sum_int;
+        biases_int32[ii] = (int32_t)t;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ src/blas.c:108-168 with size_channel == 1 */
+int orc_quantize_image(const float *x, int count, uint8_t *out, float *scale, uint8_t *zp)
+{
+    float min_value = 0.0f, max_value = 0.0f; /* :115-116: the range always includes 0 */
+    for (int j = 0; j < count; ++j) {
+        max_value = x[j] > max_value ? x[j] : max_value;
+        min_value = x[j] < min_value ? x[j] : min_value;
+    }
+    if (min_value == 0 && max_value == 0) return -1; /* :125-128 assert */
+    /* :136  (max - min) / (quant_max_float - quant_min_float).  The reference is built with -Ofast
+     * (Makefile:36), under which gcc folds the division by the constant 255.0f into a multiplication by
+     * (1.0f/255.0f) (`mulss .LC` in the object code); that is 1 ulp away from the IEEE quotient for some inputs,
+     * and the golden vector 'qimg_unit' pins the multiply form. */
+    float nudged_scale = (max_value - min_value) * (1.0f / 255.0f);
+    if (nudged_scale == 0) return -1;
+    const double initial_zero_point = (double)(0.0f - min_value / nudged_scale); /* :138 float expr widened */
+    uint8_t nudged_zero_point;
+    if (initial_zero_point < 0) nudged_zero_point = 0;
+    else if (initial_zero_point > 255) nudged_zero_point = 255;
+    else nudged_zero_point = (uint8_t)round(initial_zero_point);
+    *scale = nudged_scale;
+    *zp = nudged_zero_point;
+    for (int k = 0; k < count; ++k) {
+        /* :154 float temp = round(x / scale) + zp  (round() in double, sum in double, store to float) */
+        float t = (float)(round((double)(x[k] / nudged_scale)) + (double)nudged_zero_point);
+        int v = (int)t; /* :158 clamp(int input, ...) takes the float by value conversion */
+        out[k] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ src/yolo_layer.c:132-146 */
+static float logistic(float x) { return (float)(1. / (1. + exp(-(double)x))); } /* src/activations.h:39 */
+void orc_yolo_forward(const float *in, int n, int classes, int h, int w, float *out)
+{
+    int hw = h * w, per = classes + 5;
+    memcpy(out, in, sizeof(float) * (size_t)n * per * hw);
+    for (int a = 0; a < n; ++a) {
+        float *o = out + (size_t)a * per * hw;
+        for (int i = 0; i < 2 * hw; ++i) o[i] = logistic(o[i]);                       /* x, y */
+        for (int i = 4 * hw; i < per * hw; ++i) o[i] = logistic(o[i]);                /* obj + classes */
+    }
+}

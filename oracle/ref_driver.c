@@ -1,0 +1,203 @@
+/*
+ * ref_driver.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * A thin C-ABI driver around the *unmodified* reference sources (compiled in place from
+ * /root/reference by oracle/build_ref.sh into oracle/_ref/).  It exists so that tests and the
+ * golden-vector generator can execute the reference's own functions:
+ *
+ *   load_network                                   src/network.c:49
+ *   quantization_weights_and_activations           src/blas.c:259-346
+ *   layer.forward (function pointer)               include/darknet.h:158
+ *   forward_network's uint8 hand-off               src/network.c:229-261
+ *   gemm_nn_uint8_int32_te                         src/gemm.c:279-299
+ *   im2col_cpu_uint8                               src/im2col.c:26-50
+ *   quant_multi_smaller_than_one_to_scale_and_shift src/blas.c:387-418
+ *
+ * Everything in this file is our own code; it only *calls* the reference's public API.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include "darknet.h"
+
+/* not in the public header, but exported by the reference objects */
+void gemm_nn_uint8_int32_te(int M, int N, int K, float ALPHA, uint8_t *A, int lda, uint8_t *B, int ldb,
+                            int BETA, int32_t *C, int ldc);
+void im2col_cpu_uint8(uint8_t *data_im, int channels, int height, int width, int ksize, int stride, int pad,
+                      uint8_t *data_col, uint8_t return_data);
+void quant_multi_smaller_than_one_to_scale_and_shift(float real_multiplier, int32_t *quantized_multiplier,
+                                                     int *right_shift);
+void quant_weights_with_min_max_channel(int size_channel, float *input, uint8_t *input_int8, int16_t *input_int16,
+                                        int16_t *zero_point_int16, int size_feature, float *quantzation_scale,
+                                        uint8_t *quantization_zero_point, int zp_flag);
+
+/* The reference printf()s per layer; silence it around calls. */
+static int g_saved_stdout = -1;
+static void hush(void)
+{
+    fflush(stdout);
+    g_saved_stdout = dup(1);
+    int fd = open("/dev/null", O_WRONLY);
+    dup2(fd, 1);
+    close(fd);
+}
+static void unhush(void)
+{
+    fflush(stdout);
+    if (g_saved_stdout >= 0) {
+        dup2(g_saved_stdout, 1);
+        close(g_saved_stdout);
+        g_saved_stdout = -1;
+    }
+}
+
+typedef struct {
+    network *net;
+    int prepared;
+} refnet;
+
+void *refdrv_load(const char *cfg, const char *weights)
+{
+    hush();
+    refnet *r = calloc(1, sizeof(refnet));
+    r->net = load_network((char *)cfg, (char *)weights, 0);
+    set_batch_network(r->net, 1);
+    unhush();
+    return r;
+}
+
+int refdrv_nlayers(void *h) { return ((refnet *)h)->net->n; }
+
+/* info[0..11] = type, out_c, out_h, out_w, c, h, w, n(filters), size, stride, pad, activation,
+ * info[12..15] = batch_normalize, layer_quant_flag, quant_stop_flag, outputs */
+int refdrv_layer_info(void *h, int i, int *info)
+{
+    network *net = ((refnet *)h)->net;
+    if (i < 0 || i >= net->n) return -1;
+    layer *l = &net->layers[i];
+    info[0] = l->type; info[1] = l->out_c; info[2] = l->out_h; info[3] = l->out_w;
+    info[4] = l->c; info[5] = l->h; info[6] = l->w; info[7] = l->n;
+    info[8] = l->size; info[9] = l->stride; info[10] = l->pad; info[11] = l->activation;
+    info[12] = l->batch_normalize; info[13] = l->layer_quant_flag; info[14] = l->quant_stop_flag;
+    info[15] = l->outputs;
+    return 0;
+}
+
+/* Run the reference's host prep exactly once (it is not idempotent: src/blas.c:309 accumulates
+ * weights_sum_int and 285-286 re-folds batch-norm on every call).  X = float CHW image. */
+int refdrv_prepare(void *h, float *X)
+{
+    refnet *r = h;
+    if (r->prepared) return -1;
+    r->net->input = X;
+    hush();
+    quantization_weights_and_activations(r->net);
+    unhush();
+    r->prepared = 1;
+    return 0;
+}
+
+/* Overwrite the quantised network input (after refdrv_prepare fixed the layer-0 scale / zero point). */
+int refdrv_set_input_u8(void *h, const uint8_t *x)
+{
+    refnet *r = h;
+    memcpy(r->net->input_uint8, x, (size_t)r->net->inputs);
+    return 0;
+}
+const uint8_t *refdrv_input_u8(void *h) { return ((refnet *)h)->net->input_uint8; }
+
+/* The layer loop of forward_network (src/network.c:238-259) with the reference's own function
+ * pointers; identical hand-off rule.  Returns wall seconds spent per layer in t[] (nullable). */
+int refdrv_forward(void *h, double *t)
+{
+    refnet *r = h;
+    if (!r->prepared) return -1;
+    network net = *r->net;
+    net.train = 0;
+    hush();
+    for (int i = 0; i < net.n; ++i) {
+        net.index = i;
+        layer l = net.layers[i];
+        double t0 = what_time_is_it_now();
+        l.forward(l, net);
+        if (t) t[i] = what_time_is_it_now() - t0;
+        if (l.layer_quant_flag && !net.train) {
+            net.input_uint8 = l.output_uint8_final;
+            net.input = l.output;
+        } else {
+            net.input = l.output;
+        }
+        /* the reference leaks the im2col workspace every call (src/convolutional_layer.c:702);
+           nothing to free here: net is a by-value copy and the pointer is lost, as upstream. */
+    }
+    unhush();
+    return 0;
+}
+
+/* Whole-net predict through the reference's own entry point (for timing "Predicted in"). */
+double refdrv_network_predict(void *h, float *X)
+{
+    refnet *r = h;
+    hush();
+    double t0 = what_time_is_it_now();
+    network_predict(r->net, X);
+    double dt = what_time_is_it_now() - t0;
+    unhush();
+    return dt;
+}
+
+const int32_t *refdrv_layer_int32(void *h, int i) { return ((refnet *)h)->net->layers[i].output_int32; }
+const uint8_t *refdrv_layer_u8(void *h, int i) { return ((refnet *)h)->net->layers[i].output_uint8_final; }
+const float *refdrv_layer_f32(void *h, int i) { return ((refnet *)h)->net->layers[i].output; }
+
+/* Host-prep products of conv layer i (arrays of l.n entries each, caller-allocated; any may be NULL). */
+int refdrv_layer_prep(void *h, int i, int32_t *biases_int32, double *M_value, double *shift_value, int32_t *M0,
+                      int *shift, float *in_scale_zp_act_scale_zp /* [4]: s_in, zp_in, s_act, zp_act */)
+{
+    network *net = ((refnet *)h)->net;
+    layer *l = &net->layers[i];
+    if (in_scale_zp_act_scale_zp && l->activ_data_uint8_scales) {
+        in_scale_zp_act_scale_zp[2] = l->activ_data_uint8_scales[0];
+        in_scale_zp_act_scale_zp[3] = l->activ_data_uint8_zero_point[0];
+        if (l->type == CONVOLUTIONAL) {
+            in_scale_zp_act_scale_zp[0] = l->input_data_uint8_scales[0];
+            in_scale_zp_act_scale_zp[1] = l->input_data_uint8_zero_point[0];
+        }
+    }
+    if (l->type != CONVOLUTIONAL) return 1;
+    for (int k = 0; k < l->n; ++k) {
+        if (biases_int32) biases_int32[k] = l->biases_int32[k];
+        if (M_value) M_value[k] = l->M_value[k];
+        if (shift_value) shift_value[k] = l->M0_right_shift_value[k];
+        if (M0) M0[k] = l->M0[k];
+        if (shift) shift[k] = l->M0_right_shift[k];
+    }
+    return 0;
+}
+
+/* ---- single-function entry points (known-answer vectors for the restatement) ---- */
+void refdrv_gemm_u8(int M, int N, int K, float ALPHA, uint8_t *A, int lda, uint8_t *B, int ldb, int BETA,
+                    int32_t *C, int ldc)
+{
+    gemm_nn_uint8_int32_te(M, N, K, ALPHA, A, lda, B, ldb, BETA, C, ldc);
+}
+void refdrv_im2col_u8(uint8_t *im, int c, int h, int w, int k, int stride, int pad, uint8_t *col, uint8_t padv)
+{
+    im2col_cpu_uint8(im, c, h, w, k, stride, pad, col, padv);
+}
+void refdrv_quant_multiplier(float m, int32_t *M0, int *shift)
+{
+    quant_multi_smaller_than_one_to_scale_and_shift(m, M0, shift);
+}
+void refdrv_quantize_image(float *x, int n, uint8_t *out, float *scale, uint8_t *zp)
+{
+    int16_t *tmp16 = calloc(n, sizeof(int16_t));
+    int16_t zp16 = 0;
+    hush();
+    quant_weights_with_min_max_channel(1, x, out, tmp16, &zp16, n, scale, zp, 0);
+    unhush();
+    free(tmp16);
+}

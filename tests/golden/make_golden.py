@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by RUNNING THE REFERENCE ITSELF (oracle/_ref = the unmodified
+/root/reference sources compiled by oracle/build_ref.sh, Makefile-default flags: GPU=0 QUANTIZATION=1 -Ofast).
+
+  python tests/golden/make_golden.py            # rewrites tests/golden/*.npz, *.json
+
+Fixtures are data only (inputs + the reference's outputs):
+  tiny_unit_seed{1,2}.npz   full per-layer tensors of cfg/tiny_unit.cfg (seed 2 = act_gain 8: wrap-on-store cases)
+  funcs.npz                 known-answer vectors for gemm_nn_uint8_int32_te / im2col_cpu_uint8 /
+                            quant_multi_smaller_than_one_to_scale_and_shift / quant_weights_with_min_max_channel
+  yolov3_tiny_{leaky,relu6}.json   per-layer SHA-256 of output_int32 / output_uint8_final / output (f32) of the
+                            24-layer net @416x416 on the seeded synthetic model + seeded uint8 image, the host-prep
+                            arrays' SHA-256, and the full head tensors' uint8 bytes (L15, L22) as hex.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from yolo_quantization_amd import synth  # noqa: E402
+import refdrv  # noqa: E402
+
+WEIGHT_SEED, IMAGE_SEED = 1234, 7
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run_ref(cfg, wts, img_seed):
+    net = refdrv.RefNet(cfg, wts)
+    _, layers = synth.layer_shapes(synth.read_cfg(cfg))
+    L0 = layers[0]
+    x = synth.synth_image_u8(L0.c, L0.h, L0.w, seed=img_seed)
+    xq = net.prepare(synth.image_u8_to_float(x))
+    assert np.array_equal(xq, x.ravel()), "layer-0 quantiser is expected to be the identity on pinned images"
+    net.forward()
+    return net, layers, x
+
+
+def tiny_unit(seed, act_gain):
+    cfg = os.path.join(ROOT, "cfg", "tiny_unit.cfg")
+    wts = f"/tmp/golden_tiny_unit_{seed}.weights"
+    meta = synth.synth_weights(cfg, wts, seed=seed, act_gain=act_gain)
+    net, layers, x = run_ref(cfg, wts, img_seed=100 + seed)
+    d = {"input_u8": x, "weights_sha256": np.array(meta["sha256"]), "seed": np.array(seed),
+         "act_gain": np.array(act_gain), "img_seed": np.array(100 + seed)}
+    for i, L in enumerate(layers):
+        if L.type == "conv":
+            d[f"L{i}_int32"] = net.layer_int32(i)
+            p = net.prep(i)
+            for k in ("biases_int32", "M_value", "shift_value", "M0", "shift"):
+                d[f"L{i}_{k}"] = p[k]
+        if L.type != "yolo":
+            d[f"L{i}_u8"] = net.layer_u8(i)
+        if L.quant_stop or L.type == "yolo":
+            d[f"L{i}_f32"] = net.layer_f32(i)
+    np.savez_compressed(os.path.join(HERE, f"tiny_unit_seed{seed}.npz"), **d)
+    nwrap = 0
+    print(f"tiny_unit seed {seed}: wrote {len(d)} arrays")
+
+
+def funcs():
+    L = refdrv.lib()
+    rng = np.random.default_rng(42)
+    d = {}
+    # GEMM: a small exact case and a case whose running sums exceed 2^24 (fp32 rounding visible)
+    for name, (M, N, K, lo, hi) in {"small": (5, 7, 33, 0, 256), "big": (3, 11, 700, 180, 256)}.items():
+        A = rng.integers(lo, hi, (M, K), dtype=np.uint8)
+        B = rng.integers(lo, hi, (K, N), dtype=np.uint8)
+        Z = np.repeat(rng.integers(100, 157, (M, 1), dtype=np.uint8), K, axis=1)
+        Cm = np.zeros((M, N), np.int32)
+        L.refdrv_gemm_u8(M, N, K, 1.0, A.ctypes.data, K, B.ctypes.data, N, 0, Cm.ctypes.data, N)
+        C1 = Cm.copy()
+        L.refdrv_gemm_u8(M, N, K, -1.0, Z.ctypes.data, K, B.ctypes.data, N, 1, Cm.ctypes.data, N)
+        d[f"gemm_{name}_A"] = A; d[f"gemm_{name}_B"] = B; d[f"gemm_{name}_Z"] = Z
+        d[f"gemm_{name}_C1"] = C1; d[f"gemm_{name}_C2"] = Cm
+    # im2col 3x3 pad 1 with non-zero pad value, and stride 2
+    im = rng.integers(0, 256, (3, 5, 6), dtype=np.uint8)
+    for name, (k, s, p, pv) in {"k3s1": (3, 1, 1, 23), "k3s2": (3, 2, 1, 128)}.items():
+        oh = (5 + 2 * p - k) // s + 1; ow = (6 + 2 * p - k) // s + 1
+        col = np.zeros((3 * k * k, oh * ow), np.uint8)
+        L.refdrv_im2col_u8(im.ctypes.data, 3, 5, 6, k, s, p, col.ctypes.data, pv)
+        d[f"im2col_{name}"] = col
+    d["im2col_im"] = im
+    # multiplier decomposition
+    ms = np.concatenate([rng.uniform(1e-6, 0.999, 200), [0.5, 0.25, 0.99999994, 0.49999997, 1e-7, 0.75]]).astype(np.float32)
+    m0 = np.zeros(ms.size, np.int32); sh = np.zeros(ms.size, np.int32)
+    import ctypes as C
+    for i, m in enumerate(ms):
+        a = C.c_int32(); b = C.c_int()
+        L.refdrv_quant_multiplier(float(m), C.byref(a), C.byref(b))
+        m0[i] = a.value; sh[i] = b.value
+    d["qm_M"] = ms; d["qm_M0"] = m0; d["qm_shift"] = sh
+    # image quantiser: a signed-range float image (non-trivial zero point) and a [0,1] image
+    for name, x in {"signed": rng.normal(0.2, 0.7, 500).astype(np.float32),
+                    "unit": rng.uniform(0, 1, 500).astype(np.float32)}.items():
+        out = np.zeros(x.size, np.uint8); s = C.c_float(); z = C.c_uint8()
+        xx = x.copy()
+        L.refdrv_quantize_image(xx.ctypes.data, x.size, out.ctypes.data, C.byref(s), C.byref(z))
+        d[f"qimg_{name}_x"] = x; d[f"qimg_{name}_u8"] = out
+        d[f"qimg_{name}_scale"] = np.float32(s.value); d[f"qimg_{name}_zp"] = np.uint8(z.value)
+    np.savez_compressed(os.path.join(HERE, "funcs.npz"), **d)
+    print("funcs: wrote", len(d), "arrays")
+
+
+def yolov3_tiny(tag, cfgname):
+    cfg = os.path.join(ROOT, "cfg", cfgname)
+    wts = f"/tmp/golden_{tag}.weights"
+    meta = synth.synth_weights(cfg, wts, seed=WEIGHT_SEED)
+    net, layers, x = run_ref(cfg, wts, img_seed=IMAGE_SEED)
+    out = {"cfg": cfgname, "weight_seed": WEIGHT_SEED, "image_seed": IMAGE_SEED, "weights_sha256": meta["sha256"],
+           "input_sha256": sha(x), "oracle": "reference default build (GPU=0 QUANTIZATION=1 -Ofast)", "layers": []}
+    for i, L in enumerate(layers):
+        e = {"i": i, "type": L.type}
+        if L.type == "conv":
+            a = net.layer_int32(i)
+            e["int32_sha256"] = sha(a)
+            e["int32_min"] = int(a.min()); e["int32_max"] = int(a.max())
+            p = net.prep(i)
+            e["prep_sha256"] = sha(np.concatenate([p["biases_int32"].view(np.uint8), p["M_value"].view(np.uint8),
+                                                   p["shift_value"].view(np.uint8)]))
+        if L.type != "yolo":
+            u = net.layer_u8(i)
+            e["u8_sha256"] = sha(u)
+            e["u8_head"] = u[:16].tolist()
+        if L.quant_stop or L.type == "yolo":
+            e["f32_sha256"] = sha(net.layer_f32(i))
+        if L.type == "conv" and L.quant_stop:
+            e["u8_hex"] = net.layer_u8(i).tobytes().hex()
+        out["layers"].append(e)
+    json.dump(out, open(os.path.join(HERE, f"yolov3_tiny_{tag}.json"), "w"), indent=1)
+    print(f"yolov3_tiny_{tag}: wrote {len(out['layers'])} layers")
+
+
+if __name__ == "__main__":
+    assert refdrv.available(), "run oracle/build_ref.sh first (needs /root/reference)"
+    tiny_unit(1, 1.0)
+    tiny_unit(2, 8.0)
+    funcs()
+    yolov3_tiny("leaky", "yolov3-tiny_quant.cfg")
+    yolov3_tiny("relu6", "yolov3-tiny_quant_relu6.cfg")

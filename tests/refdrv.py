@@ -1,0 +1,99 @@
+"""ctypes binding to oracle/_ref/libdarknet_ref*.so (the unmodified reference + oracle/ref_driver.c).
+TEST INFRASTRUCTURE: only tests/, bench.py's cpu_baseline leg and the golden generator may import this."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(_HERE, "..", "oracle", "_ref")
+
+
+def available(omp=False):
+    return os.path.exists(os.path.join(REF_DIR, "libdarknet_ref_omp.so" if omp else "libdarknet_ref.so"))
+
+
+_libs = {}
+
+
+def lib(omp=False):
+    if omp not in _libs:
+        L = C.CDLL(os.path.join(REF_DIR, "libdarknet_ref_omp.so" if omp else "libdarknet_ref.so"))
+        L.refdrv_load.restype = C.c_void_p
+        L.refdrv_load.argtypes = [C.c_char_p, C.c_char_p]
+        L.refdrv_nlayers.argtypes = [C.c_void_p]
+        L.refdrv_layer_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.refdrv_prepare.argtypes = [C.c_void_p, C.c_void_p]
+        L.refdrv_set_input_u8.argtypes = [C.c_void_p, C.c_void_p]
+        L.refdrv_input_u8.restype = C.c_void_p
+        L.refdrv_input_u8.argtypes = [C.c_void_p]
+        L.refdrv_forward.argtypes = [C.c_void_p, C.c_void_p]
+        L.refdrv_network_predict.restype = C.c_double
+        L.refdrv_network_predict.argtypes = [C.c_void_p, C.c_void_p]
+        for n in ("int32", "u8", "f32"):
+            f = getattr(L, "refdrv_layer_" + n)
+            f.restype = C.c_void_p
+            f.argtypes = [C.c_void_p, C.c_int]
+        L.refdrv_layer_prep.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        L.refdrv_gemm_u8.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_void_p, C.c_int]
+        L.refdrv_im2col_u8.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_uint8]
+        L.refdrv_quant_multiplier.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        L.refdrv_quantize_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _libs[omp] = L
+    return _libs[omp]
+
+
+INFO_KEYS = ["type", "out_c", "out_h", "out_w", "c", "h", "w", "n", "size", "stride", "pad", "activation",
+             "batch_normalize", "quantized", "quant_stop", "outputs"]
+# LAYER_TYPE enum values of the reference (include/darknet.h:99-130)
+T_CONV, T_MAXPOOL, T_ROUTE, T_UPSAMPLE, T_YOLO = 0, 3, 8, 26, 23
+
+
+def _as(ptr, n, dt):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dt)), shape=(n,))
+
+
+class RefNet:
+    def __init__(self, cfg, weights, omp=False):
+        self.L = lib(omp)
+        self.h = self.L.refdrv_load(cfg.encode(), weights.encode())
+        self.n = self.L.refdrv_nlayers(self.h)
+        self.info = []
+        for i in range(self.n):
+            a = (C.c_int * 16)()
+            self.L.refdrv_layer_info(self.h, i, a)
+            self.info.append(dict(zip(INFO_KEYS, list(a))))
+
+    def prepare(self, x_float_chw):
+        x = np.ascontiguousarray(x_float_chw, dtype=np.float32)
+        self._keep = x
+        assert self.L.refdrv_prepare(self.h, x.ctypes.data) == 0
+        n = x.size
+        return _as(self.L.refdrv_input_u8(self.h), n, C.c_uint8).copy()
+
+    def set_input_u8(self, x):
+        x = np.ascontiguousarray(x, dtype=np.uint8)
+        self.L.refdrv_set_input_u8(self.h, x.ctypes.data)
+
+    def forward(self):
+        t = np.zeros(self.n, dtype=np.float64)
+        assert self.L.refdrv_forward(self.h, t.ctypes.data) == 0
+        return t
+
+    def layer_int32(self, i):
+        return _as(self.L.refdrv_layer_int32(self.h, i), self.info[i]["outputs"], C.c_int32).copy()
+
+    def layer_u8(self, i):
+        return _as(self.L.refdrv_layer_u8(self.h, i), self.info[i]["outputs"], C.c_uint8).copy()
+
+    def layer_f32(self, i):
+        return _as(self.L.refdrv_layer_f32(self.h, i), self.info[i]["outputs"], C.c_float).copy()
+
+    def prep(self, i):
+        n = max(self.info[i]["n"], 1)
+        b = np.zeros(n, np.int32); mv = np.zeros(n, np.float64); sv = np.zeros(n, np.float64)
+        m0 = np.zeros(n, np.int32); sh = np.zeros(n, np.int32); q = np.zeros(4, np.float32)
+        self.L.refdrv_layer_prep(self.h, i, b.ctypes.data, mv.ctypes.data, sv.ctypes.data, m0.ctypes.data,
+                                 sh.ctypes.data, q.ctypes.data)
+        return dict(biases_int32=b, M_value=mv, shift_value=sv, M0=m0, shift=sh, s_in=q[0], zp_in=int(q[1]),
+                    s_act=q[2], zp_act=int(q[3]))
