@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s of the yolov3-tiny INT8 path on MI355X (BASELINE.json metric), with the dominant kernel's
+roofline and the reference's CPU path timed beside it.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the hot path (the plain-C darknet host's forward_network_gpu: input layout conversion + 24
+layer.forward_gpu launches) over one batch of 64 synthetic uint8 416x416 images that are already resident in HBM in
+the reference's [B][C][H][W] layout.  Images shard embarrassingly over the ranks (weak scaling, 64 per GPU); the only
+collective is a one-time RCCL broadcast of the packed quantized weights at start-up.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_INT8_TOPS = 256 * 4 * 2048 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs x 2048 int8 ops/clk/SIMD x 2.4 GHz = 5033 TOP/s dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--cfg", default=os.path.join(ROOT, "cfg", "yolov3-tiny_quant.cfg"))
+    ap.add_argument("--graph", action="store_true", help="replay the layer loop as a hipGraph (no per-layer events)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=8, help="bounded CPU-baseline sample (images through the reference)")
+    ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
+    return ap.parse_args()
+
+
+def conv_layer_work(info, batch):
+    """Algorithmic ops / bytes of one conv launch: 2*M*K*N ops, uint8 in + weights + uint8 out."""
+    K = info["c"] * info["size"] * info["size"]
+    N = info["out_h"] * info["out_w"] * batch
+    ops = 2.0 * info["n"] * K * N
+    byt = info["c"] * info["h"] * info["w"] * batch + info["n"] * K + info["n"] * N
+    return ops, byt
+
+
+def cpu_baseline(cfg, wts, nimg):
+    """The reference itself (oracle/_ref/libdarknet_ref.so, Makefile-default build, 1 thread) timed on this box's host
+    cores on a bounded sample; falls back to the CPU restatement ('port') if the prebuilt reference is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from yolo_quantization_amd import synth
+    x = synth.synth_image_u8(3, 416, 416, seed=7)
+    try:
+        import refdrv
+        if not refdrv.available():
+            raise FileNotFoundError("oracle/_ref not built")
+        net = refdrv.RefNet(cfg, wts)
+        net.prepare(synth.image_u8_to_float(x))
+        t0 = time.time()
+        for _ in range(nimg):
+            net.forward()
+        dt = time.time() - t0
+        kind = "reference"
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] reference CPU baseline unavailable ({e}); timing the oracle restatement instead", file=sys.stderr)
+        import oracle
+        onet = oracle.OracleNet(cfg, wts)
+        onet.prepare(np.float32(1.0 / 255.0), 0)
+        nimg = max(1, nimg // 4)
+        t0 = time.time()
+        for _ in range(nimg):
+            onet.forward(x, accum=oracle.ACC_REF_F32)
+        dt = time.time() - t0
+        kind = "port"
+    return {"value": nimg / dt, "unit": "images/s", "cores": 1, "kind": kind,
+            "sample": f"{nimg} x yolov3-tiny 416x416 image, whole net, batch 1, {os.cpu_count()} host cores present"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"[bench] --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    import numpy as np
+    import torch  # first: its bundled HIP runtime must be the one the process uses (same SONAME as /opt/rocm's)
+    if not torch.cuda.is_available():
+        print("[bench] no GPU visible: the INT8 path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from yolo_quantization_amd import binding, synth
+    binding.init(local_rank)
+    B = args.batch
+    wts = f"/tmp/bench_yolov3_tiny_{os.getpid()}.weights"
+
+    # ---- model: rank 0 reads the weights file, preps and packs; the packed bytes travel by RCCL broadcast
+    if rank == 0:
+        synth.synth_weights(args.cfg, wts, seed=1234)
+        net = binding.Net(args.cfg, wts, batch=B, gpu=local_rank, use_graph=args.graph)
+        net.prepare_fixed(1.0 / 255.0, 0)
+        packed = net.export_packed()
+        size_t = torch.tensor([packed.size], dtype=torch.int64, device=dev)
+    else:
+        net = binding.Net(args.cfg, None, batch=B, gpu=local_rank, use_graph=args.graph)
+        size_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    bcast_ms = 0.0
+    if world > 1:
+        dist.broadcast(size_t, 0)
+        nbytes = int(size_t.item())
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            blob.copy_(torch.from_numpy(packed))
+        torch.cuda.synchronize()
+        t0 = time.time()
+        dist.broadcast(blob, 0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.time() - t0) * 1e3
+        if rank != 0:
+            net.import_packed_gpu(blob.data_ptr(), nbytes)
+
+    # ---- synthetic input, resident in HBM in the reference layout before the timed region
+    x = synth.synth_image_u8(3, 416, 416, seed=1000 + rank, batch=B)
+    net.push_input(x)
+    net.sync()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        net.sync()
+
+    for _ in range(args.warmup):
+        net.forward()
+    barrier()
+    prof_steps = 0 if args.graph else min(args.steps, 64)
+    net.profile_begin(prof_steps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.forward()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    # ---- roofline of the dominant kernel (the MFMA implicit-GEMM conv), from HIP events on the launch stream
+    roof = None
+    layers = []
+    if prof_steps and rank == 0:
+        nprof, ms = net.profile_read()
+        mf_ops = mf_ms = 0.0
+        for i, inf in enumerate(net.info):
+            t_ms = float(ms[i + 1]) / nprof
+            row = {"i": i, "type": inf["type"], "ms": round(t_ms, 5)}
+            if inf["type"] == binding.T_CONV:
+                ops, byt = conv_layer_work(inf, B)
+                row.update(tops=round(ops / (t_ms * 1e-3) / 1e12, 2), gbs=round(byt / (t_ms * 1e-3) / 1e9, 1),
+                           k=inf["size"], c=inf["c"], n=inf["n"], hw=inf["out_h"])
+                if inf["c"] % 16 == 0:  # conv_igemm_i8_kernel launches (everything but the 3-channel first layer)
+                    mf_ops += ops
+                    mf_ms += t_ms
+            layers.append(row)
+        nlaunch = sum(1 for inf in net.info if inf["type"] == binding.T_CONV and inf["c"] % 16 == 0)
+        achieved = mf_ops / (mf_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm_i8_kernel (12 launches/step: all convs with c%16==0)",
+                "achieved": round(achieved, 2), "peak": round(PEAK_INT8_TOPS, 1), "unit": "TOP/s",
+                "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": None,
+                "ops_per_launch_avg": mf_ops / nlaunch, "ms_per_launch_avg": round(mf_ms / nlaunch, 5),
+                "input_layout_ms": round(float(ms[0]) / nprof, 5)}
+        if args.layers:
+            for r in layers:
+                print("[layer]", json.dumps(r), file=sys.stderr)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cfg, wts, args.cpu_images)
+
+    if rank == 0:
+        out = {"metric": "images/sec yolov3-tiny INT8 416x416", "value": round(value, 1), "unit": "images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x s8 -> int32 (f64 requant)",
+               "data": "synthetic",
+               "config": {"workload": "yolov3-tiny full net (cfg/yolov3-tiny_quant.cfg, leaky, per-channel quant), "
+                                      f"batch {B}/GPU synthetic uint8 416x416, inputs resident in HBM (NCHW uint8)",
+                          "global_batch": world * B, "parallelism": f"image-sharded x{world}, RCCL weight broadcast once",
+                          "launch": "hipGraph replay" if args.graph else "eager, per-layer HIP events",
+                          "weight_broadcast_ms": round(bcast_ms, 3)},
+               "roofline": roof, "cpu_baseline": cpu}
+        if layers:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            json.dump({"ms_per_step": ms_per_step, "layers": layers},
+                      open(os.path.join(ROOT, "gpurun_out", f"bench_layers_n{world}.json"), "w"), indent=1)
+        print(json.dumps(out), flush=True)
+    try:
+        os.remove(wts)
+    except OSError:
+        pass
+    net.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,177 @@
+/*
+ * darknet_q.h -- plain-C host side of the MI355X INT8 path (libdarknet_q.so, ./darknet).
+ *
+ * Mirrors the reference's host interface for the quantized inference path only, with the same names, argument
+ * meaning and error behaviour (die via error(), ref: src/utils.c:232-237), so a darknet user finds what they know:
+ *
+ *   struct layer { forward, forward_gpu, ... quant fields }   ref: include/darknet.h:154-226, 471-491
+ *   struct network                                            ref: include/darknet.h:562-639
+ *   parse_network_cfg / load_weights / load_network           ref: src/parser.c:682-815, 1201-1305; src/network.c:49
+ *   set_batch_network                                         ref: src/network.c:383-397
+ *   quantization_weights_and_activations                      ref: src/blas.c:259-346
+ *   forward_network / forward_network_gpu / network_predict   ref: src/network.c:229-261, 835-861, 570-581
+ *
+ * What differs, on purpose:
+ *   * `forward` (the CPU function pointer) is not a compute path here: it is set to a function that dies with a
+ *     message.  This build has exactly one data path, `forward_gpu` -> libmi355yolo.so (HIP, gfx950).
+ *   * the network carries a device uint8 activation pointer (the reference's GPU executor only threads floats,
+ *     ref: src/network.c:835-861) and batch > 1 means "the batch-1 function applied per image" (the reference's
+ *     epilogue handles image 0 only, ref: src/convolutional_layer.c:726-751).
+ *   * quantization_weights_and_activations() is idempotent (the reference's accumulates weights_sum_int and
+ *     re-folds batch-norm on every call, ref: src/blas.c:285-286,309 -- valid for the first call only, which is the
+ *     behaviour reproduced).
+ */
+#ifndef DARKNET_Q_H
+#define DARKNET_Q_H
+#include <stddef.h>
+#include <stdint.h>
+#include "mi355_yolo_int8.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same enumerator values as the reference (include/darknet.h:87-89, 99-130) */
+typedef enum { LOGISTIC = 0, RELU = 1, LINEAR = 3, RELU6 = 8, LEAKY = 9 } ACTIVATION;
+typedef enum { CONVOLUTIONAL = 0, MAXPOOL = 3, ROUTE = 8, YOLO = 23, UPSAMPLE = 26 } LAYER_TYPE;
+
+#define QUANT_POSITIVE_LIMIT 255
+#define QUANT_NEGATIVE_LIMIT 0
+
+struct network;
+typedef struct network network;
+struct layer;
+typedef struct layer layer;
+
+struct layer {
+    LAYER_TYPE type;
+    ACTIVATION activation;
+    void (*forward)(struct layer, struct network);     /* dies: no CPU data path in this build */
+    void (*forward_gpu)(struct layer, struct network); /* HIP path */
+
+    int batch, h, w, c, out_h, out_w, out_c;
+    int n, size, stride, pad, groups;
+    int inputs, outputs, nweights, batch_normalize;
+    int count; /* layer index */
+
+    /* quantization fields, same names as the reference */
+    int close_quantization, layer_quant_flag, quant_stop_flag, fisrt_time_train_fag;
+    float *input_data_uint8_scales, *activ_data_uint8_scales, *weight_data_uint8_scales;
+    uint8_t *input_data_uint8_zero_point, *activ_data_uint8_zero_point, *weight_data_uint8_zero_point;
+    int32_t *weights_sum_int;
+    uint32_t *mult_zero_point;
+    float *M;
+    int32_t *M0;
+    int *M0_right_shift;
+    double *M_value, *M0_right_shift_value;
+    uint8_t *weights_uint8;
+    int32_t *biases_int32;
+    float *biases, *scales, *rolling_mean, *rolling_variance;
+
+    /* route */
+    int *input_layers, *input_sizes;
+    /* yolo */
+    int classes, total;
+    int *mask;
+    float *anchors; /* the reference calls this l.biases for yolo layers */
+
+    /* host mirrors of the outputs, reference layout (filled by pull_layer_output) */
+    float *output;               /* [batch][outputs] float (quant_stop convs, yolo) */
+    int32_t *output_int32;       /* [batch][outputs] pre-requant accumulators (conv) */
+    uint8_t *output_uint8_final; /* [batch][outputs] */
+
+    /* device side */
+    mi355_tensor out_t;            /* PHWC uint8 activations */
+    void *blob_gpu;                /* packed weights + per-channel params (mi355_conv_pack) */
+    size_t blob_bytes;
+    void *blob_host;
+    uint8_t *weights_uint8_gpu;    /* raw weights / zero points for the ref-f32 verification mode */
+    uint8_t *weight_zero_point_gpu;
+    int32_t *output_int32_gpu;     /* reference layout; allocated only when net->dump_int32 */
+    float *output_gpu;             /* reference layout float (quant_stop convs, yolo) */
+    uint8_t *output_uint8_nchw_gpu; /* scratch for pull_layer_output */
+    int prepared;
+};
+
+struct network {
+    int n, batch;
+    layer *layers;
+    int h, w, c, inputs, outputs;
+    size_t *seen;
+    float *input;         /* host float CHW image(s) (layer-0 quantiser input) */
+    uint8_t *input_uint8; /* host [batch][c][h][w] */
+    float *output;
+    int train, index;
+    int close_quantization;
+
+    /* device side */
+    int gpu_index;
+    void *stream;
+    uint8_t *input_uint8_gpu; /* reference layout on the device */
+    mi355_tensor input_t;     /* cs==4 image tensor */
+    const mi355_tensor *cur_t; /* uint8 hand-off: the reference's `net.input_uint8 = l.output_uint8_final` */
+    const float *cur_f32_gpu;  /* float hand-off: `net.input = l.output` */
+
+    /* knobs (CLI: -accum exact|ref-f32, -parity wrap|saturate) */
+    int accum_mode, store_mode;
+    int dump_int32; /* keep int32 accumulators of every conv (parity runs) */
+    int verbose;
+    int prepared;
+    void *graph; /* hipGraph of the layer loop, built lazily when use_graph */
+    int use_graph;
+    /* per-layer HIP-event timing on net->stream (replaces the commented what_time_is_it_now() probes of
+     * ref: src/network.c:244-246) */
+    void **prof_ev;      /* [prof_cap][n+2] events */
+    int prof_cap, prof_used;
+};
+
+/* ---- construction / IO ------------------------------------------------------------------------------------ */
+network *parse_network_cfg(char *filename, int close_quantization);
+void load_weights(network *net, char *filename);
+network *load_network(char *cfg, char *weights, int clear);
+void set_batch_network(network *net, int b);
+void free_network(network *net);
+
+/* ---- host prep (M0/shift/biases_int32, packing, upload, device buffers) ------------------------------------ */
+void quant_multi_smaller_than_one_to_scale_and_shift(float real_multiplier, int32_t *quantized_multiplier,
+                                                     int *right_shift);
+void quant_image_with_min_max(int count, const float *input, uint8_t *out, float *scale, uint8_t *zero_point);
+void quantization_weights_and_activations(network *net);
+/* same, but with the layer-0 input scale / zero point given instead of derived from net->input (serving mode:
+ * uint8 images arrive already quantised) */
+void quantization_weights_and_activations_fixed_input(network *net, float in_scale, uint8_t in_zp);
+/* the host half of the prep only (per-channel integers + packed blobs, no device needed) */
+void quantization_prep_host(network *net, float in_scale, uint8_t in_zp);
+
+/* ---- execution ----------------------------------------------------------------------------------------------- */
+void forward_network(network *net);     /* == forward_network_gpu; dies if no device */
+void forward_network_gpu(network *net); /* input: net->input_uint8_gpu already holds [batch][c][h][w] uint8 */
+float *network_predict(network *net, float *input);
+/* upload net->input_uint8 (host) -> device */
+void push_network_input_uint8(network *net, const uint8_t *host_nchw);
+/* device -> host mirrors of layer i in the reference layout */
+void pull_layer_output(network *net, int i);
+
+/* per-layer profiling: record HIP events around every layer for the next `max_steps` forward passes (eager
+ * launches only), then read the per-layer sums in ms: out[0] = input layout conversion, out[1+i] = layer i. */
+void network_profile_begin(network *net, int max_steps);
+int network_profile_read(network *net, float *ms_sum /* [n+1] */);
+
+/* packed-weight exchange for multi-GPU start-up: rank 0 exports, the bytes travel by RCCL broadcast, the other
+ * ranks import into a network parsed from the same cfg (no weights file needed there). */
+size_t network_packed_size(network *net);
+void network_export_packed(network *net, void *buf);
+void network_import_packed(network *net, const void *buf, size_t bytes);
+/* same exchange with the buffer already on the device (what bench.py hands over after torch.distributed.broadcast) */
+void network_import_packed_gpu(network *net, const void *dev_buf, size_t bytes);
+
+/* misc */
+void error(const char *s);
+void file_error(const char *s);
+double what_time_is_it_now(void);
+const char *get_layer_string(LAYER_TYPE t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

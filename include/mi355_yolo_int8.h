@@ -1,0 +1,144 @@
+/*
+ * mi355_yolo_int8.h -- C-ABI of libmi355yolo.so: the MI355X (gfx950) INT8 quantized-convolution inference
+ * kernels for the darknet uint8-quantization fork ArtyZe/yolo_quantization.
+ *
+ * This is the drop-in boundary: plain C, raw device pointers and sizes, no HIP / torch types.  A darknet host
+ * (ours: yolo_quantization_amd/host, or the reference itself -- see INTEGRATION.md) binds these from the
+ * `layer.forward_gpu` function pointers (reference include/darknet.h:158-163).  Every entry point returns 0 on
+ * success or a negative MI355_E* code; nothing aborts, nothing falls back to the CPU.
+ *
+ * Paths cited as `ref:` are relative to the reference repository root.
+ *
+ * Device activation layout ("PHWC"): a tensor of B images x H x W pixels x C channels is an array of *cells*
+ * of `cs` bytes (cs >= C, cs % 16 == 0, or cs == 4 for the 3-channel network input):
+ *
+ *     cell(b, y, x) = lead + (b*(H+1) + (y+1))*(W+1) + x          0 <= y < H, 0 <= x < W
+ *
+ * Row 0 of every image block and column W of every row are *pad cells* shared between neighbours (the right pad
+ * of row y is the left pad of row y+1; the bottom pad row of image b is the top pad row of image b+1), so a 3x3
+ * tap is the constant cell offset dy*(W+1)+dx everywhere.  Pad cells hold the consumer's input zero point
+ * (ref: src/convolutional_layer.c:703-705,715 -- im2col pads with the input zero point).  Bytes are stored
+ * *biased*: stored = uint8 ^ 0x80, i.e. the signed value (uint8 - 128) that V_MFMA_I32_*_I8 consumes directly.
+ */
+#ifndef MI355_YOLO_INT8_H
+#define MI355_YOLO_INT8_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ---------------------------------------------------------------------------------------- */
+#define MI355_OK 0
+#define MI355_EINVAL (-22)   /* bad argument / unsupported shape */
+#define MI355_ENOMEM (-12)   /* device allocation failed */
+#define MI355_EHIP (-5)      /* HIP runtime error: mi355_last_error() has the text */
+#define MI355_ENODEV (-19)   /* no gfx950 device */
+
+/* ACTIVATION enum values of the reference (ref: include/darknet.h:87-89) */
+#define MI355_ACT_RELU 1
+#define MI355_ACT_LINEAR 3
+#define MI355_ACT_RELU6 8
+#define MI355_ACT_LEAKY 9
+
+/* uint8 store behaviour of the requantise epilogue */
+#define MI355_STORE_WRAP 0      /* ref default path: stored before clamp -> wraps mod 256 (convolutional_layer.c:737-749) */
+#define MI355_STORE_SATURATE 1  /* ref MKL path: clamp(0,255) then store (convolutional_layer.c:594) */
+
+/* accumulation semantics */
+#define MI355_ACC_EXACT 0    /* exact int32 on V_MFMA_I32_16X16X64_I8 (== ref MKL path, cblas_gemm_s16s16s32) */
+#define MI355_ACC_REF_F32 1  /* bit-faithful emulation of ref src/gemm.c:279-299 (fp32 step-wise accumulate,
+                                two passes); slow verification kernel, never on the throughput path */
+
+/* ---- runtime (replaces ref src/cuda.c: cuda_set_device :9, cuda_make_array :90-104, cuda_push/pull_array
+ *      :151-167, cuda_free :144-149, check_error :27-49) ---------------------------------------------------- */
+int mi355_init(int device);                       /* select device, verify gfx950 */
+const char *mi355_last_error(void);
+int mi355_device_count(void);
+int mi355_alloc(void **dptr, size_t bytes);
+int mi355_free(void *dptr);
+int mi355_memset(void *dptr, int byte, size_t bytes, void *stream);
+int mi355_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int mi355_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int mi355_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int mi355_stream_create(void **stream);
+int mi355_stream_destroy(void *stream);
+int mi355_stream_sync(void *stream);              /* stream == NULL: device synchronize */
+/* HIP events on the launch stream (bench.py times kernels with these, not with torch.cuda.Event) */
+int mi355_event_create(void **ev);
+int mi355_event_destroy(void *ev);
+int mi355_event_record(void *ev, void *stream);
+int mi355_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+/* hipGraph capture of a layer sequence (launch-bound tail of the net) */
+int mi355_graph_begin(void *stream);
+int mi355_graph_end(void *stream, void **graph_exec);
+int mi355_graph_launch(void *graph_exec, void *stream);
+int mi355_graph_destroy(void *graph_exec);
+
+/* ---- tensors ----------------------------------------------------------------------------------------------- */
+typedef struct mi355_tensor {
+    void *data;   /* device pointer to cell 0 */
+    int B, H, W;  /* images, rows, columns */
+    int C;        /* logical channels */
+    int cs;       /* bytes per cell */
+    int lead;     /* pad cells in front of image 0 */
+    int tail;     /* pad cells behind the last image */
+} mi355_tensor;
+
+/* Fill in cs/lead/tail for (B,H,W,C) and return the byte size of the buffer (0 on bad dims). data untouched. */
+size_t mi355_tensor_describe(mi355_tensor *t, int B, int H, int W, int C);
+/* Set every byte of the buffer (pads included) to the biased zero point (zp ^ 0x80). */
+int mi355_tensor_fill(const mi355_tensor *t, uint8_t zero_point, void *stream);
+/* Reference layout <-> device layout.  nchw is the reference's `net.input_uint8` / `l.output_uint8_final`
+ * layout [B][C][H][W] uint8 (ref: src/network.c:248-250), resident on the device. */
+int mi355_nchw_to_tensor(const uint8_t *nchw, const mi355_tensor *t, void *stream);
+int mi355_tensor_to_nchw(const mi355_tensor *t, uint8_t *nchw, void *stream);
+
+/* ---- quantized convolution ----------------------------------------------------------------------------- */
+/* Host-side packing of one conv layer's weights (replaces the per-forward operand prep of the reference: the
+ * `zero_point_uint8` table ref: src/blas.c:290-300 and GEMM pass 2 ref: src/convolutional_layer.c:721 are
+ * folded into per-channel constants).  weights_uint8: [n][c*k*k] in the reference's (ci,ky,kx) order
+ * (ref: src/parser.c:1146), zp_w: [n].  Returns the packed blob size; writes it when `blob` != NULL.
+ * The blob is position independent (offsets only) so it can be broadcast to other GPUs as bytes. */
+size_t mi355_conv_pack_size(int n, int c, int ksize);
+int mi355_conv_pack(int n, int c, int ksize, const uint8_t *weights_uint8, const uint8_t *zp_w,
+                    const int32_t *biases_int32, const double *M_value, const double *shift_value, void *blob);
+
+typedef struct mi355_conv_desc {
+    int n, c, ksize, stride, pad; /* filters, input channels, 1|3, 1, ksize/2 */
+    int activation;               /* MI355_ACT_* */
+    int store_mode;               /* MI355_STORE_* */
+    int accum_mode;               /* MI355_ACC_* */
+    uint8_t zp_in, zp_act;        /* input / activation zero points */
+    float s_act;                  /* activation scale (only for y_f32) */
+} mi355_conv_desc;
+
+/* forward_convolutional_layer_quant_inputi_outputi (ref: src/convolutional_layer.c:694-761) for a whole batch,
+ * "apply the batch-1 function independently per image".
+ *   x        input tensor (C == desc.c).  desc.c == 3 selects the first-layer kernel and x.cs must be 4.
+ *   blob     device copy of the mi355_conv_pack blob
+ *   w_u8     device copy of the raw weights_uint8 / zp_w (only read when accum_mode == MI355_ACC_REF_F32)
+ *   y        output tensor (C == desc.n), nullable
+ *   acc_out  nullable: pre-requant int32 accumulators, reference layout [B][n][H*W] == l.output_int32
+ *   y_f32    nullable: quant_stop tail (ref :752-760), reference layout [B][n][H*W] float == l.output */
+int mi355_conv_forward(const mi355_conv_desc *desc, const mi355_tensor *x, const void *blob, const uint8_t *w_u8,
+                       const uint8_t *zp_w, const mi355_tensor *y, int32_t *acc_out, float *y_f32, void *stream);
+
+/* Tile configuration override for benchmarking (0 = auto). */
+int mi355_conv_set_tile(int bm, int bn);
+
+/* ---- glue layers ---------------------------------------------------------------------------------------- */
+/* forward_maxpool_layer_quant (ref: src/maxpool_layer.c:109-172): window offset -pad/2, OOB taps = uint8 0 */
+int mi355_maxpool_forward(const mi355_tensor *x, const mi355_tensor *y, int size, int stride, int pad, void *stream);
+/* forward_upsample_layer_quant (ref: src/upsample_layer.c:96-113, src/blas.c:781-803), nearest x stride */
+int mi355_upsample_forward(const mi355_tensor *x, const mi355_tensor *y, int stride, void *stream);
+/* forward_route_layer_quant (ref: src/route_layer.c:107-130): channel concat of n inputs, no rescale */
+int mi355_route_forward(const mi355_tensor *const *xs, int n, const mi355_tensor *y, void *stream);
+/* yolo head activations (ref: src/yolo_layer.c:132-146) on the float head tensor [B][n*(classes+5)][H*W] */
+int mi355_yolo_forward(const float *in, float *out, int B, int n, int classes, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,334 @@
+"""GPU parity suite (`-m gpu`, runs on the MI355X box): every kernel is called through the C-ABI
+(libmi355yolo.so / libdarknet_q.so) and compared bit-for-bit with the oracle and the committed golden fixtures.
+Nothing here reads /root/reference."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from yolo_quantization_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    binding.init(0)
+
+
+def _rand_layer(rng, n, c, k, m_lo=2.0 ** -11, m_hi=2.0 ** -7):
+    K = c * k * k
+    wq = rng.integers(0, 256, (n, K), dtype=np.uint8)
+    zp_w = rng.integers(90, 166, n, dtype=np.uint8)
+    bias = rng.integers(-20000, 20000, n).astype(np.int32)
+    M = rng.uniform(m_lo, m_hi, n)
+    # realistic decomposition M = M0*2^-31 * 2^-shift
+    shift = np.floor(-np.log2(M)).astype(int)
+    M0 = np.round(M * 2.0 ** shift * 2 ** 31)
+    return wq, zp_w, bias, M0 * 2.0 ** -31, 2.0 ** -shift.astype(np.float64)
+
+
+def _oracle_layer(x, wq, zp_w, k, zp_in, bias, mv, sv, zp_act, act, store, accum):
+    B = x.shape[0]
+    accs, u8s = [], []
+    for b in range(B):
+        a = oracle.conv_acc(x[b], wq, zp_w, k, 1, k // 2, zp_in, accum)
+        accs.append(a)
+        u8s.append(oracle.requant(a, bias, mv, sv, zp_act, act, store))
+    return np.stack(accs), np.stack(u8s)
+
+
+CONV_CASES = [
+    # (B, c, n, H, W, k, act, zp_in, zp_act)   -- ragged tiles, odd sizes, every chunk width, n not multiple of 16
+    (1, 16, 32, 12, 12, 3, "leaky", 23, 23),
+    (3, 32, 64, 7, 5, 3, "relu6", 0, 0),
+    (2, 64, 128, 13, 13, 3, "leaky", 23, 23),
+    (2, 128, 30, 13, 13, 1, "linear", 23, 128),
+    (1, 384, 256, 26, 26, 3, "leaky", 23, 23),
+    (5, 256, 255, 13, 13, 1, "linear", 0, 128),
+    (2, 48, 40, 9, 11, 3, "relu", 7, 0),
+    (1, 16, 16, 40, 300, 3, "leaky", 200, 23),   # wide rows: halo >> tile
+    (1, 1024, 256, 13, 13, 1, "relu6", 0, 0),
+    (1, 512, 1024, 13, 13, 3, "leaky", 23, 23),  # K = 4608: the deep layer of the net
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "B%d_c%d_n%d_%dx%d_k%d_%s" % c[:7])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+def test_conv_mfma_bit_exact(case, store):
+    B, c, n, H, W, k, act, zp_in, zp_act = case
+    rng = np.random.default_rng(sum(v for v in case if isinstance(v, int)))
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, k)
+    xt = binding.DevTensor.from_nchw(x, zp_in)
+    got = binding.conv_forward(xt, wq, zp_w, k, bias, mv, sv, zp_in, zp_act, 0.05, binding.ACT[act], store,
+                               binding.ACC_EXACT, want_acc=True, want_f32=True)
+    acc, u8 = _oracle_layer(x, wq, zp_w, k, zp_in, bias, mv, sv, zp_act, oracle.ACT[act], store, oracle.ACC_EXACT)
+    assert np.array_equal(got["int32"], acc), "int32 pre-requant accumulators"
+    assert np.array_equal(got["u8"].reshape(B, n, H * W), u8), "uint8 activations"
+    f32 = oracle.dequant(u8, zp_act, np.float32(0.05))
+    assert np.array_equal(got["f32"], f32), "quant_stop float tail"
+    if store == binding.STORE_WRAP:
+        sat = np.stack([oracle.requant(acc[b], bias, mv, sv, zp_act, oracle.ACT[act], oracle.STORE_SATURATE) for b in range(B)])
+        assert (sat != u8).any(), "case should exercise out-of-range (wrap != saturate) elements"
+
+
+@pytest.mark.parametrize("bm,bn", [(128, 256), (128, 128), (64, 256), (64, 128), (32, 256), (32, 128)])
+def test_conv_every_tile_config(bm, bn):
+    """Force each compiled tile configuration on a shape it supports."""
+    n = {128: 256, 64: 64, 32: 32}[bm]
+    B, c, H, W, k = 2, 64, 20, 19, 3
+    rng = np.random.default_rng(bm * 7 + bn)
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, k)
+    xt = binding.DevTensor.from_nchw(x, 23)
+    binding.shim().mi355_conv_set_tile(bm, bn)
+    try:
+        got = binding.conv_forward(xt, wq, zp_w, k, bias, mv, sv, 23, 23, 1.0, binding.ACT["leaky"])
+    finally:
+        binding.shim().mi355_conv_set_tile(0, 0)
+    acc, u8 = _oracle_layer(x, wq, zp_w, k, 23, bias, mv, sv, 23, oracle.LEAKY, oracle.STORE_WRAP, oracle.ACC_EXACT)
+    assert np.array_equal(got["int32"], acc)
+    assert np.array_equal(got["u8"].reshape(B, n, H * W), u8)
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_conv_first_layer_kernel(n):
+    rng = np.random.default_rng(n)
+    B, H, W = 2, 33, 47
+    x = rng.integers(0, 256, (B, 3, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, 3, 3, 2.0 ** -9, 2.0 ** -6)
+    xt = binding.DevTensor.from_nchw(x, 5)
+    assert xt.t.cs == 4
+    got = binding.conv_forward(xt, wq, zp_w, 3, bias, mv, sv, 5, 23, 1.0, binding.ACT["leaky"])
+    acc, u8 = _oracle_layer(x, wq, zp_w, 3, 5, bias, mv, sv, 23, oracle.LEAKY, oracle.STORE_WRAP, oracle.ACC_EXACT)
+    assert np.array_equal(got["int32"], acc)
+    assert np.array_equal(got["u8"].reshape(B, n, H * W), u8)
+
+
+def test_conv_ref_f32_mode_reproduces_fp32_rounding():
+    """accum_mode REF_F32 == the oracle's bit-faithful restatement of src/gemm.c:279-299, on data whose running
+    sums exceed 2^24 (so it differs from exact integers)."""
+    rng = np.random.default_rng(5)
+    B, c, n, H, W, k = 1, 256, 32, 6, 6, 3
+    x = rng.integers(150, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, k)
+    wq = np.maximum(wq, 160)
+    xt = binding.DevTensor.from_nchw(x, 23)
+    got = binding.conv_forward(xt, wq, zp_w, k, bias, mv, sv, 23, 23, 1.0, binding.ACT["leaky"],
+                               accum=binding.ACC_REF_F32)
+    acc, u8 = _oracle_layer(x, wq, zp_w, k, 23, bias, mv, sv, 23, oracle.LEAKY, oracle.STORE_WRAP, oracle.ACC_REF_F32)
+    exact, _ = _oracle_layer(x, wq, zp_w, k, 23, bias, mv, sv, 23, oracle.LEAKY, oracle.STORE_WRAP, oracle.ACC_EXACT)
+    assert (acc != exact).any(), "test data must enter the fp32-rounding regime"
+    assert np.array_equal(got["int32"], acc)
+    assert np.array_equal(got["u8"].reshape(B, n, H * W), u8)
+
+
+@pytest.mark.parametrize("size,stride,H,W", [(2, 2, 12, 12), (2, 2, 13, 9), (2, 1, 13, 13), (3, 2, 11, 14)])
+def test_maxpool(size, stride, H, W):
+    rng = np.random.default_rng(size * 10 + stride)
+    B, c = 3, 32
+    pad = size - 1
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    xt = binding.DevTensor.from_nchw(x, 23)
+    oh, ow = (H + pad - size) // stride + 1, (W + pad - size) // stride + 1
+    y = binding.DevTensor(B, oh, ow, c, 23)
+    binding.check(binding.shim().mi355_maxpool_forward(xt.ref(), y.ref(), size, stride, pad, None), "maxpool")
+    want = np.stack([oracle.maxpool_u8(x[b], size, stride, pad) for b in range(B)])
+    assert np.array_equal(y.to_nchw(), want)
+
+
+def test_upsample_and_route():
+    rng = np.random.default_rng(9)
+    B = 2
+    a = rng.integers(0, 256, (B, 32, 5, 7), dtype=np.uint8)
+    b = rng.integers(0, 256, (B, 48, 10, 14), dtype=np.uint8)
+    at, bt = binding.DevTensor.from_nchw(a, 3), binding.DevTensor.from_nchw(b, 3)
+    up = binding.DevTensor(B, 10, 14, 32, 3)
+    binding.check(binding.shim().mi355_upsample_forward(at.ref(), up.ref(), 2, None), "upsample")
+    want_up = np.stack([oracle.upsample_u8(a[i], 2) for i in range(B)])
+    assert np.array_equal(up.to_nchw(), want_up)
+    out = binding.DevTensor(B, 10, 14, 80, 3)
+    import ctypes as C
+    arr = (C.POINTER(binding.Tensor) * 2)(C.pointer(up.t), C.pointer(bt.t))
+    binding.check(binding.shim().mi355_route_forward(arr, 2, out.ref(), None), "route")
+    assert np.array_equal(out.to_nchw(), np.concatenate([want_up, b], axis=1))
+
+
+def test_layout_roundtrip_and_pads():
+    rng = np.random.default_rng(11)
+    for shape in [(2, 3, 9, 13), (3, 16, 4, 6), (1, 30, 13, 13)]:
+        x = rng.integers(0, 256, shape, dtype=np.uint8)
+        t = binding.DevTensor.from_nchw(x, 77)
+        assert np.array_equal(t.to_nchw(), x)
+        raw = t.buf.to_numpy(np.uint8, t.buf.nbytes).reshape(-1, t.t.cs)
+        H, W = shape[2], shape[3]
+        # pad cells keep the (biased) zero point
+        padcell = raw[t.t.lead + W]  # column W of row 0 block
+        if t.t.cs == 4:
+            assert list(padcell) == [77, 77, 77, 0]
+        else:
+            assert (padcell == (77 ^ 0x80)).all()
+
+
+# ------------------------------------------------------------------------------------------------ whole networks
+def _run_host_net(cfg, wts, x_u8_batch, accum, store=binding.STORE_WRAP, graph=False, dump_int32=True):
+    B = x_u8_batch.shape[0]
+    net = binding.Net(cfg, wts, batch=B, accum=accum, store=store, dump_int32=dump_int32, use_graph=graph)
+    # the reference flow: float image -> dynamic layer-0 quantiser (identity on pinned full-range images)
+    xq = net.prepare_from_float(synth.image_u8_to_float(x_u8_batch))
+    assert np.array_equal(xq, x_u8_batch.ravel())
+    net.forward()
+    if graph:
+        net.forward()
+    net.sync()
+    outs = [net.pull(i) for i in range(net.n)]
+    info = net.info
+    net.close()
+    return outs, info
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("accum", [binding.ACC_EXACT, binding.ACC_REF_F32], ids=["exact", "ref_f32"])
+def test_tiny_unit_net_vs_reference_golden(golden_dir, cfg_dir, tmp_path, seed, accum):
+    """Full-tensor equality with the tensors the reference itself produced (tests/golden/tiny_unit_seed*.npz),
+    through the plain-C darknet host (cfg parser, weights reader, prep, layer.forward_gpu loop)."""
+    g = np.load(os.path.join(golden_dir, f"tiny_unit_seed{seed}.npz"))
+    cfg = os.path.join(cfg_dir, "tiny_unit.cfg")
+    wts = str(tmp_path / "w.weights")
+    meta = synth.synth_weights(cfg, wts, seed=seed, act_gain=float(g["act_gain"]))
+    assert meta["sha256"] == str(g["weights_sha256"])
+    x = g["input_u8"][None]
+    outs, info = _run_host_net(cfg, wts, x, accum)
+    for i, inf in enumerate(info):
+        if inf["type"] == binding.T_CONV:
+            assert np.array_equal(outs[i]["int32"], g[f"L{i}_int32"]), f"layer {i} int32"
+        if inf["type"] != binding.T_YOLO:
+            assert np.array_equal(outs[i]["u8"], g[f"L{i}_u8"]), f"layer {i} u8"
+        if inf["quant_stop"]:
+            assert np.array_equal(outs[i]["f32"], g[f"L{i}_f32"]), f"layer {i} f32"
+        if inf["type"] == binding.T_YOLO:
+            np.testing.assert_allclose(outs[i]["f32"], g[f"L{i}_f32"], rtol=0, atol=2e-7)  # float logistic: 1 ulp
+
+
+@pytest.mark.parametrize("tag", ["leaky", "relu6"])
+def test_yolov3_tiny_416_ref_f32_equals_reference_hashes(golden_dir, cfg_dir, tmp_path, tag):
+    """BASELINE config[0]: whole yolov3-tiny @416, one image, bit-faithful mode: per-layer SHA-256 of the int32
+    accumulators, uint8 activations and float heads equal the reference default build's."""
+    g = json.load(open(os.path.join(golden_dir, f"yolov3_tiny_{tag}.json")))
+    cfg = os.path.join(cfg_dir, g["cfg"])
+    wts = str(tmp_path / "w.weights")
+    assert synth.synth_weights(cfg, wts, seed=g["weight_seed"])["sha256"] == g["weights_sha256"]
+    x = synth.synth_image_u8(3, 416, 416, seed=g["image_seed"])[None]
+    outs, info = _run_host_net(cfg, wts, x, binding.ACC_REF_F32)
+    for e in g["layers"]:
+        i = e["i"]
+        if "int32_sha256" in e:
+            assert sha(outs[i]["int32"]) == e["int32_sha256"], f"layer {i} int32"
+        if "u8_sha256" in e:
+            assert sha(outs[i]["u8"]) == e["u8_sha256"], f"layer {i} u8"
+        if "f32_sha256" in e and e["type"] == "conv":
+            assert sha(outs[i]["f32"]) == e["f32_sha256"], f"layer {i} f32"
+
+
+@pytest.mark.parametrize("tag", ["leaky", "relu6"])
+def test_yolov3_tiny_416_exact_equals_oracle(golden_dir, cfg_dir, tmp_path, tag):
+    """Production mode (exact int32 on MFMA): whole net equals the oracle in exact mode on every tensor, and equals
+    the reference's hashes on every layer up to the first one where the reference's fp32 accumulation rounds."""
+    g = json.load(open(os.path.join(golden_dir, f"yolov3_tiny_{tag}.json")))
+    cfg = os.path.join(cfg_dir, g["cfg"])
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=g["weight_seed"])
+    x = synth.synth_image_u8(3, 416, 416, seed=g["image_seed"])
+    outs, info = _run_host_net(cfg, wts, x[None], binding.ACC_EXACT)
+    onet = oracle.OracleNet(cfg, wts)
+    onet.prepare(np.float32(1.0 / 255.0), 0)
+    want = onet.forward(x, accum=oracle.ACC_EXACT)
+    first_diverged = None
+    for i, inf in enumerate(info):
+        if inf["type"] == binding.T_CONV:
+            assert np.array_equal(outs[i]["int32"], want[i]["int32"].ravel()), f"layer {i} int32"
+        if inf["type"] != binding.T_YOLO:
+            assert np.array_equal(outs[i]["u8"], want[i]["u8"].ravel()), f"layer {i} u8"
+            if first_diverged is None and sha(outs[i]["u8"]) != g["layers"][i]["u8_sha256"]:
+                first_diverged = i
+        if inf["quant_stop"]:
+            assert np.array_equal(outs[i]["f32"], want[i]["f32"].ravel()), f"layer {i} f32"
+    # layers 0..9 have K <= 1152: 1152*255^2 > 2^24 is possible in theory, but the reference stays exact there on
+    # this model (tests/test_oracle_golden.py); the first rounding shows up at K >= 2304.
+    assert first_diverged is None or first_diverged >= 10
+
+
+def test_batch_is_per_image_independent(cfg_dir, tmp_path):
+    """batch > 1 == the batch-1 function applied to each image: a batch of different images equals the images run
+    alone, including ragged N tiles that straddle image boundaries."""
+    cfg = os.path.join(cfg_dir, "tiny_unit.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=1)
+    xs = synth.synth_image_u8(3, 12, 12, seed=99, batch=5)
+    outs, info = _run_host_net(cfg, wts, xs, binding.ACC_EXACT)
+    for b in range(5):
+        o1, _ = _run_host_net(cfg, wts, xs[b:b + 1], binding.ACC_EXACT)
+        for i, inf in enumerate(info):
+            per = inf["outputs"]
+            if inf["type"] != binding.T_YOLO:
+                assert np.array_equal(outs[i]["u8"][b * per:(b + 1) * per], o1[i]["u8"]), (b, i)
+            if inf["type"] == binding.T_CONV:
+                assert np.array_equal(outs[i]["int32"][b * per:(b + 1) * per], o1[i]["int32"]), (b, i)
+
+
+def test_yolov3_tiny_batch64_properties(cfg_dir, tmp_path):
+    """BASELINE config[2] at full size (batch 64 @416): size-independent properties -- identical images give
+    identical outputs in every batch slot (checksum of checksums), image 0 equals the batch-1 run, and hipGraph
+    replay gives the same bytes as eager launches."""
+    cfg = os.path.join(cfg_dir, "yolov3-tiny_quant.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=1234)
+    x = synth.synth_image_u8(3, 416, 416, seed=7)
+    xb = np.repeat(x[None], 64, axis=0)
+    xb[1::2] = synth.synth_image_u8(3, 416, 416, seed=8)  # two distinct images interleaved
+    outs, info = _run_host_net(cfg, wts, xb, binding.ACC_EXACT, graph=True, dump_int32=False)
+    one, _ = _run_host_net(cfg, wts, x[None], binding.ACC_EXACT)
+    for i, inf in enumerate(info):
+        if inf["type"] == binding.T_YOLO:
+            continue
+        per = inf["outputs"]
+        u = outs[i]["u8"].reshape(64, per)
+        assert np.array_equal(u[0], one[i]["u8"]), f"layer {i}: slot 0 != batch-1 run"
+        hs = [sha(u[b]) for b in range(64)]
+        assert len(set(hs[0::2])) == 1 and len(set(hs[1::2])) == 1, f"layer {i}: slots differ"
+        assert hs[0] != hs[1]
+
+
+def test_microbench_shape_vs_oracle_and_linearity():
+    """BASELINE config[1]: 3x3 s1 conv 256->256, 52x52, batch 32.  Oracle on 2 of the 32 images (full tensors) plus
+    properties at full size: duplicated images -> identical outputs; accumulators are linear in the weights:
+    acc(w1) + acc(w2) - acc(zero-weights) == acc(w1 + w2 - 0) when w1 + w2 stays in uint8."""
+    rng = np.random.default_rng(1)
+    B, c, n, H, W, k = 32, 256, 256, 52, 52, 3
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    x[5] = x[2]
+    wq, zp_w, bias, mv, sv = _rand_layer(np.random.default_rng(2), n, c, k, 2.0 ** -10, 2.0 ** -9)
+    zp_w = np.random.default_rng(3).integers(100, 157, n, dtype=np.uint8)
+    xt = binding.DevTensor.from_nchw(x, 0)
+    got = binding.conv_forward(xt, wq, zp_w, k, bias, mv, sv, 0, 23, 1.0, binding.ACT["leaky"])
+    for b in (0, 31):
+        acc = oracle.conv_acc(x[b], wq, zp_w, k, 1, 1, 0, oracle.ACC_EXACT)
+        assert np.array_equal(got["int32"][b], acc), f"image {b} accumulators"
+        u8 = oracle.requant(acc, bias, mv, sv, 23, oracle.LEAKY, oracle.STORE_WRAP)
+        assert np.array_equal(got["u8"][b].reshape(n, H * W), u8), f"image {b} uint8"
+    assert np.array_equal(got["int32"][5], got["int32"][2])
+    # linearity in the weights (zero points fixed): acc is sum (w - zp) x
+    w1 = (wq // 2).astype(np.uint8); w2 = (wq - w1).astype(np.uint8)
+    z = np.zeros_like(wq)
+    a1 = binding.conv_forward(xt, w1, zp_w, k, bias, mv, sv, 0, 23, 1.0, binding.ACT["leaky"])["int32"].astype(np.int64)
+    a2 = binding.conv_forward(xt, w2, zp_w, k, bias, mv, sv, 0, 23, 1.0, binding.ACT["leaky"])["int32"].astype(np.int64)
+    a0 = binding.conv_forward(xt, z, zp_w, k, bias, mv, sv, 0, 23, 1.0, binding.ACT["leaky"])["int32"].astype(np.int64)
+    assert np.array_equal(a1 + a2 - a0, got["int32"].astype(np.int64))

@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, bench, rocprofv3 kernel trace.  Everything lands in gpurun_out/.
+# usage: tools/gpu_session.sh [tests|bench|prof|all]
+set -uo pipefail
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+what=${1:-all}
+export TMPDIR=/tmp
+if [[ $what == all || $what == tests ]]; then
+  timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 | tee gpurun_out/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
+fi
+if [[ $what == all || $what == bench ]]; then
+  timeout 900 python bench.py --steps 20 --warmup 3 --layers 2>gpurun_out/bench.err | tee gpurun_out/bench.json
+  tail -40 gpurun_out/bench.err
+fi
+if [[ $what == all || $what == prof ]]; then
+  rm -rf gpurun_out/prof
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r01 -- \
+      python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err" )
+  find gpurun_out/prof -name "*stats*" | head
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && head -30 "$f"
+fi

@@ -44,8 +44,9 @@ def yolov3_tiny(act, classes=5, w=416, h=416):
     return s
 
 def tiny_unit(act="leaky"):
-    # 12x12 input, exercises every quantised layer type + both maxpool geometries + multi-input route
-    s = net(12, 12, c=8)
+    # 12x12x3 input, exercises the first-layer kernel, every quantised layer type, both maxpool geometries and a
+    # multi-input route
+    s = net(12, 12, c=3)
     s += conv(16, 3, act)            # 0
     s += maxpool(2, 2)               # 1   6x6
     s += conv(32, 3, act)            # 2

@@ -1,0 +1,65 @@
+// common.h -- device-side helpers shared by the gfx950 kernels (CDNA4 only; no CUDA compatibility layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mi355_yolo_int8.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------
+// Packed conv blob (position independent; see mi355_conv_pack in shim.hip).
+// Weights are stored signed-biased (w_u8 - 128) in "unit" order: a unit is 16 consecutive input channels of one
+// tap; the K axis is  for chunk (cb bytes of channels)  for tap (ky,kx)  for 16-channel block.  One MFMA K-step
+// (64 bytes) = 4 units.  Rows are grouped by 16 output channels: [mpad/16][ksteps][16 rows][64 bytes].
+// ---------------------------------------------------------------------------------------------------------
+#define MI355_BLOB_MAGIC 0x4D493335u /* "MI35" */
+struct ConvBlobHeader {
+    uint32_t magic;
+    int32_t n, c, ksize;
+    int32_t mpad;       // n rounded up to 16
+    int32_t cb;         // channel-chunk bytes per cell: 64, 32 or 16 (4 for the 3-channel first layer)
+    int32_t nchunks;    // c / cb
+    int32_t upc;        // valid units per chunk = ksize*ksize*(cb/16)
+    int32_t spc;        // K-steps per chunk = ceil(upc/4)
+    int32_t ksteps;     // nchunks*spc
+    int32_t ktrue;      // c*ksize*ksize
+    int32_t first;      // 1: first-layer (c==3) packing: wp = [n][9] dwords (ky,kx)(c0,c1,c2,0) plain uint8
+    uint64_t off_wp, off_cw, off_dzp, off_bias, off_mval, off_sval;  // byte offsets from blob start
+    uint64_t total;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Requantise epilogue: ref src/convolutional_layer.c:726-751.  FP64 with two truncations, activation, zero point,
+// uint8 store that wraps (default path) or saturates (MKL path).  `acc` is the true pre-requant accumulator.
+// Compile with -ffp-contract=off: every double op below must stay a separate IEEE operation.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t requant_u8(int32_t acc, int32_t bias, double M, double S, int zp_act, int act,
+                                               int store_mode)
+{
+    long long t = (long long)((double)(acc + bias) * M);  // :732  int64_t temp = (acc + bias) * M_value
+    int32_t q = (int32_t)((double)t * S);                  // :733  q = temp * 2^-shift
+    int32_t v;
+    if (act == MI355_ACT_LEAKY) {
+        // :737  q < 0 ? round(q*0.1) + zp : q + zp   (double arithmetic, round half away from zero)
+        double d = q < 0 ? (round((double)q * 0.1) + (double)zp_act) : (double)(q + zp_act);
+        v = (int32_t)d;
+    } else if (act == MI355_ACT_RELU6) {
+        v = q <= 0 ? zp_act : q + zp_act;  // :744
+    } else {
+        v = q + zp_act;  // :740-742 LINEAR, RELU
+    }
+    if (store_mode == MI355_STORE_SATURATE) v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    return (uint32_t)v & 0xFFu;  // uint8_t store: modular
+}
+
+// cell index of pixel n (n enumerates b,y,x) in a PHWC tensor
+__device__ __forceinline__ int cell_of_pixel(int n, int H, int W, int lead)
+{
+    int hw = H * W;
+    int b = n / hw;
+    int r = n - b * hw;
+    int y = r / W;
+    int x = r - y * W;
+    return lead + (b * (H + 1) + (y + 1)) * (W + 1) + x;
+}

@@ -1,0 +1,69 @@
+// kargs.h -- kernel argument blocks and host-side launcher prototypes shared by the translation units.
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    const int8_t *x;
+    const int8_t *wp;
+    const int32_t *cw, *dzp, *bias;
+    const double *mval, *sval;
+    uint8_t *y;
+    int32_t *acc_out;
+    float *y_f32;
+    int in_cs, in_lead, in_cells;
+    int out_cs, out_lead;
+    int B, H, W, n;
+    int ksize, cb, nchunks, upc, spc, ksteps;
+    int total_n, ntiles_n, mtiles;
+    int zp_act, act, store_mode;
+    float s_act;
+    int ncell_cap;
+    int mpad;
+};
+
+struct AuxArgs {
+    const uint8_t *x;  // input tensor (cs==4: plain uint8 image cells; else biased PHWC)
+    int in_cs, in_lead, in_cells;
+    const uint32_t *wfirst;  // first-layer packing [n][9] dwords
+    const uint8_t *w_u8;     // raw reference weights [n][c*k*k] (ref-f32 kernel)
+    const uint8_t *zp_w;     // [n]
+    const int32_t *dzp, *bias;
+    const double *mval, *sval;
+    uint8_t *y;
+    int out_cs, out_lead;
+    int32_t *acc_out;
+    float *y_f32;
+    int B, H, W, c, n, ksize, pad;
+    int zp_in, zp_act, act, store_mode;
+    float s_act;
+    int total_n;
+};
+
+struct PoolArgs {
+    const uint8_t *x;
+    uint8_t *y;
+    int B, H, W, OH, OW, cs_in, cs_out, in_lead, out_lead, groups;  // groups = C/16
+    int size, stride, offset;                                       // offset = -pad/2
+};
+
+struct CopyArgs {
+    const uint8_t *x;
+    uint8_t *y;
+    int B, H, W, OH, OW, cs_in, cs_out, in_lead, out_lead, groups, stride, coff;  // coff: channel offset in y
+};
+
+struct LayoutArgs {
+    uint8_t *nchw;
+    uint8_t *t;
+    int B, H, W, C, cs, lead;
+};
+
+int conv_igemm_launch(ConvArgs &a, hipStream_t st);
+int conv_first_launch(AuxArgs &a, hipStream_t st);
+int conv_ref_f32_launch(AuxArgs &a, hipStream_t st);
+int maxpool_launch(const PoolArgs &a, hipStream_t st);
+int copy_cells_launch(const CopyArgs &a, hipStream_t st);
+int nchw_to_phwc_launch(const LayoutArgs &a, hipStream_t st);
+int phwc_to_nchw_launch(const LayoutArgs &a, hipStream_t st);
+int fill_u32_launch(uint32_t *p, uint32_t v, long n, hipStream_t st);
+int yolo_logistic_launch(const float *in, float *out, int B, int n, int classes, int hw, hipStream_t st);

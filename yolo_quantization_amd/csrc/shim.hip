@@ -1,0 +1,409 @@
+// shim.hip -- the C-ABI of libmi355yolo.so (include/mi355_yolo_int8.h): runtime helpers, tensor descriptors,
+// weight packing and kernel launch wrappers.  HIP only; no CUDA-compat headers, no CPU fallback: if the device or
+// a kernel is unavailable the call fails with a negative code.
+#include "kargs.h"
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+
+
+static thread_local char g_err[512] = "";
+static int hip_fail(hipError_t e, const char *what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return MI355_EHIP;
+}
+#define HIPCHK(call)                                      \
+    do {                                                  \
+        hipError_t e__ = (call);                          \
+        if (e__ != hipSuccess) return hip_fail(e__, #call); \
+    } while (0)
+static int einval(const char *msg)
+{
+    snprintf(g_err, sizeof(g_err), "invalid argument: %s", msg);
+    return MI355_EINVAL;
+}
+
+extern "C" {
+
+const char *mi355_last_error(void) { return g_err; }
+
+int mi355_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mi355_init(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        snprintf(g_err, sizeof(g_err), "no HIP device visible (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        return MI355_ENODEV;
+    }
+    if (device < 0 || device >= n) return einval("device index");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_err, sizeof(g_err), "device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                 p.gcnArchName);
+        return MI355_ENODEV;
+    }
+    return MI355_OK;
+}
+
+int mi355_alloc(void **dptr, size_t bytes)
+{
+    if (!dptr) return einval("dptr");
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e == hipErrorOutOfMemory) {
+        snprintf(g_err, sizeof(g_err), "hipMalloc(%zu) out of memory", bytes);
+        return MI355_ENOMEM;
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    return MI355_OK;
+}
+int mi355_free(void *dptr)
+{
+    HIPCHK(hipFree(dptr));
+    return MI355_OK;
+}
+int mi355_memset(void *dptr, int byte, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemsetAsync(dptr, byte, bytes, (hipStream_t)stream));
+    return MI355_OK;
+}
+int mi355_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return MI355_OK;
+}
+int mi355_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return MI355_OK;
+}
+int mi355_d2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MI355_OK;
+}
+int mi355_stream_create(void **stream)
+{
+    hipStream_t s;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return MI355_OK;
+}
+int mi355_stream_destroy(void *stream)
+{
+    HIPCHK(hipStreamDestroy((hipStream_t)stream));
+    return MI355_OK;
+}
+int mi355_stream_sync(void *stream)
+{
+    if (stream) HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    else HIPCHK(hipDeviceSynchronize());
+    return MI355_OK;
+}
+int mi355_event_create(void **ev)
+{
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    *ev = e;
+    return MI355_OK;
+}
+int mi355_event_destroy(void *ev)
+{
+    HIPCHK(hipEventDestroy((hipEvent_t)ev));
+    return MI355_OK;
+}
+int mi355_event_record(void *ev, void *stream)
+{
+    HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return MI355_OK;
+}
+int mi355_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    HIPCHK(hipEventSynchronize((hipEvent_t)stop));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return MI355_OK;
+}
+int mi355_graph_begin(void *stream)
+{
+    HIPCHK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return MI355_OK;
+}
+int mi355_graph_end(void *stream, void **graph_exec)
+{
+    hipGraph_t g;
+    HIPCHK(hipStreamEndCapture((hipStream_t)stream, &g));
+    hipGraphExec_t ge;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate");
+    *graph_exec = ge;
+    return MI355_OK;
+}
+int mi355_graph_launch(void *graph_exec, void *stream)
+{
+    HIPCHK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return MI355_OK;
+}
+int mi355_graph_destroy(void *graph_exec)
+{
+    HIPCHK(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return MI355_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- tensors
+static size_t tensor_cells(const mi355_tensor *t)
+{
+    return (size_t)t->lead + (size_t)t->B * (t->H + 1) * (t->W + 1) + t->tail;
+}
+
+size_t mi355_tensor_describe(mi355_tensor *t, int B, int H, int W, int C)
+{
+    if (!t || B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    t->B = B; t->H = H; t->W = W; t->C = C;
+    t->cs = (C == 3) ? 4 : ((C + 15) / 16) * 16;
+    t->lead = 2;
+    t->tail = W + 3;
+    return tensor_cells(t) * (size_t)t->cs;
+}
+
+int mi355_tensor_fill(const mi355_tensor *t, uint8_t zero_point, void *stream)
+{
+    if (!t || !t->data) return einval("tensor");
+    const size_t cells = tensor_cells(t);
+    if (t->cs == 4) {
+        const uint32_t v = (uint32_t)zero_point | ((uint32_t)zero_point << 8) | ((uint32_t)zero_point << 16);
+        return fill_u32_launch((uint32_t *)t->data, v, (long)cells, (hipStream_t)stream);
+    }
+    HIPCHK(hipMemsetAsync(t->data, zero_point ^ 0x80, cells * t->cs, (hipStream_t)stream));
+    return MI355_OK;
+}
+
+int mi355_nchw_to_tensor(const uint8_t *nchw, const mi355_tensor *t, void *stream)
+{
+    if (!nchw || !t || !t->data) return einval("nchw_to_tensor");
+    LayoutArgs a{const_cast<uint8_t *>(nchw), (uint8_t *)t->data, t->B, t->H, t->W, t->C, t->cs, t->lead};
+    return nchw_to_phwc_launch(a, (hipStream_t)stream);
+}
+int mi355_tensor_to_nchw(const mi355_tensor *t, uint8_t *nchw, void *stream)
+{
+    if (!nchw || !t || !t->data) return einval("tensor_to_nchw");
+    LayoutArgs a{nchw, (uint8_t *)t->data, t->B, t->H, t->W, t->C, t->cs, t->lead};
+    return phwc_to_nchw_launch(a, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- weight packing
+static int default_bm(int n) { return n >= 128 ? 128 : (n > 32 ? 64 : 32); }
+static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+static int blob_layout(int n, int c, int ksize, ConvBlobHeader *h)
+{
+    if (n <= 0 || c <= 0 || (ksize != 1 && ksize != 3)) return MI355_EINVAL;
+    memset(h, 0, sizeof(*h));
+    h->magic = MI355_BLOB_MAGIC;
+    h->n = n; h->c = c; h->ksize = ksize;
+    h->ktrue = c * ksize * ksize;
+    size_t off = align16(sizeof(ConvBlobHeader));
+    if (c == 3 && ksize == 3) {
+        h->first = 1;
+        h->mpad = ((n + 3) / 4) * 4;
+        h->cb = 4; h->nchunks = 1; h->upc = 9; h->spc = 9; h->ksteps = 9;
+        h->off_wp = off; off = align16(off + (size_t)h->mpad * 9 * 4);
+    } else {
+        if (c % 16) return MI355_EINVAL;
+        const int bm = default_bm(n);
+        h->mpad = ((n + bm - 1) / bm) * bm;
+        h->cb = (c % 64 == 0) ? 64 : (c % 32 == 0 ? 32 : 16);
+        h->nchunks = c / h->cb;
+        h->upc = ksize * ksize * (h->cb / 16);
+        h->spc = (h->upc + 3) / 4;
+        h->ksteps = h->nchunks * h->spc;
+        h->off_wp = off; off = align16(off + (size_t)h->mpad * h->ksteps * 64);
+    }
+    h->off_cw = off;   off = align16(off + (size_t)h->mpad * 4);
+    h->off_dzp = off;  off = align16(off + (size_t)h->mpad * 4);
+    h->off_bias = off; off = align16(off + (size_t)h->mpad * 4);
+    h->off_mval = off; off = align16(off + (size_t)h->mpad * 8);
+    h->off_sval = off; off = align16(off + (size_t)h->mpad * 8);
+    h->total = off;
+    return MI355_OK;
+}
+
+size_t mi355_conv_pack_size(int n, int c, int ksize)
+{
+    ConvBlobHeader h;
+    if (blob_layout(n, c, ksize, &h) != MI355_OK) return 0;
+    return (size_t)h.total;
+}
+
+int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *zp_w, const int32_t *biases_int32,
+                    const double *M_value, const double *shift_value, void *blob)
+{
+    ConvBlobHeader h;
+    if (blob_layout(n, c, ksize, &h) != MI355_OK) return einval("conv_pack: need ksize 1|3 and c==3 or c%16==0");
+    if (!wq || !zp_w || !biases_int32 || !M_value || !shift_value || !blob) return einval("conv_pack: null");
+    char *base = (char *)blob;
+    memset(base, 0, (size_t)h.total);
+    memcpy(base, &h, sizeof(h));
+    int32_t *cw = (int32_t *)(base + h.off_cw), *dzp = (int32_t *)(base + h.off_dzp);
+    int32_t *bias = (int32_t *)(base + h.off_bias);
+    double *mval = (double *)(base + h.off_mval), *sval = (double *)(base + h.off_sval);
+    const int K = h.ktrue;
+    for (int oc = 0; oc < n; ++oc) {
+        bias[oc] = biases_int32[oc];
+        mval[oc] = M_value[oc];
+        sval[oc] = shift_value[oc];
+        const int d = 128 - (int)zp_w[oc];
+        dzp[oc] = d;
+        long sw = 0;
+        for (int k = 0; k < K; ++k) sw += (int)wq[(size_t)oc * K + k] - 128;
+        cw[oc] = (int32_t)(128 * sw + 128L * K * d);  // 128*sum(w') + 128*K*d   (|.| < 2^28 for K <= 9216)
+    }
+    if (h.first) {
+        uint32_t *wp = (uint32_t *)(base + h.off_wp);
+        for (int oc = 0; oc < n; ++oc)
+            for (int t = 0; t < 9; ++t) {
+                uint32_t v = 0;
+                for (int ci = 0; ci < 3; ++ci) v |= (uint32_t)wq[(size_t)oc * K + ci * 9 + t] << (8 * ci);
+                wp[oc * 9 + t] = v;
+            }
+        return MI355_OK;
+    }
+    int8_t *wp = (int8_t *)(base + h.off_wp);
+    const int bpc = h.cb / 16;
+    for (int oc = 0; oc < n; ++oc) {
+        const int mt = oc / 16, row = oc % 16;
+        for (int chunk = 0; chunk < h.nchunks; ++chunk)
+            for (int s = 0; s < h.spc; ++s) {
+                const int g = chunk * h.spc + s;
+                int8_t *dst = wp + ((size_t)mt * h.ksteps + g) * 1024 + row * 64;
+                for (int kg = 0; kg < 4; ++kg) {
+                    const int u = 4 * s + kg;
+                    if (u >= h.upc) continue;
+                    const int tap = u / bpc, blk = u % bpc;
+                    const int ky = tap / ksize, kx = tap % ksize;
+                    for (int e = 0; e < 16; ++e) {
+                        const int ci = chunk * h.cb + blk * 16 + e;
+                        const uint8_t w = wq[(size_t)oc * K + (ci * ksize + ky) * ksize + kx];  // (ci,ky,kx) order
+                        dst[kg * 16 + e] = (int8_t)(w ^ 0x80);
+                    }
+                }
+            }
+    }
+    return MI355_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ convolution
+int mi355_conv_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const uint8_t *w_u8,
+                       const uint8_t *zp_w, const mi355_tensor *y, int32_t *acc_out, float *y_f32, void *stream)
+{
+    if (!d || !x || !x->data || !blob) return einval("conv_forward: null");
+    if (d->stride != 1) return einval("conv_forward: stride must be 1 (3x3 s1 / 1x1 of yolov3-tiny)");
+    if (!((d->ksize == 3 && d->pad == 1) || (d->ksize == 1 && d->pad == 0))) return einval("conv_forward: ksize/pad");
+    if (x->C != d->c) return einval("conv_forward: x.C != desc.c");
+    if (y && (y->C != d->n || y->B != x->B || y->H != x->H || y->W != x->W || !y->data))
+        return einval("conv_forward: y shape");
+    ConvBlobHeader h;
+    if (blob_layout(d->n, d->c, d->ksize, &h) != MI355_OK) return einval("conv_forward: shape");
+    const char *base = (const char *)blob;
+    hipStream_t st = (hipStream_t)stream;
+    const int total_n = x->B * x->H * x->W;
+    const int in_cells = (int)tensor_cells(x);
+
+    if (d->accum_mode == MI355_ACC_REF_F32 || h.first) {
+        AuxArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = (const uint8_t *)x->data; a.in_cs = x->cs; a.in_lead = x->lead; a.in_cells = in_cells;
+        a.wfirst = (const uint32_t *)(base + h.off_wp);
+        a.w_u8 = w_u8; a.zp_w = zp_w;
+        a.dzp = (const int32_t *)(base + h.off_dzp); a.bias = (const int32_t *)(base + h.off_bias);
+        a.mval = (const double *)(base + h.off_mval); a.sval = (const double *)(base + h.off_sval);
+        a.y = y ? (uint8_t *)y->data : nullptr; a.out_cs = y ? y->cs : 0; a.out_lead = y ? y->lead : 0;
+        a.acc_out = acc_out; a.y_f32 = y_f32;
+        a.B = x->B; a.H = x->H; a.W = x->W; a.c = d->c; a.n = d->n; a.ksize = d->ksize; a.pad = d->pad;
+        a.zp_in = d->zp_in; a.zp_act = d->zp_act; a.act = d->activation; a.store_mode = d->store_mode;
+        a.s_act = d->s_act; a.total_n = total_n;
+        if (d->accum_mode == MI355_ACC_REF_F32) {
+            if (!w_u8 || !zp_w) return einval("conv_forward: ref-f32 mode needs the raw weights_uint8 / zp_w");
+            return conv_ref_f32_launch(a, st);
+        }
+        if (x->cs != 4) return einval("conv_forward: first layer expects a cs==4 image tensor");
+        return conv_first_launch(a, st);
+    }
+    if (x->cs % 16) return einval("conv_forward: x.cs must be a multiple of 16");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const int8_t *)x->data; a.wp = (const int8_t *)(base + h.off_wp);
+    a.cw = (const int32_t *)(base + h.off_cw); a.dzp = (const int32_t *)(base + h.off_dzp);
+    a.bias = (const int32_t *)(base + h.off_bias);
+    a.mval = (const double *)(base + h.off_mval); a.sval = (const double *)(base + h.off_sval);
+    a.y = y ? (uint8_t *)y->data : nullptr; a.acc_out = acc_out; a.y_f32 = y_f32;
+    a.in_cs = x->cs; a.in_lead = x->lead; a.in_cells = in_cells;
+    a.out_cs = y ? y->cs : 0; a.out_lead = y ? y->lead : 0;
+    a.B = x->B; a.H = x->H; a.W = x->W; a.n = d->n;
+    a.ksize = d->ksize; a.cb = h.cb; a.nchunks = h.nchunks; a.upc = h.upc; a.spc = h.spc; a.ksteps = h.ksteps;
+    a.total_n = total_n;
+    a.zp_act = d->zp_act; a.act = d->activation; a.store_mode = d->store_mode; a.s_act = d->s_act;
+    a.mpad = h.mpad;
+    int rc = conv_igemm_launch(a, st);
+    if (rc == MI355_EINVAL) return einval("conv_forward: no tile configuration fits this shape");
+    if (rc != MI355_OK) return hip_fail(hipGetLastError(), "conv_igemm launch");
+    return rc;
+}
+
+// -------------------------------------------------------------------------------------------------------- glue
+int mi355_maxpool_forward(const mi355_tensor *x, const mi355_tensor *y, int size, int stride, int pad, void *stream)
+{
+    if (!x || !y || !x->data || !y->data) return einval("maxpool: null");
+    if (x->cs % 16 || y->cs % 16 || x->C != y->C || x->B != y->B) return einval("maxpool: layout");
+    const int oh = (x->H + pad - size) / stride + 1, ow = (x->W + pad - size) / stride + 1;  // ref :31-32
+    if (oh != y->H || ow != y->W) return einval("maxpool: output dims");
+    PoolArgs a{(const uint8_t *)x->data, (uint8_t *)y->data, x->B, x->H, x->W, oh, ow, x->cs, y->cs, x->lead, y->lead,
+               x->cs / 16, size, stride, -pad / 2};
+    return maxpool_launch(a, (hipStream_t)stream);
+}
+
+int mi355_upsample_forward(const mi355_tensor *x, const mi355_tensor *y, int stride, void *stream)
+{
+    if (!x || !y || !x->data || !y->data) return einval("upsample: null");
+    if (x->cs % 16 || y->cs % 16 || x->C != y->C || x->B != y->B || y->H != x->H * stride || y->W != x->W * stride)
+        return einval("upsample: shape");
+    CopyArgs a{(const uint8_t *)x->data, (uint8_t *)y->data, x->B, x->H, x->W, y->H, y->W, x->cs, y->cs, x->lead,
+               y->lead, x->cs / 16, stride, 0};
+    return copy_cells_launch(a, (hipStream_t)stream);
+}
+
+int mi355_route_forward(const mi355_tensor *const *xs, int n, const mi355_tensor *y, void *stream)
+{
+    if (!xs || n <= 0 || !y || !y->data) return einval("route: null");
+    int coff = 0;
+    for (int i = 0; i < n; ++i) {
+        const mi355_tensor *x = xs[i];
+        if (!x || !x->data || x->cs % 16 || x->C % 16 || x->B != y->B || x->H != y->H || x->W != y->W)
+            return einval("route: input layout (channels must be multiples of 16)");
+        if (coff + x->C > y->cs) return einval("route: too many channels");
+        CopyArgs a{(const uint8_t *)x->data, (uint8_t *)y->data, x->B, x->H, x->W, y->H, y->W, x->cs, y->cs, x->lead,
+                   y->lead, x->C / 16, 1, coff};
+        int rc = copy_cells_launch(a, (hipStream_t)stream);
+        if (rc) return rc;
+        coff += x->C;
+    }
+    if (coff != y->C) return einval("route: channel sum != y.C");
+    return MI355_OK;
+}
+
+int mi355_yolo_forward(const float *in, float *out, int B, int n, int classes, int H, int W, void *stream)
+{
+    if (!in || !out) return einval("yolo: null");
+    return yolo_logistic_launch(in, out, B, n, classes, H * W, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+/* capi.c -- flat accessors over struct network / struct layer for FFI callers (ctypes in tests and bench.py) that
+ * should not replicate the struct layouts. */
+#include <string.h>
+#include "host_internal.h"
+
+int dnq_net_n(network *net) { return net->n; }
+int dnq_net_batch(network *net) { return net->batch; }
+int dnq_net_inputs(network *net) { return net->inputs; }
+void *dnq_net_stream(network *net) { return net->stream; }
+void *dnq_net_input_gpu(network *net) { return net->input_uint8_gpu; }
+uint8_t *dnq_net_input_host(network *net) { return net->input_uint8; }
+float *dnq_net_input_float(network *net) { return net->input; }
+
+int dnq_net_set(network *net, const char *key, int val)
+{
+    if (!strcmp(key, "accum_mode")) net->accum_mode = val;
+    else if (!strcmp(key, "store_mode")) net->store_mode = val;
+    else if (!strcmp(key, "dump_int32")) net->dump_int32 = val;
+    else if (!strcmp(key, "use_graph")) net->use_graph = val;
+    else if (!strcmp(key, "gpu_index")) net->gpu_index = val;
+    else if (!strcmp(key, "verbose")) net->verbose = val;
+    else return -1;
+    return 0;
+}
+
+/* info[0..15] = type, out_c, out_h, out_w, c, h, w, n, size, stride, pad, activation, batch_normalize,
+ * layer_quant_flag, quant_stop_flag, outputs  (same order as oracle/ref_driver.c) */
+int dnq_layer_info(network *net, int i, int *info)
+{
+    if (i < 0 || i >= net->n) return -1;
+    layer *l = &net->layers[i];
+    info[0] = l->type; info[1] = l->out_c; info[2] = l->out_h; info[3] = l->out_w;
+    info[4] = l->c; info[5] = l->h; info[6] = l->w; info[7] = l->n;
+    info[8] = l->size; info[9] = l->stride; info[10] = l->pad; info[11] = l->activation;
+    info[12] = l->batch_normalize; info[13] = l->layer_quant_flag; info[14] = l->quant_stop_flag;
+    info[15] = l->outputs;
+    return 0;
+}
+const uint8_t *dnq_layer_u8(network *net, int i) { return net->layers[i].output_uint8_final; }
+const int32_t *dnq_layer_int32(network *net, int i) { return net->layers[i].output_int32; }
+const float *dnq_layer_f32(network *net, int i) { return net->layers[i].output; }
+void *dnq_layer_f32_gpu(network *net, int i) { return net->layers[i].output_gpu; }
+
+int dnq_layer_prep(network *net, int i, int32_t *biases_int32, double *M_value, double *shift_value, int32_t *M0,
+                   int *shift, float *q)
+{
+    layer *l = &net->layers[i];
+    if (q && l->activ_data_uint8_scales) {
+        q[2] = l->activ_data_uint8_scales[0];
+        q[3] = l->activ_data_uint8_zero_point[0];
+        if (l->type == CONVOLUTIONAL) { q[0] = l->input_data_uint8_scales[0]; q[1] = l->input_data_uint8_zero_point[0]; }
+    }
+    if (l->type != CONVOLUTIONAL) return 1;
+    for (int k = 0; k < l->n; ++k) {
+        if (biases_int32) biases_int32[k] = l->biases_int32[k];
+        if (M_value) M_value[k] = l->M_value[k];
+        if (shift_value) shift_value[k] = l->M0_right_shift_value[k];
+        if (M0) M0[k] = l->M0[k];
+        if (shift) shift[k] = l->M0_right_shift[k];
+    }
+    return 0;
+}

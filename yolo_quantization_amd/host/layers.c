@@ -1,0 +1,229 @@
+/*
+ * layers.c -- layer constructors and the forward_gpu function pointers of the INT8 path.
+ *
+ *   make_convolutional_layer   ref: src/convolutional_layer.c:179-279 (quant fields 214-257, dispatch 258-273)
+ *   make_maxpool_layer         ref: src/maxpool_layer.c:20-75
+ *   make_upsample_layer        ref: src/upsample_layer.c:7-60
+ *   make_route_layer           ref: src/route_layer.c:7-50
+ *   make_yolo_layer            ref: src/yolo_layer.c:13-60
+ * Each forward_*_gpu is the device replacement of the reference's forward_*_quant (cited at the function).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "host_internal.h"
+
+static void forward_cpu_not_built(layer l, network net)
+{
+    (void)net;
+    fprintf(stderr,
+            "layer %d (%s): this is the MI355X build -- there is no CPU data path; call forward_gpu / "
+            "forward_network_gpu (libmi355yolo.so)\n",
+            l.count, get_layer_string(l.type));
+    error("forward: CPU path not built");
+}
+
+static void alloc_act_record(layer *l)
+{
+    l->activ_data_uint8_scales = calloc(1, sizeof(float));
+    l->activ_data_uint8_zero_point = calloc(1, sizeof(uint8_t));
+}
+
+/* ref: forward_convolutional_layer_quant_inputi_outputi, src/convolutional_layer.c:694-761 */
+static void forward_convolutional_layer_quant_gpu(layer l, network net)
+{
+    if (!l.prepared) error("forward_gpu before quantization_weights_and_activations");
+    mi355_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.n = l.n; d.c = l.c; d.ksize = l.size; d.stride = l.stride; d.pad = l.pad;
+    d.activation = l.activation;
+    d.store_mode = net.store_mode;
+    d.accum_mode = net.accum_mode;
+    d.zp_in = l.input_data_uint8_zero_point[0];
+    d.zp_act = l.activ_data_uint8_zero_point[0];
+    d.s_act = l.activ_data_uint8_scales[0];
+    check_mi355(mi355_conv_forward(&d, net.cur_t, l.blob_gpu, l.weights_uint8_gpu, l.weight_zero_point_gpu, &l.out_t,
+                                   net.dump_int32 ? l.output_int32_gpu : NULL,
+                                   l.quant_stop_flag ? l.output_gpu : NULL, net.stream),
+                "mi355_conv_forward");
+}
+
+/* ref: forward_maxpool_layer_quant, src/maxpool_layer.c:109-172 */
+static void forward_maxpool_layer_quant_gpu(layer l, network net)
+{
+    check_mi355(mi355_maxpool_forward(net.cur_t, &l.out_t, l.size, l.stride, l.pad, net.stream), "mi355_maxpool_forward");
+}
+
+/* ref: forward_upsample_layer_quant, src/upsample_layer.c:96-113 */
+static void forward_upsample_layer_quant_gpu(layer l, network net)
+{
+    check_mi355(mi355_upsample_forward(net.cur_t, &l.out_t, l.stride, net.stream), "mi355_upsample_forward");
+}
+
+/* ref: forward_route_layer_quant, src/route_layer.c:107-130 */
+static void forward_route_layer_quant_gpu(layer l, network net)
+{
+    const mi355_tensor *xs[16];
+    if (l.n > 16) error("route: more than 16 inputs");
+    for (int i = 0; i < l.n; ++i) xs[i] = &net.layers[l.input_layers[i]].out_t;
+    check_mi355(mi355_route_forward(xs, l.n, &l.out_t, net.stream), "mi355_route_forward");
+}
+
+/* ref: forward_yolo_layer (inference part), src/yolo_layer.c:132-146 */
+static void forward_yolo_layer_gpu(layer l, network net)
+{
+    if (!net.cur_f32_gpu) error("yolo layer needs a float input (previous layer must have quant_stop=1)");
+    check_mi355(mi355_yolo_forward(net.cur_f32_gpu, l.output_gpu, l.batch, l.n, l.classes, l.h, l.w, net.stream),
+                "mi355_yolo_forward");
+}
+
+layer make_convolutional_layer(int batch, int h, int w, int c, int n, int groups, int size, int stride, int padding,
+                               ACTIVATION activation, int batch_normalize, int quant_stop_flag,
+                               int close_quantization, int layer_quantization, int count)
+{
+    layer l;
+    memset(&l, 0, sizeof(l));
+    l.type = CONVOLUTIONAL;
+    l.groups = groups; l.h = h; l.w = w; l.c = c; l.n = n; l.batch = batch;
+    l.stride = stride; l.size = size; l.pad = padding; l.batch_normalize = batch_normalize;
+    l.activation = activation; l.count = count;
+    l.nweights = c / groups * n * size * size;
+    l.out_h = (h + 2 * padding - size) / stride + 1; /* ref: convolutional_out_height */
+    l.out_w = (w + 2 * padding - size) / stride + 1;
+    l.out_c = n;
+    l.outputs = l.out_h * l.out_w * l.out_c;
+    l.inputs = h * w * c;
+    l.layer_quant_flag = layer_quantization;
+    l.close_quantization = close_quantization;
+    l.quant_stop_flag = quant_stop_flag;
+    if (!layer_quantization) {
+        fprintf(stderr, "layer %d: [convolutional] without quantized=1 would take the reference's float path "
+                        "(src/convolutional_layer.c:271), which this INT8 build does not contain\n", count);
+        error("unquantized convolution");
+    }
+    alloc_act_record(&l);
+    l.weight_data_uint8_scales = calloc(n, sizeof(float));
+    l.input_data_uint8_scales = calloc(1, sizeof(float));
+    l.weight_data_uint8_zero_point = calloc(n, sizeof(uint8_t));
+    l.input_data_uint8_zero_point = calloc(1, sizeof(uint8_t));
+    l.weights_sum_int = calloc(n, sizeof(int32_t));
+    l.mult_zero_point = calloc(n, sizeof(uint32_t));
+    l.M = calloc(n, sizeof(float));
+    l.M0 = calloc(n, sizeof(int32_t));
+    l.M_value = calloc(n, sizeof(double));
+    l.M0_right_shift = calloc(n, sizeof(int));
+    l.M0_right_shift_value = calloc(n, sizeof(double));
+    l.weights_uint8 = calloc(l.nweights, sizeof(uint8_t));
+    l.biases_int32 = calloc(n, sizeof(int32_t));
+    l.biases = calloc(n, sizeof(float));
+    if (batch_normalize) {
+        l.scales = calloc(n, sizeof(float));
+        l.rolling_mean = calloc(n, sizeof(float));
+        l.rolling_variance = calloc(n, sizeof(float));
+        for (int i = 0; i < n; ++i) l.scales[i] = 1;
+    }
+    l.forward = forward_cpu_not_built;
+    l.forward_gpu = forward_convolutional_layer_quant_gpu;
+    return l;
+}
+
+layer make_maxpool_layer(int batch, int h, int w, int c, int size, int stride, int padding, int layer_quant_flag,
+                         int quant_stop_flag, int close_quantization, int count)
+{
+    layer l;
+    memset(&l, 0, sizeof(l));
+    l.type = MAXPOOL;
+    l.batch = batch; l.h = h; l.w = w; l.c = c; l.pad = padding; l.count = count;
+    l.out_w = (w + padding - size) / stride + 1; /* ref :31-32 */
+    l.out_h = (h + padding - size) / stride + 1;
+    l.out_c = c;
+    l.outputs = l.out_h * l.out_w * l.out_c;
+    l.inputs = h * w * c;
+    l.size = size; l.stride = stride;
+    l.layer_quant_flag = layer_quant_flag; l.quant_stop_flag = quant_stop_flag;
+    l.close_quantization = close_quantization;
+    if (!layer_quant_flag) error("[maxpool] without quantized=1 is the reference's float path; not built");
+    if (quant_stop_flag) error("quant_stop on a maxpool layer is not supported on the device path");
+    alloc_act_record(&l);
+    l.forward = forward_cpu_not_built;
+    l.forward_gpu = forward_maxpool_layer_quant_gpu;
+    return l;
+}
+
+layer make_upsample_layer(int batch, int w, int h, int c, int stride, int layer_quant_flag, int quant_stop_flag,
+                          int close_quantization, int count)
+{
+    layer l;
+    memset(&l, 0, sizeof(l));
+    l.type = UPSAMPLE;
+    l.batch = batch; l.w = w; l.h = h; l.c = c; l.count = count;
+    l.out_w = w * stride; l.out_h = h * stride; l.out_c = c;
+    l.stride = stride;
+    l.outputs = l.out_w * l.out_h * l.out_c;
+    l.inputs = w * h * c;
+    l.layer_quant_flag = layer_quant_flag; l.quant_stop_flag = quant_stop_flag;
+    l.close_quantization = close_quantization;
+    if (!layer_quant_flag) error("[upsample] without quantized=1 is the reference's float path; not built");
+    if (quant_stop_flag) error("quant_stop on an upsample layer is not supported on the device path");
+    alloc_act_record(&l);
+    l.forward = forward_cpu_not_built;
+    l.forward_gpu = forward_upsample_layer_quant_gpu;
+    return l;
+}
+
+layer make_route_layer(int batch, int n, int *input_layers, int *input_sizes, int layer_quant_flag,
+                       int quant_stop_flag, int close_quantization, int count)
+{
+    layer l;
+    memset(&l, 0, sizeof(l));
+    l.type = ROUTE;
+    l.batch = batch; l.n = n; l.count = count;
+    l.input_layers = input_layers; l.input_sizes = input_sizes;
+    int outputs = 0;
+    for (int i = 0; i < n; ++i) outputs += input_sizes[i];
+    l.outputs = outputs; l.inputs = outputs;
+    l.layer_quant_flag = layer_quant_flag; l.quant_stop_flag = quant_stop_flag;
+    l.close_quantization = close_quantization;
+    if (!layer_quant_flag) error("[route] without quantized=1 is the reference's float path; not built");
+    if (quant_stop_flag) error("quant_stop on a route layer is not supported on the device path");
+    alloc_act_record(&l);
+    l.forward = forward_cpu_not_built;
+    l.forward_gpu = forward_route_layer_quant_gpu;
+    return l;
+}
+
+layer make_yolo_layer(int batch, int w, int h, int n, int total, int *mask, int classes, int count)
+{
+    layer l;
+    memset(&l, 0, sizeof(l));
+    l.type = YOLO;
+    l.n = n; l.total = total; l.batch = batch; l.h = h; l.w = w; l.count = count;
+    l.c = n * (classes + 4 + 1);
+    l.out_w = w; l.out_h = h; l.out_c = l.c;
+    l.classes = classes;
+    l.anchors = calloc(total * 2, sizeof(float));
+    if (mask) l.mask = mask;
+    else {
+        l.mask = calloc(n, sizeof(int));
+        for (int i = 0; i < n; ++i) l.mask[i] = i;
+    }
+    l.outputs = h * w * n * (classes + 4 + 1);
+    l.inputs = l.outputs;
+    for (int i = 0; i < total * 2; ++i) l.anchors[i] = .5f;
+    l.forward = forward_cpu_not_built;
+    l.forward_gpu = forward_yolo_layer_gpu;
+    return l;
+}
+
+void free_layer_device(layer *l)
+{
+    if (l->out_t.data) mi355_free(l->out_t.data);
+    if (l->blob_gpu) mi355_free(l->blob_gpu);
+    if (l->weights_uint8_gpu) mi355_free(l->weights_uint8_gpu);
+    if (l->weight_zero_point_gpu) mi355_free(l->weight_zero_point_gpu);
+    if (l->output_int32_gpu) mi355_free(l->output_int32_gpu);
+    if (l->output_gpu) mi355_free(l->output_gpu);
+    if (l->output_uint8_nchw_gpu) mi355_free(l->output_uint8_nchw_gpu);
+    l->out_t.data = NULL; l->blob_gpu = NULL; l->weights_uint8_gpu = NULL; l->weight_zero_point_gpu = NULL;
+    l->output_int32_gpu = NULL; l->output_gpu = NULL; l->output_uint8_nchw_gpu = NULL;
+}

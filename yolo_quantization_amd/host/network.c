@@ -1,0 +1,463 @@
+/*
+ * network.c -- host prep, device buffer management and the layer-loop executor.
+ *
+ *   quantization_weights_and_activations   ref: src/blas.c:259-346
+ *   quant_multi_smaller_than_one_...       ref: src/blas.c:387-418
+ *   quant_image_with_min_max               ref: src/blas.c:108-168 (quant_weights_with_min_max_channel, 1 channel)
+ *   forward_network_gpu                    ref: src/network.c:835-861 with the uint8 hand-off of :248-250
+ *   network_predict                        ref: src/network.c:570-581
+ *   set_batch_network                      ref: src/network.c:383-397
+ */
+#include <assert.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+#include "host_internal.h"
+
+/* ------------------------------------------------------------------------------------------------------ utils */
+void error(const char *s) /* ref: src/utils.c:232-237 */
+{
+    fprintf(stderr, "darknet_q: %s\n", s);
+    fflush(stderr);
+    exit(-1);
+}
+void file_error(const char *s)
+{
+    fprintf(stderr, "Couldn't open file: %s\n", s);
+    exit(0);
+}
+void check_mi355(int rc, const char *what) /* ref: check_error, src/cuda.c:27-49 */
+{
+    if (rc != MI355_OK) {
+        fprintf(stderr, "MI355 error %d in %s: %s\n", rc, what, mi355_last_error());
+        error(what);
+    }
+}
+double what_time_is_it_now(void)
+{
+    struct timeval time;
+    if (gettimeofday(&time, NULL)) return 0;
+    return (double)time.tv_sec + (double)time.tv_usec * .000001;
+}
+const char *get_layer_string(LAYER_TYPE t)
+{
+    switch (t) {
+    case CONVOLUTIONAL: return "CONV";
+    case MAXPOOL: return "MAX";
+    case ROUTE: return "ROUTE";
+    case UPSAMPLE: return "UPSAMPLE";
+    case YOLO: return "YOLO";
+    }
+    return "?";
+}
+
+/* ------------------------------------------------------------------------------------------------- host prep */
+void quant_multi_smaller_than_one_to_scale_and_shift(float real_multiplier, int32_t *quantized_multiplier,
+                                                     int *right_shift)
+{
+    if (!(real_multiplier > 0.f) || !(real_multiplier < 1.f)) { /* ref :391-392 asserts */
+        fprintf(stderr, "requantisation multiplier %g is outside (0,1)\n", real_multiplier);
+        error("quant_multi_smaller_than_one_to_scale_and_shift");
+    }
+    int s = 0;
+    while (real_multiplier < 0.5f) {
+        real_multiplier *= 2.0f;
+        s++;
+    }
+    int64_t q = (int64_t)round((double)(real_multiplier * (float)(1ll << 31)));
+    if (q == (1ll << 31)) {
+        q /= 2;
+        s--;
+    }
+    if (s < 0) error("quant_multi: negative shift");
+    *quantized_multiplier = (int32_t)q;
+    *right_shift = s;
+}
+
+void quant_image_with_min_max(int count, const float *input, uint8_t *out, float *scale, uint8_t *zero_point)
+{
+    float min_value = 0.0f, max_value = 0.0f;
+    for (int j = 0; j < count; ++j) {
+        max_value = input[j] > max_value ? input[j] : max_value;
+        min_value = input[j] < min_value ? input[j] : min_value;
+    }
+    if (min_value == 0 && max_value == 0) error("input image is all zero (ref: src/blas.c:125-128 assert)");
+    /* the reference binary (gcc -Ofast) multiplies by the reciprocal constant here; see oracle/oracle.c */
+    float nudged_scale = (max_value - min_value) * (1.0f / 255.0f);
+    if (nudged_scale == 0) error("zero input scale");
+    const double initial_zero_point = (double)(0.0f - min_value / nudged_scale);
+    uint8_t zp;
+    if (initial_zero_point < QUANT_NEGATIVE_LIMIT) zp = QUANT_NEGATIVE_LIMIT;
+    else if (initial_zero_point > QUANT_POSITIVE_LIMIT) zp = QUANT_POSITIVE_LIMIT;
+    else zp = (uint8_t)round(initial_zero_point);
+    *scale = nudged_scale;
+    *zero_point = zp;
+    for (int k = 0; k < count; ++k) {
+        float t = (float)(round((double)(input[k] / nudged_scale)) + (double)zp);
+        int v = (int)t;
+        out[k] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+static void prep_conv_layer(network *net, int i)
+{
+    layer *l = &net->layers[i];
+    if (i > 0) { /* ref :301-305: input scale / zero point are the previous layer's activation record */
+        l->input_data_uint8_scales[0] = net->layers[i - 1].activ_data_uint8_scales[0];
+        l->input_data_uint8_zero_point[0] = net->layers[i - 1].activ_data_uint8_zero_point[0];
+    }
+    const int K = l->c * l->size * l->size; /* ref :306 */
+    const float s_in = l->input_data_uint8_scales[0];
+    const int zp_in = l->input_data_uint8_zero_point[0];
+    if (s_in == 0 || l->activ_data_uint8_scales[0] == 0) error("zero quantisation scale (ref: src/blas.c:312,332 asserts)");
+    for (int ii = 0; ii < l->n; ++ii) {
+        float b = l->biases[ii];
+        if (l->batch_normalize) /* ref :286 -> :594-600, evaluated in double as the C expression promotes */
+            b = (float)((double)b - (double)(l->scales[ii] * l->rolling_mean[ii]) /
+                                        (sqrt((double)l->rolling_variance[ii]) + (double).000001f));
+        if (l->weight_data_uint8_scales[ii] == 0) error("zero weight scale (ref: src/blas.c:293 assert)");
+        l->mult_zero_point[ii] = (uint32_t)(K * zp_in * (int)l->weight_data_uint8_zero_point[ii]);
+        int32_t wsum = 0;
+        for (int jj = 0; jj < K; ++jj) wsum += l->weights_uint8[(size_t)ii * K + jj];
+        l->weights_sum_int[ii] = (int32_t)(l->mult_zero_point[ii] - (uint32_t)(wsum * zp_in));
+        l->M[ii] = s_in * l->weight_data_uint8_scales[ii] / l->activ_data_uint8_scales[0];
+        quant_multi_smaller_than_one_to_scale_and_shift(l->M[ii], &l->M0[ii], &l->M0_right_shift[ii]);
+        l->M0_right_shift_value[ii] = pow(2, -l->M0_right_shift[ii]);
+        l->M_value[ii] = pow(2, -31) * l->M0[ii];
+        float t = b / (s_in * l->weight_data_uint8_scales[ii]) + (float)l->weights_sum_int[ii]; /* ref :333 */
+        l->biases_int32[ii] = (int32_t)t;
+    }
+}
+
+static void alloc_layer_device(network *net, int i)
+{
+    layer *l = &net->layers[i];
+    free_layer_device(l);
+    const int B = net->batch;
+    l->batch = B;
+    if (l->type != YOLO) {
+        size_t bytes = mi355_tensor_describe(&l->out_t, B, l->out_h, l->out_w, l->out_c);
+        if (!bytes) error("bad tensor dims");
+        check_mi355(mi355_alloc(&l->out_t.data, bytes), "alloc activations");
+        check_mi355(mi355_tensor_fill(&l->out_t, l->activ_data_uint8_zero_point[0], net->stream), "fill activations");
+        check_mi355(mi355_alloc((void **)&l->output_uint8_nchw_gpu, (size_t)B * l->outputs), "alloc nchw scratch");
+    }
+    if (l->type == YOLO || l->quant_stop_flag)
+        check_mi355(mi355_alloc((void **)&l->output_gpu, (size_t)B * l->outputs * sizeof(float)), "alloc float out");
+    if (l->type == CONVOLUTIONAL && net->dump_int32)
+        check_mi355(mi355_alloc((void **)&l->output_int32_gpu, (size_t)B * l->outputs * sizeof(int32_t)), "alloc int32 out");
+    free(l->output); free(l->output_int32); free(l->output_uint8_final);
+    l->output = calloc((size_t)B * l->outputs, sizeof(float));
+    l->output_int32 = l->type == CONVOLUTIONAL ? calloc((size_t)B * l->outputs, sizeof(int32_t)) : NULL;
+    l->output_uint8_final = calloc((size_t)B * l->outputs, sizeof(uint8_t));
+}
+
+static void upload_conv(network *net, int i, int with_raw)
+{
+    layer *l = &net->layers[i];
+    if (l->blob_gpu) { mi355_free(l->blob_gpu); l->blob_gpu = NULL; }
+    check_mi355(mi355_alloc(&l->blob_gpu, l->blob_bytes), "alloc blob");
+    check_mi355(mi355_h2d(l->blob_gpu, l->blob_host, l->blob_bytes, net->stream), "upload blob");
+    if (with_raw) {
+        check_mi355(mi355_alloc((void **)&l->weights_uint8_gpu, (size_t)l->nweights), "alloc raw weights");
+        check_mi355(mi355_h2d(l->weights_uint8_gpu, l->weights_uint8, (size_t)l->nweights, net->stream), "upload raw weights");
+        check_mi355(mi355_alloc((void **)&l->weight_zero_point_gpu, (size_t)l->n), "alloc zp_w");
+        check_mi355(mi355_h2d(l->weight_zero_point_gpu, l->weight_data_uint8_zero_point, (size_t)l->n, net->stream), "upload zp_w");
+    }
+    l->prepared = 1;
+}
+
+static void alloc_network_device(network *net)
+{
+    check_mi355(mi355_init(net->gpu_index), "mi355_init");
+    if (!net->stream) check_mi355(mi355_stream_create(&net->stream), "stream");
+    if (net->input_uint8_gpu) mi355_free(net->input_uint8_gpu);
+    if (net->input_t.data) mi355_free(net->input_t.data);
+    check_mi355(mi355_alloc((void **)&net->input_uint8_gpu, (size_t)net->batch * net->inputs), "alloc input");
+    size_t bytes = mi355_tensor_describe(&net->input_t, net->batch, net->h, net->w, net->c);
+    check_mi355(mi355_alloc(&net->input_t.data, bytes), "alloc input tensor");
+    check_mi355(mi355_tensor_fill(&net->input_t, net->layers[0].input_data_uint8_zero_point[0], net->stream), "fill input");
+    for (int i = 0; i < net->n; ++i) alloc_layer_device(net, i);
+    if (net->graph) { mi355_graph_destroy(net->graph); net->graph = NULL; }
+}
+
+void quantization_prep_host(network *net, float in_scale, uint8_t in_zp)
+{
+    layer *l0 = &net->layers[0];
+    if (l0->type != CONVOLUTIONAL) error("first layer must be convolutional");
+    l0->input_data_uint8_scales[0] = in_scale;
+    l0->input_data_uint8_zero_point[0] = in_zp;
+    for (int i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        if (l->type != CONVOLUTIONAL) continue;
+        prep_conv_layer(net, i);
+        size_t sz = mi355_conv_pack_size(l->n, l->c, l->size);
+        if (!sz) {
+            fprintf(stderr, "layer %d: conv %dx%d, %d->%d channels is not supported by the gfx950 kernels "
+                            "(need size 1|3 and c==3 or c%%16==0)\n", i, l->size, l->size, l->c, l->n);
+            error("unsupported convolution shape");
+        }
+        free(l->blob_host);
+        l->blob_host = malloc(sz);
+        l->blob_bytes = sz;
+        check_mi355(mi355_conv_pack(l->n, l->c, l->size, l->weights_uint8, l->weight_data_uint8_zero_point,
+                                    l->biases_int32, l->M_value, l->M0_right_shift_value, l->blob_host),
+                    "mi355_conv_pack");
+    }
+}
+
+void quantization_weights_and_activations_fixed_input(network *net, float in_scale, uint8_t in_zp)
+{
+    quantization_prep_host(net, in_scale, in_zp);
+    alloc_network_device(net);
+    for (int i = 0; i < net->n; ++i)
+        if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, 1);
+    check_mi355(mi355_stream_sync(net->stream), "sync");
+    net->prepared = 1;
+}
+
+void quantization_weights_and_activations(network *net)
+{
+    /* ref :279: dynamic layer-0 quantiser on the float image in net->input (image 0 defines scale / zero point) */
+    float s; uint8_t zp;
+    quant_image_with_min_max(net->inputs, net->input, net->input_uint8, &s, &zp);
+    quantization_weights_and_activations_fixed_input(net, s, zp);
+    for (int b = 1; b < net->batch; ++b) { /* further images: same scale (batch > 1 is our extension) */
+        float *x = net->input + (size_t)b * net->inputs;
+        uint8_t *o = net->input_uint8 + (size_t)b * net->inputs;
+        for (int k = 0; k < net->inputs; ++k) {
+            int v = (int)(float)(round((double)(x[k] / s)) + (double)zp);
+            o[k] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+    push_network_input_uint8(net, net->input_uint8);
+}
+
+void set_batch_network(network *net, int b)
+{
+    if (b < 1) error("set_batch_network: batch < 1");
+    if (b == net->batch && net->prepared) return;
+    net->batch = b;
+    free(net->input); free(net->input_uint8);
+    net->input = calloc((size_t)net->inputs * b, sizeof(float));
+    net->input_uint8 = calloc((size_t)net->inputs * b, sizeof(uint8_t));
+    for (int i = 0; i < net->n; ++i) net->layers[i].batch = b;
+    if (net->prepared) { /* re-size the device buffers, keep the packed weights */
+        alloc_network_device(net);
+        for (int i = 0; i < net->n; ++i)
+            if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, net->layers[i].weights_uint8 != NULL);
+        check_mi355(mi355_stream_sync(net->stream), "sync");
+    }
+}
+
+/* -------------------------------------------------------------------------------------------------- execution */
+void push_network_input_uint8(network *net, const uint8_t *host_nchw)
+{
+    if (!net->prepared) error("push_network_input_uint8 before quantization_weights_and_activations");
+    check_mi355(mi355_h2d(net->input_uint8_gpu, host_nchw, (size_t)net->batch * net->inputs, net->stream), "push input");
+}
+
+void network_profile_begin(network *net, int max_steps)
+{
+    if (net->prof_ev) {
+        for (int i = 0; i < net->prof_cap * (net->n + 2); ++i) mi355_event_destroy(net->prof_ev[i]);
+        free(net->prof_ev);
+        net->prof_ev = NULL;
+    }
+    net->prof_cap = max_steps;
+    net->prof_used = 0;
+    if (max_steps <= 0) return;
+    net->prof_ev = calloc((size_t)max_steps * (net->n + 2), sizeof(void *));
+    for (int i = 0; i < max_steps * (net->n + 2); ++i) check_mi355(mi355_event_create(&net->prof_ev[i]), "event create");
+}
+
+int network_profile_read(network *net, float *ms_sum)
+{
+    for (int i = 0; i < net->n + 1; ++i) ms_sum[i] = 0;
+    for (int s = 0; s < net->prof_used; ++s) {
+        void **e = net->prof_ev + (size_t)s * (net->n + 2);
+        for (int i = 0; i < net->n + 1; ++i) {
+            float ms = 0;
+            check_mi355(mi355_event_elapsed_ms(e[i], e[i + 1], &ms), "event elapsed");
+            ms_sum[i] += ms;
+        }
+    }
+    return net->prof_used;
+}
+
+static void run_layers(network *netp)
+{
+    network net = *netp;
+    void **ev = NULL;
+    if (netp->prof_ev && netp->prof_used < netp->prof_cap && !netp->use_graph)
+        ev = netp->prof_ev + (size_t)(netp->prof_used++) * (net.n + 2);
+    if (ev) check_mi355(mi355_event_record(ev[0], net.stream), "event");
+    check_mi355(mi355_nchw_to_tensor(netp->input_uint8_gpu, &netp->input_t, net.stream), "input layout");
+    if (ev) check_mi355(mi355_event_record(ev[1], net.stream), "event");
+    net.cur_t = &netp->input_t;
+    net.cur_f32_gpu = NULL;
+    for (int i = 0; i < net.n; ++i) {
+        net.index = i;
+        layer l = net.layers[i];
+        l.forward_gpu(l, net);
+        if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
+        if (l.layer_quant_flag && !net.train) { /* ref src/network.c:248-250 */
+            net.cur_t = &netp->layers[i].out_t;
+            net.cur_f32_gpu = l.output_gpu;
+        } else {
+            net.cur_f32_gpu = l.output_gpu;
+        }
+        if (net.verbose) fprintf(stderr, "layer %2d %-8s done\n", i, get_layer_string(l.type));
+    }
+}
+
+void forward_network_gpu(network *netp)
+{
+    if (!netp->prepared) error("forward_network_gpu before quantization_weights_and_activations");
+    if (netp->use_graph) {
+        if (!netp->graph) {
+            run_layers(netp); /* warm-up outside capture (module load, attribute calls) */
+            check_mi355(mi355_stream_sync(netp->stream), "sync");
+            check_mi355(mi355_graph_begin(netp->stream), "graph begin");
+            run_layers(netp);
+            check_mi355(mi355_graph_end(netp->stream, &netp->graph), "graph end");
+        }
+        check_mi355(mi355_graph_launch(netp->graph, netp->stream), "graph launch");
+    } else {
+        run_layers(netp);
+    }
+}
+
+void forward_network(network *net) { forward_network_gpu(net); }
+
+float *network_predict(network *net, float *input)
+{
+    /* ref src/network.c:570-581; the integer path ignores `input` after the prep quantised it (examples/detector.c
+     * :914-921), so does this one: the uint8 image must already be on the device. */
+    (void)input;
+    net->train = 0;
+    forward_network_gpu(net);
+    check_mi355(mi355_stream_sync(net->stream), "sync");
+    layer *last = &net->layers[net->n - 1];
+    if (last->output_gpu) {
+        check_mi355(mi355_d2h(last->output, last->output_gpu, (size_t)net->batch * last->outputs * sizeof(float), net->stream), "pull output");
+        check_mi355(mi355_stream_sync(net->stream), "sync");
+    }
+    net->output = last->output;
+    return net->output;
+}
+
+void pull_layer_output(network *net, int i)
+{
+    if (i < 0 || i >= net->n) error("pull_layer_output: index");
+    layer *l = &net->layers[i];
+    const size_t cnt = (size_t)net->batch * l->outputs;
+    if (l->type != YOLO) {
+        check_mi355(mi355_tensor_to_nchw(&l->out_t, l->output_uint8_nchw_gpu, net->stream), "layout");
+        check_mi355(mi355_d2h(l->output_uint8_final, l->output_uint8_nchw_gpu, cnt, net->stream), "pull u8");
+    }
+    if (l->output_gpu) check_mi355(mi355_d2h(l->output, l->output_gpu, cnt * sizeof(float), net->stream), "pull f32");
+    if (l->output_int32_gpu) check_mi355(mi355_d2h(l->output_int32, l->output_int32_gpu, cnt * sizeof(int32_t), net->stream), "pull i32");
+    check_mi355(mi355_stream_sync(net->stream), "sync");
+}
+
+/* ------------------------------------------------------------------------------------ packed-weight exchange */
+typedef struct { uint32_t magic; int32_t nlayers; float in_scale; int32_t in_zp; uint64_t total; } pack_head;
+typedef struct { float s_act, s_in; int32_t zp_act, zp_in; uint64_t blob_bytes; } pack_rec;
+#define PACK_MAGIC 0x51444B4Eu
+
+size_t network_packed_size(network *net)
+{
+    if (!net->prepared) error("network_packed_size before prep");
+    size_t sz = sizeof(pack_head) + (size_t)net->n * sizeof(pack_rec);
+    for (int i = 0; i < net->n; ++i) sz += (net->layers[i].blob_bytes + 15) & ~(size_t)15;
+    return sz;
+}
+
+void network_export_packed(network *net, void *buf)
+{
+    char *p = buf;
+    pack_head h = {PACK_MAGIC, net->n, net->layers[0].input_data_uint8_scales[0],
+                   net->layers[0].input_data_uint8_zero_point[0], network_packed_size(net)};
+    memcpy(p, &h, sizeof(h)); p += sizeof(h);
+    for (int i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        pack_rec r;
+        memset(&r, 0, sizeof(r));
+        if (l->activ_data_uint8_scales) { r.s_act = l->activ_data_uint8_scales[0]; r.zp_act = l->activ_data_uint8_zero_point[0]; }
+        if (l->type == CONVOLUTIONAL) { r.s_in = l->input_data_uint8_scales[0]; r.zp_in = l->input_data_uint8_zero_point[0]; }
+        r.blob_bytes = l->blob_bytes;
+        memcpy(p, &r, sizeof(r)); p += sizeof(r);
+    }
+    for (int i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        if (!l->blob_bytes) continue;
+        memcpy(p, l->blob_host, l->blob_bytes);
+        p += (l->blob_bytes + 15) & ~(size_t)15;
+    }
+}
+
+void network_import_packed(network *net, const void *buf, size_t bytes)
+{
+    const char *p = buf;
+    pack_head h;
+    memcpy(&h, p, sizeof(h)); p += sizeof(h);
+    if (h.magic != PACK_MAGIC || h.nlayers != net->n || h.total != bytes) error("network_import_packed: header mismatch (different cfg?)");
+    const pack_rec *recs = (const pack_rec *)p;
+    p += (size_t)net->n * sizeof(pack_rec);
+    for (int i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        pack_rec r;
+        memcpy(&r, &recs[i], sizeof(r));
+        if (l->activ_data_uint8_scales) { l->activ_data_uint8_scales[0] = r.s_act; l->activ_data_uint8_zero_point[0] = (uint8_t)r.zp_act; }
+        if (l->type == CONVOLUTIONAL) {
+            l->input_data_uint8_scales[0] = r.s_in; l->input_data_uint8_zero_point[0] = (uint8_t)r.zp_in;
+            if (r.blob_bytes != mi355_conv_pack_size(l->n, l->c, l->size)) error("network_import_packed: blob size mismatch");
+            free(l->blob_host);
+            l->blob_host = malloc(r.blob_bytes);
+            l->blob_bytes = r.blob_bytes;
+            memcpy(l->blob_host, p, r.blob_bytes);
+            p += (r.blob_bytes + 15) & ~(size_t)15;
+        }
+    }
+    alloc_network_device(net);
+    for (int i = 0; i < net->n; ++i)
+        if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, 0);
+    check_mi355(mi355_stream_sync(net->stream), "sync");
+    net->prepared = 1;
+}
+
+void network_import_packed_gpu(network *net, const void *dev_buf, size_t bytes)
+{
+    check_mi355(mi355_init(net->gpu_index), "mi355_init");
+    void *host = malloc(bytes);
+    check_mi355(mi355_d2h(host, dev_buf, bytes, NULL), "d2h packed");
+    check_mi355(mi355_stream_sync(NULL), "sync");
+    network_import_packed(net, host, bytes);
+    free(host);
+}
+
+void free_network(network *net)
+{
+    if (!net) return;
+    for (int i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        free_layer_device(l);
+        free(l->input_data_uint8_scales); free(l->activ_data_uint8_scales); free(l->weight_data_uint8_scales);
+        free(l->input_data_uint8_zero_point); free(l->activ_data_uint8_zero_point); free(l->weight_data_uint8_zero_point);
+        free(l->weights_sum_int); free(l->mult_zero_point); free(l->M); free(l->M0); free(l->M0_right_shift);
+        free(l->M_value); free(l->M0_right_shift_value); free(l->weights_uint8); free(l->biases_int32);
+        free(l->biases); free(l->scales); free(l->rolling_mean); free(l->rolling_variance);
+        free(l->input_layers); free(l->input_sizes); free(l->mask); free(l->anchors);
+        free(l->output); free(l->output_int32); free(l->output_uint8_final); free(l->blob_host);
+    }
+    network_profile_begin(net, 0);
+    if (net->graph) mi355_graph_destroy(net->graph);
+    if (net->input_uint8_gpu) mi355_free(net->input_uint8_gpu);
+    if (net->input_t.data) mi355_free(net->input_t.data);
+    if (net->stream) mi355_stream_destroy(net->stream);
+    free(net->layers); free(net->input); free(net->input_uint8); free(net->seen);
+    free(net);
+}
