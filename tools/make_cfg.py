@@ -54,7 +54,7 @@ def tiny_unit(act="leaky"):
     s += conv(16, 1, act)            # 4
     s += upsample(2)                 # 5   12x12
     s += route("-1, 0")              # 6   32ch 12x12
-    s += conv(24, 3, "relu6")        # 7
+    s += conv(32, 3, "relu6")        # 7
     s += conv(30, 1, "linear", bn=0, stop=1)  # 8
     s += yolo("0,1,2")               # 9
     return s
