@@ -128,7 +128,7 @@ def test_pack_blob_reconstructs_exact_accumulators(n, c, k):
         assert np.array_equal(got, want)
         return
     cb, bpc = h["cb"], h["cb"] // 16
-    wp = np.frombuffer(blob, np.int8, h["mpad"] * h["ksteps"] * 64, off_wp).reshape(h["mpad"] // 16, h["ksteps"], 16, 64)
+    wp = np.frombuffer(blob, np.int8, h["mpad"] * h["ksteps"] * 64, off_wp).reshape(h["mpad"] // 16, h["ksteps"], 4, 16, 16)
     xs = x.reshape(c, k * k).astype(np.int64) - 128  # x' per (ci, tap)
     mf = np.zeros(n, np.int64); sx = 0
     for chunk in range(h["nchunks"]):
@@ -137,12 +137,12 @@ def test_pack_blob_reconstructs_exact_accumulators(n, c, k):
             for kg in range(4):
                 u = 4 * s + kg
                 if u >= h["upc"]:
-                    assert not wp[:, g, :, kg * 16:(kg + 1) * 16].any()
+                    assert not wp[:, g, kg].any()
                     continue
                 tap, blk = u // bpc, u % bpc
                 ci0 = chunk * cb + blk * 16
                 xv = xs[ci0:ci0 + 16, tap]
-                wv = wp[:, g, :, kg * 16:(kg + 1) * 16].reshape(h["mpad"], 16)[:n].astype(np.int64)
+                wv = wp[:, g, kg].reshape(h["mpad"], 16)[:n].astype(np.int64)
                 mf += wv @ xv
                 sx += xv.sum()
     got = mf + dzp[:n].astype(np.int64) * sx + cw[:n].astype(np.int64)

@@ -37,13 +37,17 @@ struct ConvBlobHeader {
 __device__ __forceinline__ uint32_t requant_u8(int32_t acc, int32_t bias, double M, double S, int zp_act, int act,
                                                int store_mode)
 {
-    long long t = (long long)((double)(acc + bias) * M);  // :732  int64_t temp = (acc + bias) * M_value
-    int32_t q = (int32_t)((double)t * S);                  // :733  q = temp * 2^-shift
+    // :732  int64_t temp = (acc + bias) * M_value.  mi355_conv_pack guarantees 0 < M_value < 1 (the reference asserts
+    // 0 < M < 1, src/blas.c:391-392), so |product| < 2^31 and the truncation to int64 equals the single-instruction
+    // truncation to int32 (v_cvt_i32_f64) -- bit-identical, ~4x fewer instructions than a generic f64->i64.
+    const int32_t t = (int32_t)((double)(acc + bias) * M);
+    const int32_t q = (int32_t)((double)t * S);  // :733  q = temp * 2^-shift  (0 < S <= 1)
     int32_t v;
     if (act == MI355_ACT_LEAKY) {
-        // :737  q < 0 ? round(q*0.1) + zp : q + zp   (double arithmetic, round half away from zero)
-        double d = q < 0 ? (round((double)q * 0.1) + (double)zp_act) : (double)(q + zp_act);
-        v = (int32_t)d;
+        // :737  q < 0 ? round(q*0.1) + zp : q + zp.  round((double)q * 0.1) == -((|q| + 5) / 10) for every negative
+        // int32 q (exhaustively verified, tests/test_host_cpu.py + DESIGN.md), so no FP64 here.
+        const uint32_t uq = 0u - (uint32_t)q;
+        v = q < 0 ? zp_act - (int32_t)((uq + 5u) / 10u) : q + zp_act;
     } else if (act == MI355_ACT_RELU6) {
         v = q <= 0 ? zp_act : q + zp_act;  // :744
     } else {

@@ -1,228 +1,366 @@
-// conv_igemm.hip -- implicit-GEMM INT8 convolution on V_MFMA_I32_16X16X64_I8 (gfx950), fused requantise epilogue.
+// conv_igemm.hip -- implicit-GEMM INT8 convolution on V_MFMA_I32_32X32X32_I8 (gfx950), fused requantise epilogue.
 //
 // Replaces, for a whole batch, the reference's
 //     im2col_cpu_uint8 (ref: src/im2col.c:26-50)  ->  gemm_nn_uint8_int32_te x2 (ref: src/gemm.c:279-299,
 //     src/convolutional_layer.c:718-721)  ->  requant / activation loop (ref: src/convolutional_layer.c:726-751)
-// without materialising im2col: the GEMM is  acc[oc][p] = sum_k W[oc][k] * X[k][p]  with p = (image, y, x)
-// flattened over the whole batch (so 13x13 layers still fill 128/256-wide N tiles) and k = (chunk, tap, channel).
+// without materialising im2col: the GEMM is  acc[oc][p] = sum_k W[oc][k] * X[k][p]  with p = (image, y, x) over the
+// whole batch and k = (channel chunk, tap, channel).
 //
-// Signed x signed MFMA vs the reference's (u8 - zp_w) x u8 operands: with w' = w_u8 - 128 and
-// x' = x_u8 - 128 (activations are *stored* biased, so no flip in the loop) and d = 128 - zp_w,
+// Signed x signed MFMA vs the reference's (u8 - zp_w) x u8 operands: with w' = w_u8 - 128,
+// x' = x_u8 - 128 (activations are *stored* biased, so there is no flip in the loop) and d = 128 - zp_w,
 //     sum_k (w_u8 - zp_w) x_u8 = sum_k w'x'  +  d * sum_k x'  +  [128 * sum_k w' + 128 * K * d]
 // The first term is the MFMA; sum_k x' (receptive-field sum, pad taps included) is accumulated on the VALU with
-// v_dot4 against 0x01010101 from the very B fragments the MFMA consumes (MFMA and VALU pipes are separate); the
+// v_dot4 against 0x01010101 from the very B fragments the MFMA consumes (MFMA and VALU are separate pipes); the
 // bracket is a per-channel constant folded at pack time.  Everything is exact in int32.
 //
-// Data flow per workgroup (BM output channels x BN pixels):
-//   * B operand: for each 64-byte channel chunk the *contiguous* cell range that covers the tile's pixels plus a
-//     (W+2)-cell halo is staged once in LDS (coalesced 16-byte loads); all 9 taps read it at constant cell offsets
-//     (the PHWC layout makes a tap a constant offset), i.e. 9x less global->LDS traffic than per-tap gathers.
-//   * A operand: the packed weight slab of one K-step ([BM][64 B], contiguous in HBM) is double buffered in LDS.
-//   * global loads for step g+1 are issued before the MFMAs of step g and written to the other LDS buffer after
-//     them: one barrier per K-step.
+// Structure of one workgroup (BM output channels x BN pixels):
+//   * N tile = BN consecutive valid pixels of the flattened batch (FLAT, small feature maps: 13x13 layers still
+//     fill 256-wide tiles) or a TH x 16 pixel patch of one image (PATCH, large feature maps: small halo).
+//   * B operand: per 64-byte channel chunk the tile's cells + halo are DMA'd ONCE into LDS
+//     (global_load_lds_dwordx4); all 9 taps read them at constant cell offsets (the PHWC layout makes a tap a
+//     constant offset): 9x less global->LDS traffic than per-tap gathers.  Double buffered per chunk.
+//   * A operand: the packed weight slab of one K-step ([BM][64 B], 1 KiB per 16 rows, stored in HBM in LDS image
+//     order) is DMA'd into a 3-stage LDS ring, two K-steps ahead of its use.
+//   * LDS images are "piece-major" ([16-byte piece][16 rows|cells][16 B] per KiB): every ds_read_b128 lane group
+//     of an MFMA fragment read then covers 16 distinct 16-byte bank slots (conflict-free); with DMA staging the
+//     permutation is applied on the per-lane *source* address, the LDS destination stays lane-linear.
+//   * one s_barrier per K-step; DMA stays in flight across it (counted s_waitcnt vmcnt(N), never 0 in steady state).
+//   * epilogue: corrections + FP64 requantise (exact reference op order) in registers, uint8 tile transposed through
+//     LDS so that every pixel's channel run is written with 16-byte stores.
 #include "kargs.h"
 
+#define DMA16(gsrc, ldst)                                                                               \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),           \
+                                     (__attribute__((address_space(3))) void *)(ldst), 16, 0, 0)
 
-template <int BM, int BN, int WMW, int WNW, int BPT>
+__device__ __forceinline__ void wait_vmcnt(int n)
+{
+    // counted wait; n is wave-uniform.  (s_waitcnt needs an immediate.)
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+constexpr int A_STAGES = 3;
+constexpr int BPT_MAX = 8;  // B DMA instructions per wave per chunk load (upper bound)
+
+template <int BM, int BN, int WMW, int WNW, bool PATCH>
 __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_i8_kernel(const ConvArgs a)
 {
-    constexpr int NT = 64 * WMW * WNW;
+    constexpr int NW = WMW * WNW, NT = 64 * NW;
     constexpr int TM = BM / WMW, TN = BN / WNW;
-    constexpr int MS = TM / 16, NS = TN / 16;
-    constexpr int APT = (BM * 4 + NT - 1) / NT;  // 16-byte pieces of the A slab per thread
-    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA tile");
+    constexpr int MS = TM / 32, NS = TN / 32;
+    constexpr int ACH = BM / 16;                 // 1 KiB chunks per A stage
+    constexpr int APT = (ACH + NW - 1) / NW;     // A DMA instructions per wave per stage
+    constexpr int TW = 16, TH = BN / 16;         // PATCH geometry
+    constexpr int OSTR = BM + 4;                 // epilogue LDS row stride (bytes): odd dword count -> conflict-free b32
+    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *ldsA = smem;                                   // [2][BM*64]
-    char *ldsB = smem + 2 * BM * 64;                     // [2][ncell_cap*cb]
-    const int bbytes = a.ncell_cap * a.cb;
+    char *ldsA = smem;                                 // [A_STAGES][BM*64]
+    char *ldsB = smem + A_STAGES * BM * 64;            // [2][bchunks KiB]
+    const int bbytes = a.bchunks << 10;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WNW, wn = wave % WNW;
-    const int kg = lane >> 4, lj = lane & 15;
+    const int kh = lane >> 5, lj = lane & 31;
 
-    // ---- XCD-aware tile assignment: blocks b, b+8, b+16.. run on one XCD (observed dispatch), give each XCD a
+    // ---- XCD-aware tile assignment: blocks b, b+8, b+16.. run on one XCD (observed dispatch); give each XCD a
     //      contiguous range of (mtile, ntile) so weight slabs and halos are shared in its private L2.
-    const int nb = gridDim.x;
     int logical;
     {
-        const int id = blockIdx.x;
+        const int nb = gridDim.x, id = blockIdx.x;
         const int q = nb >> 3, r = nb & 7, xcd = id & 7, idx = id >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int mtile = logical / a.ntiles_n;
     const int ntile = logical - mtile * a.ntiles_n;
-    const int n0 = ntile * BN;
-    const int nlast = min(n0 + BN, a.total_n) - 1;
 
-    const int W1 = a.W + 1;
-    const int halo = (a.ksize == 3) ? (a.W + 2) : 0;
-    const int f0 = cell_of_pixel(n0, a.H, a.W, a.in_lead);
-    const int f1 = cell_of_pixel(nlast, a.H, a.W, a.in_lead);
-    const int fstart = f0 - halo;
-    const int ncell = f1 - f0 + 1 + 2 * halo;
-    const int bpc = a.cb >> 4;                 // 16-byte blocks per cell chunk: 1, 2 or 4
+    const int W1 = a.W + 1, hw = a.H * a.W;
+    const int cb = a.cb, bpc = cb >> 4;
     const int bpc_sh = (bpc == 4) ? 2 : (bpc == 2 ? 1 : 0);
-    const int npieces = ncell * bpc;
+    const int cpc_sh = 6 - bpc_sh, cpc = 1 << cpc_sh;     // cells per 1 KiB LDS chunk
+    const int pstride = cpc << 4;                          // bytes between pieces inside a chunk
 
-    // per-lane LDS byte offset of its B columns (pixel -> cell), one per 16-column sub-tile
-    int bbase[NS];
-#pragma unroll
-    for (int ns = 0; ns < NS; ++ns) {
-        int n = min(n0 + wn * TN + ns * 16 + lj, a.total_n - 1);
-        bbase[ns] = (cell_of_pixel(n, a.H, a.W, a.in_lead) - fstart) * a.cb;
+    // ---- tile geometry
+    int rs;            // LDS row stride in cells (tap (dy,dx) = dy*rs + dx)
+    int fstart = 0;    // FLAT: first global cell held in LDS
+    int pb = 0, py0 = 0, px0 = 0;  // PATCH: image, patch origin
+    int n0 = 0;
+    if constexpr (PATCH) {
+        const int tpi = a.tiles_x * a.tiles_y;
+        pb = ntile / tpi;
+        const int t = ntile - pb * tpi;
+        const int ty = t / a.tiles_x;
+        py0 = ty * TH;
+        px0 = (t - ty * a.tiles_x) * TW;
+        rs = TW + 2;
+    } else {
+        n0 = ntile * BN;
+        const int nlast = min(n0 + BN, a.total_n) - 1;
+        const int halo = (a.ksize == 3) ? (a.W + 2) : 0;
+        fstart = cell_of_pixel(n0, a.H, a.W, a.in_lead) - halo;
+        (void)nlast;
+        rs = W1;
     }
 
-    v4i acc[MS][NS];
+    // ---- per-lane B columns: LDS cell of each 32-column sub-tile's pixel (tap offset added per K-step)
+    int bcell[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+        const int nl = wn * TN + ns * 32 + lj;
+        if constexpr (PATCH) {
+            bcell[ns] = ((nl >> 4) + 1) * rs + (nl & 15) + 1;
+        } else {
+            const int n = min(n0 + nl, a.total_n - 1);
+            bcell[ns] = cell_of_pixel(n, a.H, a.W, a.in_lead) - fstart;
+        }
+    }
+
+    // ---- DMA source bookkeeping.  Every wave issues exactly APT (A) / a.bpt (B) instructions per load so that
+    //      the counted vmcnt waits are exact; surplus slots re-load the last chunk (same bytes, same place).
+    const int8_t *asrc[APT];
+    int adst[APT];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+        const int ch = min(wave + i * NW, ACH - 1);
+        asrc[i] = a.wp + ((size_t)(mtile * ACH + ch) * a.ksteps) * 1024 + lane * 16;
+        adst[i] = ch << 10;
+    }
+    // B: chunk q of this wave's i-th instruction; lane -> (cell in chunk, piece)
+    const int lcell = lane & (cpc - 1), lpiece = lane >> cpc_sh;
+    auto bsrc_of = [&](int q) -> unsigned {  // byte offset of this lane's source cell (+ piece) for LDS chunk q
+        const int lc = (q << cpc_sh) + lcell;  // logical LDS cell index
+        long f;
+        if constexpr (PATCH) {
+            const int rr = lc / rs, cc = lc - rr * rs;
+            f = (long)a.in_lead + ((long)pb * (a.H + 1) + (py0 + rr)) * W1 + (px0 - 1 + cc);
+        } else {
+            f = (long)fstart + lc;
+        }
+        f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
+        return (unsigned)(f * a.in_cs + lpiece * 16);
+    };
+    unsigned bsrc_off[BPT_MAX];  // PATCH only: the div/mod above is hoisted out of the K loop
+    if constexpr (PATCH) {
+#pragma unroll
+        for (int i = 0; i < BPT_MAX; ++i) bsrc_off[i] = (i < a.bpt) ? bsrc_of(min(wave + i * NW, a.bchunks - 1)) : 0u;
+    }
+
+    auto issueA = [&](int g) {
+        char *stage = ldsA + (g % A_STAGES) * (BM * 64);
+#pragma unroll
+        for (int i = 0; i < APT; ++i) DMA16(asrc[i] + (size_t)g * 1024, stage + adst[i]);
+    };
+    auto issueB = [&](int chunk) {
+        char *buf = ldsB + (chunk & 1) * bbytes;
+        const int8_t *base = a.x + (size_t)chunk * cb;
+#pragma unroll
+        for (int i = 0; i < BPT_MAX; ++i)
+            if (i < a.bpt) {
+                const int q = min(wave + i * NW, a.bchunks - 1);
+                unsigned off;
+                if constexpr (PATCH) off = bsrc_off[i];
+                else off = bsrc_of(q);
+                DMA16(base + off, buf + (q << 10));
+            }
+    };
+
+    v16i acc[MS][NS];
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = (v4i){0, 0, 0, 0};
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0;
     int sx[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) sx[ns] = 0;
 
-    int4 areg[APT];
-    int4 breg[BPT];
+    // A fragment LDS offsets (row part): lane row i = lj of 32-row sub-tile ms
+    int arow[MS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+        const int row = wm * TM + ms * 32 + lj;
+        arow[ms] = ((row >> 4) << 10) + ((row & 15) << 4);
+    }
 
-    auto gloadA = [&](int g) {
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            int p = tid + i * NT;
-            if (p < BM * 4) {
-                int sub = p >> 6, within = p & 63;
-                const int8_t *src = a.wp + ((size_t)(mtile * (BM / 16) + sub) * a.ksteps + g) * 1024 + within * 16;
-                areg[i] = *reinterpret_cast<const int4 *>(src);
-            }
-        }
-    };
-    auto sstoreA = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            int p = tid + i * NT;
-            if (p < BM * 4) *reinterpret_cast<int4 *>(ldsA + buf * (BM * 64) + p * 16) = areg[i];
-        }
-    };
-    auto gloadB = [&](int chunk) {
-#pragma unroll
-        for (int i = 0; i < BPT; ++i) {
-            int p = tid + i * NT;
-            if (p < npieces) {
-                int cell = p >> bpc_sh, qq = p & (bpc - 1);
-                int f = min(max(fstart + cell, 0), a.in_cells - 1);
-                const int8_t *src = a.x + (size_t)f * a.in_cs + chunk * a.cb + qq * 16;
-                breg[i] = *reinterpret_cast<const int4 *>(src);
-            }
-        }
-    };
-    auto sstoreB = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < BPT; ++i) {
-            int p = tid + i * NT;
-            if (p < npieces) *reinterpret_cast<int4 *>(ldsB + buf * bbytes + p * 16) = breg[i];
-        }
-    };
-
-    // ---- prologue
-    gloadB(0);
-    gloadA(0);
-    sstoreB(0);
-    sstoreA(0);
-    __syncthreads();
+    // ---- prologue: B(0), A(0), A(1)
+    issueB(0);
+    issueA(0);
+    if (a.ksteps > 1) issueA(1);
 
     int chunk = 0, s = 0;
+    bool b_prev = false;  // a B load was issued in the previous iteration (after A(g), before A(g+1) in the queue)
     for (int g = 0; g < a.ksteps; ++g) {
-        const int next = g + 1;
-        const bool has_next = next < a.ksteps;
-        const bool new_chunk = has_next && (s + 1 == a.spc);
-        if (has_next) {
-            gloadA(next);
-            if (new_chunk) gloadB(chunk + 1);
-        }
-        // ---- compute K-step g
+        // ---- retire A(g) (and B(chunk) when this step opens a chunk), leave younger DMA in flight
         {
-            const int u = 4 * s + kg;
-            const bool valid = u < a.upc;
-            const int uc = valid ? u : 0;
-            const int tap = uc >> bpc_sh, blk = uc & (bpc - 1);
-            int dcell = 0;
-            if (a.ksize == 3) {
-                const int ty = tap / 3, tx = tap - ty * 3;
-                dcell = (ty - 1) * W1 + (tx - 1);
-            }
-            const int koff = dcell * a.cb + blk * 16;
-            const int ones = valid ? 0x01010101 : 0;
-            const char *A = ldsA + (g & 1) * (BM * 64);
+            const int younger_a = (g + 1 < a.ksteps) ? APT : 0;
+            int n = younger_a;
+            if (b_prev && s != 0) n += a.bpt;  // B(chunk+1) sits between A(g) and A(g+1): not needed yet
+            if (g == 0) n = (a.ksteps > 1) ? APT : 0;  // queue: B(0), A(0), A(1)
+            if (n == APT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");  // steady state
+            else wait_vmcnt(n);
+        }
+        __builtin_amdgcn_s_barrier();
+        // ---- issue DMA two steps ahead (stage (g+2)%3 was last read in step g-1: every wave is past it)
+        b_prev = false;
+        if (s == 0 && chunk + 1 < a.nchunks) {
+            issueB(chunk + 1);
+            b_prev = true;
+        }
+        if (g + 2 < a.ksteps) issueA(g + 2);
+
+        // ---- compute K-step g: 2 halves of 32 k each
+        {
+            const char *A = ldsA + (g % A_STAGES) * (BM * 64);
             const char *Bt = ldsB + (chunk & 1) * bbytes;
-            v4i af[MS];
 #pragma unroll
-            for (int ms = 0; ms < MS; ++ms)
-                af[ms] = *reinterpret_cast<const v4i *>(A + (wm * TM + ms * 16 + lj) * 64 + kg * 16);
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-                const v4i bf = *reinterpret_cast<const v4i *>(Bt + bbase[ns] + koff);
-                int t = sx[ns];
-                t = __builtin_amdgcn_sdot4(bf[0], ones, t, false);
-                t = __builtin_amdgcn_sdot4(bf[1], ones, t, false);
-                t = __builtin_amdgcn_sdot4(bf[2], ones, t, false);
-                t = __builtin_amdgcn_sdot4(bf[3], ones, t, false);
-                sx[ns] = t;
+            for (int h = 0; h < 2; ++h) {
+                const int pk = 2 * h + kh;           // 16-byte piece of this K-step held by this lane
+                const int u = 4 * s + pk;
+                const bool valid = u < a.upc;
+                const int uc = valid ? u : 0;
+                const int tap = uc >> bpc_sh, blk = uc & (bpc - 1);
+                int dcell = 0;
+                if (a.ksize == 3) {
+                    const int ty = tap / 3, tx = tap - ty * 3;
+                    dcell = (ty - 1) * rs + (tx - 1);
+                }
+                const int ones = valid ? 0x01010101 : 0;
+                v4i af[MS];
 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms)
-                    acc[ms][ns] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
+                    af[ms] = *reinterpret_cast<const v4i *>(A + arow[ms] + pk * 256);
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    const int ci = bcell[ns] + dcell;
+                    const int boff = ((ci >> cpc_sh) << 10) + blk * pstride + ((ci & (cpc - 1)) << 4);
+                    const v4i bf = *reinterpret_cast<const v4i *>(Bt + boff);
+                    int t = sx[ns];
+                    t = __builtin_amdgcn_sdot4(bf[0], ones, t, false);
+                    t = __builtin_amdgcn_sdot4(bf[1], ones, t, false);
+                    t = __builtin_amdgcn_sdot4(bf[2], ones, t, false);
+                    t = __builtin_amdgcn_sdot4(bf[3], ones, t, false);
+                    sx[ns] = t;
+#pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
+                }
             }
         }
-        if (has_next) {
-            sstoreA(next & 1);
-            if (new_chunk) sstoreB((chunk + 1) & 1);
-        }
-        __syncthreads();
         if (++s == a.spc) { s = 0; ++chunk; }
     }
 
-    // ---- epilogue: receptive-field sums across the 4 k-groups, per-channel corrections, requantise, store
+    // ---- epilogue
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) sx[ns] += __shfl_xor(sx[ns], 32);  // the two 16-byte k-halves
+
+    __syncthreads();  // all MFMA reads of LDS are done: reuse it as the [BN][BM+16] uint8 output tile
+    char *otile = smem;
+    int *celltab = reinterpret_cast<int *>(smem + BN * OSTR);
+    const int m0 = mtile * BM;
+
+    bool nvalid[NS];
+    int pb_[NS], rem[NS], nl_[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-        int t = sx[ns];
-        t += __shfl_xor(t, 16);
-        t += __shfl_xor(t, 32);
-        sx[ns] = t;
+        const int nl = wn * TN + ns * 32 + lj;
+        nl_[ns] = nl;
+        int b, y, xx;
+        if constexpr (PATCH) {
+            b = pb; y = py0 + (nl >> 4); xx = px0 + (nl & 15);
+            nvalid[ns] = y < a.H && xx < a.W;
+        } else {
+            const int n = n0 + nl;
+            nvalid[ns] = n < a.total_n;
+            const int nn = nvalid[ns] ? n : 0;
+            b = nn / hw;
+            const int rem0 = nn - b * hw;
+            y = rem0 / a.W; xx = rem0 - y * a.W;
+        }
+        pb_[ns] = b;
+        rem[ns] = y * a.W + xx;
+        if (wm == 0 && kh == 0) celltab[nl] = nvalid[ns] ? a.out_lead + (b * (a.H + 1) + (y + 1)) * W1 + xx : -1;
     }
-    const int hw = a.H * a.W;
 #pragma unroll
-    for (int ns = 0; ns < NS; ++ns) {
-        const int n = n0 + wn * TN + ns * 16 + lj;
-        const bool nvalid = n < a.total_n;
-        const int nn = nvalid ? n : 0;
-        const int b = nn / hw, rem = nn - b * hw;
-        const int y = rem / a.W, xx = rem - y * a.W;
-        const int ocell = a.out_lead + (b * (a.H + 1) + (y + 1)) * W1 + xx;
+    for (int ms = 0; ms < MS; ++ms) {
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) {
-            const int oc0 = mtile * BM + wm * TM + ms * 16 + kg * 4;  // 4 consecutive channels held by this lane
-            if (!nvalid || oc0 >= a.n) continue;
+        for (int grp = 0; grp < 4; ++grp) {
+            const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;  // 4 consecutive channels held by this lane
+            const int oc0 = m0 + ocl;
+            if (oc0 >= a.n) {
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = 0x80808080u;
+                continue;
+            }
             const int4 cw4 = *reinterpret_cast<const int4 *>(a.cw + oc0);
             const int4 dz4 = *reinterpret_cast<const int4 *>(a.dzp + oc0);
             const int4 bi4 = *reinterpret_cast<const int4 *>(a.bias + oc0);
             const int cwv[4] = {cw4.x, cw4.y, cw4.z, cw4.w};
             const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
             const int biv[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
-            uint32_t packed = 0;
+            double mv[4], sv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int oc = oc0 + r;
-                const int32_t accv = acc[ms][ns][r] + cwv[r] + dzv[r] * sx[ns];
-                if (oc < a.n) {
-                    const uint32_t u8 = requant_u8(accv, biv[r], a.mval[oc], a.sval[oc], a.zp_act, a.act, a.store_mode);
-                    packed |= (u8 ^ 0x80u) << (8 * r);
-                    const size_t ridx = ((size_t)b * a.n + oc) * hw + rem;
-                    if (a.acc_out) a.acc_out[ridx] = accv;
-                    if (a.y_f32) a.y_f32[ridx] = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
-                }
+            for (int r = 0; r < 4; ++r) {  // arrays are padded to mpad: in-bounds even for oc >= n
+                mv[r] = a.mval[oc0 + r];
+                sv[r] = a.sval[oc0 + r];
             }
-            if (a.y) *reinterpret_cast<uint32_t *>(a.y + (size_t)ocell * a.out_cs + oc0) = packed;
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int oc = oc0 + r;
+                    const int32_t accv = acc[ms][ns][grp * 4 + r] + cwv[r] + dzv[r] * sx[ns];
+                    uint32_t u8 = 0;
+                    if (oc < a.n) {
+                        u8 = requant_u8(accv, biv[r], mv[r], sv[r], a.zp_act, a.act, a.store_mode);
+                        if (nvalid[ns] && (a.acc_out || a.y_f32)) {
+                            const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
+                            if (a.acc_out) a.acc_out[ridx] = accv;
+                            if (a.y_f32) a.y_f32[ridx] = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
+                        }
+                    }
+                    packed |= (u8 ^ 0x80u) << (8 * r);
+                }
+                *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed;
+            }
+        }
+    }
+    __syncthreads();
+    if (a.y) {
+        // dword-granular copy-out: consecutive lanes -> consecutive dwords of a pixel's channel run (coalesced,
+        // conflict-free LDS reads)
+        const int dwords = min(BM, a.out_cs - m0) >> 2;  // dwords of this M tile inside the output cell
+        const int total = BN * dwords;
+        for (int p = tid; p < total; p += NT) {
+            const int pix = p / dwords, d = p - pix * dwords;
+            const int cell = celltab[pix];
+            if (cell >= 0)
+                *reinterpret_cast<uint32_t *>(a.y + (size_t)cell * a.out_cs + m0 + d * 4) =
+                    *reinterpret_cast<const uint32_t *>(otile + pix * OSTR + d * 4);
         }
     }
 }
@@ -230,29 +368,45 @@ __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_i8_kernel(const Con
 // ---------------------------------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------------------
-static int g_force_bm = 0, g_force_bn = 0;
+static int g_force_bm = 0, g_force_bn = 0, g_force_patch = -1;
 extern "C" int mi355_conv_set_tile(int bm, int bn)
 {
+    // bn > 0: force tile; bn encodes the N-tile mode in bit 30 (patch) / bit 29 (flat) for benchmarking
+    g_force_patch = (bn & (1 << 30)) ? 1 : ((bn & (1 << 29)) ? 0 : -1);
     g_force_bm = bm;
-    g_force_bn = bn;
+    g_force_bn = bn & 0xFFFF;
     return MI355_OK;
 }
 
-template <int BM, int BN, int WMW, int WNW, int BPT>
+template <int BM, int BN, int WMW, int WNW, bool PATCH>
 static int launch_cfg(ConvArgs &a, hipStream_t st)
 {
-    constexpr int NT = 64 * WMW * WNW;
-    a.ntiles_n = (a.total_n + BN - 1) / BN;
-    a.mtiles = (a.n + BM - 1) / BM;
-    // B-tile capacity in cells: pixels + row pads + image-boundary pad rows + halo both sides
-    const int halo = (a.ksize == 3) ? (a.W + 2) : 0;
-    int span = BN + (BN + a.W - 1) / a.W + 1 + ((BN + a.H * a.W - 1) / (a.H * a.W) + 1) * (a.W + 1);
-    int ncell = span + 2 * halo;
-    if ((size_t)ncell * (a.cb / 16) > (size_t)BPT * NT) return MI355_EINVAL;  // staging registers exhausted
-    a.ncell_cap = ncell;
-    size_t lds = 2 * (size_t)BM * 64 + 2 * (size_t)ncell * a.cb;
+    constexpr int NW = WMW * WNW, NT = 64 * NW;
+    if (a.mpad % BM) return MI355_EINVAL;
+    a.mtiles = a.mpad / BM;
+    const int cpc = 1024 / a.cb;
+    int ncell;
+    if (PATCH) {
+        constexpr int TH = BN / 16, TW = 16;
+        a.tiles_x = (a.W + TW - 1) / TW;
+        a.tiles_y = (a.H + TH - 1) / TH;
+        a.ntiles_n = a.B * a.tiles_x * a.tiles_y;
+        ncell = (TH + 2) * (TW + 2);
+    } else {
+        a.ntiles_n = (a.total_n + BN - 1) / BN;
+        const int halo = (a.ksize == 3) ? (a.W + 2) : 0;
+        // pixels + row pads + image-boundary pad rows, + halo both sides
+        int span = BN + (BN + a.W - 1) / a.W + 1 + ((BN + a.H * a.W - 1) / (a.H * a.W) + 1) * (a.W + 1);
+        ncell = span + 2 * halo;
+    }
+    a.bchunks = (ncell + cpc - 1) / cpc;
+    a.bpt = (a.bchunks + NW - 1) / NW;
+    if (a.bpt > BPT_MAX || 2 + a.bpt > 18) return MI355_EINVAL;
+    size_t lds = (size_t)A_STAGES * BM * 64 + 2 * ((size_t)a.bchunks << 10);
+    const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
+    if (lds_epi > lds) lds = lds_epi;
     if (lds > 160 * 1024) return MI355_EINVAL;
-    auto kern = conv_igemm_i8_kernel<BM, BN, WMW, WNW, BPT>;
+    auto kern = conv_igemm_i8_kernel<BM, BN, WMW, WNW, PATCH>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
@@ -263,28 +417,38 @@ static int launch_cfg(ConvArgs &a, hipStream_t st)
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
 
+template <bool PATCH>
+static int launch_mode(ConvArgs &a, hipStream_t st, int bm, int bn)
+{
+    if (bm == 128 && bn == 256) return launch_cfg<128, 256, 2, 4, PATCH>(a, st);
+    if (bm == 128 && bn == 128) return launch_cfg<128, 128, 2, 2, PATCH>(a, st);
+    if (bm == 64 && bn == 256) return launch_cfg<64, 256, 1, 4, PATCH>(a, st);
+    if (bm == 64 && bn == 128) return launch_cfg<64, 128, 1, 4, PATCH>(a, st);
+    if (bm == 32 && bn == 256) return launch_cfg<32, 256, 1, 4, PATCH>(a, st);
+    if (bm == 32 && bn == 128) return launch_cfg<32, 128, 1, 4, PATCH>(a, st);
+    return MI355_EINVAL;
+}
+
 int conv_igemm_launch(ConvArgs &a, hipStream_t st)
 {
     int bm = g_force_bm, bn = g_force_bn;
     if (!bm) bm = a.n >= 128 ? 128 : (a.n > 32 ? 64 : 32);
+    // N-tile mode: PATCH when a 16-wide patch wastes little (W >= 24) -- its halo is (TH+2)x18 cells instead of two
+    // full image rows; FLAT for the small maps where a patch would be mostly padding.
+    bool patch = a.ksize == 3 && a.W >= 24 && a.H >= 8;
+    if (g_force_patch >= 0) patch = g_force_patch == 1;
     if (!bn) {
         bn = 256;
-        // keep at least ~1.5 workgroups per CU on the small 13x13 / 26x26 layers
-        long tiles = (long)((a.total_n + 255) / 256) * ((a.n + bm - 1) / bm);
-        if (tiles < 384) bn = 128;
+        long tiles;
+        if (patch) tiles = (long)a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
+        else tiles = (a.total_n + 255) / 256;
+        tiles *= (a.n + bm - 1) / bm;
+        if (tiles < 384) bn = 128;  // keep >= ~1.5 workgroups per CU on the small 13x13 / 26x26 layers
     }
-    int rc = MI355_EINVAL;
-    if (bm == 128 && bn == 256) rc = launch_cfg<128, 256, 2, 4, 6>(a, st);
-    else if (bm == 128 && bn == 128) rc = launch_cfg<128, 128, 2, 2, 8>(a, st);
-    else if (bm == 64 && bn == 256) rc = launch_cfg<64, 256, 1, 4, 12>(a, st);
-    else if (bm == 64 && bn == 128) rc = launch_cfg<64, 128, 1, 2, 12>(a, st);
-    else if (bm == 32 && bn == 256) rc = launch_cfg<32, 256, 1, 4, 12>(a, st);
-    else if (bm == 32 && bn == 128) rc = launch_cfg<32, 128, 1, 2, 12>(a, st);
+    int rc = patch ? launch_mode<true>(a, st, bm, bn) : launch_mode<false>(a, st, bm, bn);
     if (rc == MI355_EINVAL && !(g_force_bm || g_force_bn)) {
-        // large-W early layers: the halo dominates the staging budget -> narrower wave layout with more registers
-        if (bm == 64) rc = launch_cfg<64, 128, 1, 2, 12>(a, st);
-        else if (bm == 32) rc = launch_cfg<32, 128, 1, 2, 12>(a, st);
-        else rc = launch_cfg<128, 128, 2, 2, 8>(a, st);
+        // staging budget exceeded (very wide rows in FLAT mode): fall back to the other mode / narrower tile
+        rc = patch ? launch_mode<false>(a, st, bm, 128) : launch_mode<true>(a, st, bm, 128);
     }
     return rc;
 }

@@ -17,8 +17,9 @@ struct ConvArgs {
     int total_n, ntiles_n, mtiles;
     int zp_act, act, store_mode;
     float s_act;
-    int ncell_cap;
     int mpad;
+    int bchunks, bpt;        // LDS B buffer size in KiB chunks; DMA instructions per wave per chunk load
+    int tiles_x, tiles_y;    // PATCH mode tiling of one image
 };
 
 struct AuxArgs {

@@ -257,6 +257,9 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
     int32_t *bias = (int32_t *)(base + h.off_bias);
     double *mval = (double *)(base + h.off_mval), *sval = (double *)(base + h.off_sval);
     const int K = h.ktrue;
+    for (int oc = 0; oc < n; ++oc)
+        if (!(M_value[oc] > 0.0 && M_value[oc] < 1.0) || !(shift_value[oc] > 0.0 && shift_value[oc] <= 1.0))
+            return einval("conv_pack: need 0 < M_value < 1 and 0 < shift_value <= 1 (ref asserts 0<M<1, src/blas.c:391-392)");
     for (int oc = 0; oc < n; ++oc) {
         bias[oc] = biases_int32[oc];
         mval[oc] = M_value[oc];
@@ -284,7 +287,7 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
         for (int chunk = 0; chunk < h.nchunks; ++chunk)
             for (int s = 0; s < h.spc; ++s) {
                 const int g = chunk * h.spc + s;
-                int8_t *dst = wp + ((size_t)mt * h.ksteps + g) * 1024 + row * 64;
+                int8_t *dst = wp + ((size_t)mt * h.ksteps + g) * 1024 + row * 16;  // [piece][row][16]
                 for (int kg = 0; kg < 4; ++kg) {
                     const int u = 4 * s + kg;
                     if (u >= h.upc) continue;
@@ -293,7 +296,7 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
                     for (int e = 0; e < 16; ++e) {
                         const int ci = chunk * h.cb + blk * 16 + e;
                         const uint8_t w = wq[(size_t)oc * K + (ci * ksize + ky) * ksize + kx];  // (ci,ky,kx) order
-                        dst[kg * 16 + e] = (int8_t)(w ^ 0x80);
+                        dst[kg * 256 + e] = (int8_t)(w ^ 0x80);
                     }
                 }
             }
