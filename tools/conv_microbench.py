@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""One-kernel microbench of the MFMA implicit-GEMM conv through the C-ABI (BASELINE config[1] by default:
+3x3 s1 conv 256->256, 52x52, batch 32).  Prints achieved TOP/s from HIP events on the launch stream.
+
+  python tools/conv_microbench.py [--c 256 --n 256 --hw 52 --batch 32 --k 3] [--iters 20] [--tile BM BN] [--mode flat|patch]
+  python tools/conv_microbench.py --net       # every conv shape of yolov3-tiny at batch 64
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, ROOT)
+from yolo_quantization_amd import binding  # noqa: E402
+
+PEAK = 256 * 4 * 2048 * 2.4e9 / 1e12
+
+NET = [(16, 32, 208, 3), (32, 64, 104, 3), (64, 128, 52, 3), (128, 256, 26, 3), (256, 512, 13, 3), (512, 1024, 13, 3),
+       (1024, 256, 13, 1), (512, 30, 13, 1), (256, 128, 13, 1), (384, 256, 26, 3), (256, 30, 26, 1)]
+
+
+def run(c, n, hw, k, batch, iters, tile=None, mode=None, check=False):
+    S = binding.shim()
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 256, (batch, c, hw, hw), dtype=np.uint8)
+    wq = np.random.default_rng(2).integers(0, 256, (n, c * k * k), dtype=np.uint8)
+    zp_w = np.random.default_rng(3).integers(100, 157, n, dtype=np.uint8)
+    bias = np.zeros(n, np.int32)
+    mv = np.full(n, 0.75); sv = np.full(n, 2.0 ** -9)
+    xt = binding.DevTensor.from_nchw(x, 0)
+    y = binding.DevTensor(batch, hw, hw, n, 23)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, k, bias, mv, sv))
+    d = binding.ConvDesc(n, c, k, 1, k // 2, binding.ACT["leaky"], 0, 0, 0, 23, 1.0)
+    if tile or mode:
+        bm, bn = tile if tile else (0, 0)
+        flag = (1 << 30) if mode == "patch" else ((1 << 29) if mode == "flat" else 0)
+        S.mi355_conv_set_tile(bm, bn | flag)
+    st = C.c_void_p(); binding.check(S.mi355_stream_create(C.byref(st)))
+    e0 = C.c_void_p(); e1 = C.c_void_p()
+    S.mi355_event_create(C.byref(e0)); S.mi355_event_create(C.byref(e1))
+
+    def launch():
+        binding.check(S.mi355_conv_forward(C.byref(d), xt.ref(), blob.ptr, None, None, y.ref(), None, None, st), "conv")
+    for _ in range(3):
+        launch()
+    S.mi355_stream_sync(st)
+    S.mi355_event_record(e0, st)
+    for _ in range(iters):
+        launch()
+    S.mi355_event_record(e1, st)
+    ms = C.c_float()
+    binding.check(S.mi355_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
+    S.mi355_conv_set_tile(0, 0)
+    t = ms.value / iters * 1e-3
+    ops = 2.0 * n * c * k * k * hw * hw * batch
+    byt = x.size + wq.size + n * hw * hw * batch
+    return {"c": c, "n": n, "hw": hw, "k": k, "batch": batch, "us": round(t * 1e6, 2), "tops": round(ops / t / 1e12, 1),
+            "frac_mfma_peak": round(ops / t / 1e12 / PEAK, 4), "gbs": round(byt / t / 1e9, 1), "tile": tile, "mode": mode}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--c", type=int, default=256); ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--hw", type=int, default=52); ap.add_argument("--k", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--tile", type=int, nargs=2); ap.add_argument("--mode", choices=["flat", "patch"])
+    ap.add_argument("--net", action="store_true"); ap.add_argument("--sweep", action="store_true")
+    a = ap.parse_args()
+    binding.init(0)
+    if a.net:
+        for c, n, hw, k in NET:
+            print(json.dumps(run(c, n, hw, k, 64, a.iters)))
+    elif a.sweep:
+        for bm, bn in [(128, 256), (128, 128)]:
+            for mode in ["flat", "patch"]:
+                try:
+                    print(json.dumps(run(a.c, a.n, a.hw, a.k, a.batch, a.iters, (bm, bn), mode)))
+                except Exception as e:  # noqa: BLE001
+                    print(json.dumps({"tile": [bm, bn], "mode": mode, "error": str(e)[:100]}))
+    else:
+        print(json.dumps(run(a.c, a.n, a.hw, a.k, a.batch, a.iters, tuple(a.tile) if a.tile else None, a.mode)))

@@ -63,8 +63,10 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 constexpr int A_STAGES = 3;
 constexpr int BPT_MAX = 8;  // B DMA instructions per wave per chunk load (upper bound)
 
-template <int BM, int BN, int WMW, int WNW, bool PATCH>
-__global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_i8_kernel(const ConvArgs a)
+// KMODE: 0 = generic K loop (any cb, any ksize); 3 = cb==64 && ksize==3 (taps unrolled, address tables);
+//        1 = cb==64 && ksize==1
+template <int BM, int BN, int WMW, int WNW, bool PATCH, int KMODE>
+__global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv_igemm_i8_kernel(const ConvArgs a)
 {
     constexpr int NW = WMW * WNW, NT = 64 * NW;
     constexpr int TM = BM / WMW, TN = BN / WNW;
@@ -206,71 +208,153 @@ __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_i8_kernel(const Con
         arow[ms] = ((row >> 4) << 10) + ((row & 15) << 4);
     }
 
-    // ---- prologue: B(0), A(0), A(1)
-    issueB(0);
-    issueA(0);
-    if (a.ksteps > 1) issueA(1);
+    if constexpr (KMODE == 0) {
+        // ---- prologue: B(0), A(0), A(1)
+        issueB(0);
+        issueA(0);
+        if (a.ksteps > 1) issueA(1);
 
-    int chunk = 0, s = 0;
-    bool b_prev = false;  // a B load was issued in the previous iteration (after A(g), before A(g+1) in the queue)
-    for (int g = 0; g < a.ksteps; ++g) {
-        // ---- retire A(g) (and B(chunk) when this step opens a chunk), leave younger DMA in flight
-        {
-            const int younger_a = (g + 1 < a.ksteps) ? APT : 0;
-            int n = younger_a;
-            if (b_prev && s != 0) n += a.bpt;  // B(chunk+1) sits between A(g) and A(g+1): not needed yet
-            if (g == 0) n = (a.ksteps > 1) ? APT : 0;  // queue: B(0), A(0), A(1)
-            if (n == APT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");  // steady state
-            else wait_vmcnt(n);
-        }
-        __builtin_amdgcn_s_barrier();
-        // ---- issue DMA two steps ahead (stage (g+2)%3 was last read in step g-1: every wave is past it)
-        b_prev = false;
-        if (s == 0 && chunk + 1 < a.nchunks) {
-            issueB(chunk + 1);
-            b_prev = true;
-        }
-        if (g + 2 < a.ksteps) issueA(g + 2);
+        int chunk = 0, s = 0;
+        bool b_prev = false;  // a B load was issued in the previous iteration (after A(g), before A(g+1) in the queue)
+        for (int g = 0; g < a.ksteps; ++g) {
+            // ---- retire A(g) (and B(chunk) when this step opens a chunk), leave younger DMA in flight
+            {
+                const int younger_a = (g + 1 < a.ksteps) ? APT : 0;
+                int n = younger_a;
+                if (b_prev && s != 0) n += a.bpt;  // B(chunk+1) sits between A(g) and A(g+1): not needed yet
+                if (g == 0) n = (a.ksteps > 1) ? APT : 0;  // queue: B(0), A(0), A(1)
+                if (n == APT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");  // steady state
+                else wait_vmcnt(n);
+            }
+            __builtin_amdgcn_s_barrier();
+            // ---- issue DMA two steps ahead (stage (g+2)%3 was last read in step g-1: every wave is past it)
+            b_prev = false;
+            if (s == 0 && chunk + 1 < a.nchunks) {
+                issueB(chunk + 1);
+                b_prev = true;
+            }
+            if (g + 2 < a.ksteps) issueA(g + 2);
 
-        // ---- compute K-step g: 2 halves of 32 k each
-        {
-            const char *A = ldsA + (g % A_STAGES) * (BM * 64);
-            const char *Bt = ldsB + (chunk & 1) * bbytes;
+            // ---- compute K-step g: 2 halves of 32 k each
+            {
+                const char *A = ldsA + (g % A_STAGES) * (BM * 64);
+                const char *Bt = ldsB + (chunk & 1) * bbytes;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pk = 2 * h + kh;           // 16-byte piece of this K-step held by this lane
+                    const int u = 4 * s + pk;
+                    const bool valid = u < a.upc;
+                    const int uc = valid ? u : 0;
+                    const int tap = uc >> bpc_sh, blk = uc & (bpc - 1);
+                    int dcell = 0;
+                    if (a.ksize == 3) {
+                        const int ty = tap / 3, tx = tap - ty * 3;
+                        dcell = (ty - 1) * rs + (tx - 1);
+                    }
+                    const int ones = valid ? 0x01010101 : 0;
+                    v4i af[MS];
+#pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        af[ms] = *reinterpret_cast<const v4i *>(A + arow[ms] + pk * 256);
+#pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        const int ci = bcell[ns] + dcell;
+                        const int boff = ((ci >> cpc_sh) << 10) + blk * pstride + ((ci & (cpc - 1)) << 4);
+                        const v4i bf = *reinterpret_cast<const v4i *>(Bt + boff);
+                        int t = sx[ns];
+                        t = __builtin_amdgcn_sdot4(bf[0], ones, t, false);
+                        t = __builtin_amdgcn_sdot4(bf[1], ones, t, false);
+                        t = __builtin_amdgcn_sdot4(bf[2], ones, t, false);
+                        t = __builtin_amdgcn_sdot4(bf[3], ones, t, false);
+                        sx[ns] = t;
+#pragma unroll
+                        for (int ms = 0; ms < MS; ++ms)
+                            acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
+                    }
+                }
+            }
+            if (++s == a.spc) { s = 0; ++chunk; }
+        }
+    } else {
+        // ---- fast paths (cb == 64: one K-step = one tap of one 64-channel chunk).  All per-lane LDS addresses are
+        //      tabulated once per tile, so a K-step is 8 ds_read_b128 + 8 MFMA + 16 v_dot4 + a handful of VALU.
+        // per-lane cell -> LDS byte offset (piece-major chunks of 16 cells), incl. this lane's k-half
+        auto boff_of = [&](int ci) { return ((ci & ~15) << 6) + ((ci & 15) << 4) + kh * 256; };
+        int atab[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) atab[ms] = arow[ms] + kh * 256;
+
+        auto compute = [&](const char *A, const char *Bt, int dcell) {
+            int bt[NS];
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) bt[ns] = boff_of(bcell[ns] + dcell);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int pk = 2 * h + kh;           // 16-byte piece of this K-step held by this lane
-                const int u = 4 * s + pk;
-                const bool valid = u < a.upc;
-                const int uc = valid ? u : 0;
-                const int tap = uc >> bpc_sh, blk = uc & (bpc - 1);
-                int dcell = 0;
-                if (a.ksize == 3) {
-                    const int ty = tap / 3, tx = tap - ty * 3;
-                    dcell = (ty - 1) * rs + (tx - 1);
-                }
-                const int ones = valid ? 0x01010101 : 0;
                 v4i af[MS];
 #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    af[ms] = *reinterpret_cast<const v4i *>(A + arow[ms] + pk * 256);
+                for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const v4i *>(A + atab[ms] + h * 512);
 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns) {
-                    const int ci = bcell[ns] + dcell;
-                    const int boff = ((ci >> cpc_sh) << 10) + blk * pstride + ((ci & (cpc - 1)) << 4);
-                    const v4i bf = *reinterpret_cast<const v4i *>(Bt + boff);
+                    const v4i bf = *reinterpret_cast<const v4i *>(Bt + bt[ns] + h * 512);
                     int t = sx[ns];
-                    t = __builtin_amdgcn_sdot4(bf[0], ones, t, false);
-                    t = __builtin_amdgcn_sdot4(bf[1], ones, t, false);
-                    t = __builtin_amdgcn_sdot4(bf[2], ones, t, false);
-                    t = __builtin_amdgcn_sdot4(bf[3], ones, t, false);
+                    t = __builtin_amdgcn_sdot4(bf[0], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(bf[1], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(bf[2], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(bf[3], 0x01010101, t, false);
                     sx[ns] = t;
 #pragma unroll
                     for (int ms = 0; ms < MS; ++ms)
                         acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
                 }
             }
+        };
+
+        issueB(0);
+        issueA(0);
+        if (a.ksteps > 1) issueA(1);
+        if constexpr (KMODE == 3) {
+            for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+                const bool more_chunks = chunk + 1 < a.nchunks;
+                const char *Bt = ldsB + (chunk & 1) * bbytes;
+                const int g0 = chunk * 9;
+#pragma unroll 1
+                for (int ty = 0; ty < 3; ++ty) {
+                    const int drow = (ty - 1) * rs - 1;
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) {
+                        const int t = ty * 3 + tx;
+                        const int g = g0 + t;
+                        // queue (old -> young): A(g) [B(chunk+1) when it was issued at t==0 and this is t==1] A(g+1)
+                        if (tx == 1 && ty == 0 && more_chunks) wait_vmcnt(APT + a.bpt);
+                        else if (t < 8 || more_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // very last K-step: nothing younger
+                        __builtin_amdgcn_s_barrier();
+                        if (tx == 0 && ty == 0 && more_chunks) issueB(chunk + 1);
+                        if (t < 7 || more_chunks) issueA(g + 2);  // ring stage (g+2)%3 == (tx+2)%3: 9 taps/chunk
+                        compute(ldsA + tx * (BM * 64), Bt, drow + tx);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        } else {
+            // 1x1: every K-step opens a new 64-channel chunk: B(g) double buffered, A ring phase = g % 3
+            for (int g0 = 0; g0 < a.ksteps; g0 += 3) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int g = g0 + u;
+                    if (g < a.ksteps) {
+                        // queue: A(g) B(g) A(g+1)  (B(g) was issued in step g-1 before A(g+1))
+                        if (g + 1 < a.ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        if (g + 1 < a.ksteps) issueB(g + 1);
+                        if (g + 2 < a.ksteps) issueA(g + 2);
+                        compute(ldsA + u * (BM * 64), ldsB + (g & 1) * bbytes, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
         }
-        if (++s == a.spc) { s = 0; ++chunk; }
     }
 
     // ---- epilogue
@@ -315,38 +399,31 @@ __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_i8_kernel(const Con
                 for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = 0x80808080u;
                 continue;
             }
-            const int4 cw4 = *reinterpret_cast<const int4 *>(a.cw + oc0);
-            const int4 dz4 = *reinterpret_cast<const int4 *>(a.dzp + oc0);
-            const int4 bi4 = *reinterpret_cast<const int4 *>(a.bias + oc0);
-            const int cwv[4] = {cw4.x, cw4.y, cw4.z, cw4.w};
-            const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
-            const int biv[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
-            double mv[4], sv[4];
+            uint32_t packed[NS];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {  // arrays are padded to mpad: in-bounds even for oc >= n
-                mv[r] = a.mval[oc0 + r];
-                sv[r] = a.sval[oc0 + r];
-            }
+            for (int ns = 0; ns < NS; ++ns) packed[ns] = 0;
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-                uint32_t packed = 0;
+            for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
+                const int oc = oc0 + r;
+                const int cwv = a.cw[oc], dzv = a.dzp[oc], biv = a.bias[oc];
+                const double mv = a.mval[oc], sv = a.sval[oc];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int oc = oc0 + r;
-                    const int32_t accv = acc[ms][ns][grp * 4 + r] + cwv[r] + dzv[r] * sx[ns];
+                for (int ns = 0; ns < NS; ++ns) {
+                    const int32_t accv = acc[ms][ns][grp * 4 + r] + cwv + dzv * sx[ns];
                     uint32_t u8 = 0;
                     if (oc < a.n) {
-                        u8 = requant_u8(accv, biv[r], mv[r], sv[r], a.zp_act, a.act, a.store_mode);
+                        u8 = requant_u8(accv, biv, mv, sv, a.zp_act, a.act, a.store_mode);
                         if (nvalid[ns] && (a.acc_out || a.y_f32)) {
                             const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
                             if (a.acc_out) a.acc_out[ridx] = accv;
                             if (a.y_f32) a.y_f32[ridx] = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
                         }
                     }
-                    packed |= (u8 ^ 0x80u) << (8 * r);
+                    packed[ns] |= (u8 ^ 0x80u) << (8 * r);
                 }
-                *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed;
             }
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
         }
     }
     __syncthreads();
@@ -368,17 +445,18 @@ __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_i8_kernel(const Con
 // ---------------------------------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------------------
-static int g_force_bm = 0, g_force_bn = 0, g_force_patch = -1;
+static int g_force_bm = 0, g_force_bn = 0, g_force_patch = -1, g_force_generic = 0;
 extern "C" int mi355_conv_set_tile(int bm, int bn)
 {
     // bn > 0: force tile; bn encodes the N-tile mode in bit 30 (patch) / bit 29 (flat) for benchmarking
     g_force_patch = (bn & (1 << 30)) ? 1 : ((bn & (1 << 29)) ? 0 : -1);
+    g_force_generic = (bn & (1 << 28)) ? 1 : 0;  // bit 28: force the generic K loop (tests)
     g_force_bm = bm;
     g_force_bn = bn & 0xFFFF;
     return MI355_OK;
 }
 
-template <int BM, int BN, int WMW, int WNW, bool PATCH>
+template <int BM, int BN, int WMW, int WNW, bool PATCH, int KMODE>
 static int launch_cfg(ConvArgs &a, hipStream_t st)
 {
     constexpr int NW = WMW * WNW, NT = 64 * NW;
@@ -406,7 +484,7 @@ static int launch_cfg(ConvArgs &a, hipStream_t st)
     const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
     if (lds_epi > lds) lds = lds_epi;
     if (lds > 160 * 1024) return MI355_EINVAL;
-    auto kern = conv_igemm_i8_kernel<BM, BN, WMW, WNW, PATCH>;
+    auto kern = conv_igemm_i8_kernel<BM, BN, WMW, WNW, PATCH, KMODE>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
@@ -417,16 +495,28 @@ static int launch_cfg(ConvArgs &a, hipStream_t st)
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
 
-template <bool PATCH>
+template <bool PATCH, int KMODE>
 static int launch_mode(ConvArgs &a, hipStream_t st, int bm, int bn)
 {
-    if (bm == 128 && bn == 256) return launch_cfg<128, 256, 2, 4, PATCH>(a, st);
-    if (bm == 128 && bn == 128) return launch_cfg<128, 128, 2, 2, PATCH>(a, st);
-    if (bm == 64 && bn == 256) return launch_cfg<64, 256, 1, 4, PATCH>(a, st);
-    if (bm == 64 && bn == 128) return launch_cfg<64, 128, 1, 4, PATCH>(a, st);
-    if (bm == 32 && bn == 256) return launch_cfg<32, 256, 1, 4, PATCH>(a, st);
-    if (bm == 32 && bn == 128) return launch_cfg<32, 128, 1, 4, PATCH>(a, st);
+    if (bm == 128 && bn == 256) return launch_cfg<128, 256, 2, 4, PATCH, KMODE>(a, st);
+    if (bm == 128 && bn == 128) return launch_cfg<128, 128, 2, 2, PATCH, KMODE>(a, st);
+    if (bm == 64 && bn == 256) return launch_cfg<64, 256, 1, 4, PATCH, KMODE>(a, st);
+    if (bm == 64 && bn == 128) return launch_cfg<64, 128, 1, 4, PATCH, KMODE>(a, st);
+    if (bm == 32 && bn == 256) return launch_cfg<32, 256, 1, 4, PATCH, KMODE>(a, st);
+    if (bm == 32 && bn == 128) return launch_cfg<32, 128, 1, 4, PATCH, KMODE>(a, st);
     return MI355_EINVAL;
+}
+
+static int launch_any(ConvArgs &a, hipStream_t st, int bm, int bn, bool patch)
+{
+    const int kmode = (a.cb == 64 && !g_force_generic) ? (a.ksize == 3 ? 3 : 1) : 0;
+    if (patch) {  // PATCH is only meaningful for 3x3
+        if (kmode == 3) return launch_mode<true, 3>(a, st, bm, bn);
+        return launch_mode<true, 0>(a, st, bm, bn);
+    }
+    if (kmode == 3) return launch_mode<false, 3>(a, st, bm, bn);
+    if (kmode == 1) return launch_mode<false, 1>(a, st, bm, bn);
+    return launch_mode<false, 0>(a, st, bm, bn);
 }
 
 int conv_igemm_launch(ConvArgs &a, hipStream_t st)
@@ -443,12 +533,13 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
         if (patch) tiles = (long)a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
         else tiles = (a.total_n + 255) / 256;
         tiles *= (a.n + bm - 1) / bm;
-        if (tiles < 384) bn = 128;  // keep >= ~1.5 workgroups per CU on the small 13x13 / 26x26 layers
+        if (tiles < 200) bn = 128;  // measured: 256-wide tiles win down to ~0.8 workgroups per CU (r01 sweep)
     }
-    int rc = patch ? launch_mode<true>(a, st, bm, bn) : launch_mode<false>(a, st, bm, bn);
+    if (a.ksize == 1) patch = false;
+    int rc = launch_any(a, st, bm, bn, patch);
     if (rc == MI355_EINVAL && !(g_force_bm || g_force_bn)) {
         // staging budget exceeded (very wide rows in FLAT mode): fall back to the other mode / narrower tile
-        rc = patch ? launch_mode<false>(a, st, bm, 128) : launch_mode<true>(a, st, bm, 128);
+        rc = launch_any(a, st, bm, 128, a.ksize == 3 ? !patch : false);
     }
     return rc;
 }
