@@ -445,12 +445,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
 // ---------------------------------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------------------
-static int g_force_bm = 0, g_force_bn = 0, g_force_patch = -1, g_force_generic = 0;
+static int g_force_bm = 0, g_force_bn = 0, g_force_patch = -1, g_force_generic = 0, g_no_rows = 0;
 extern "C" int mi355_conv_set_tile(int bm, int bn)
 {
     // bn > 0: force tile; bn encodes the N-tile mode in bit 30 (patch) / bit 29 (flat) for benchmarking
     g_force_patch = (bn & (1 << 30)) ? 1 : ((bn & (1 << 29)) ? 0 : -1);
     g_force_generic = (bn & (1 << 28)) ? 1 : 0;  // bit 28: force the generic K loop (tests)
+    g_no_rows = (bn & (1 << 27)) ? 1 : 0;        // bit 27: do not use conv_rows.hip
     g_force_bm = bm;
     g_force_bn = bn & 0xFFFF;
     return MI355_OK;
@@ -523,6 +524,13 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
 {
     int bm = g_force_bm, bn = g_force_bn;
     if (!bm) bm = a.n >= 128 ? 128 : (a.n > 32 ? 64 : 32);
+    if (a.cb == 64 && !g_force_generic && !g_no_rows && g_force_patch < 0) {
+        // row-image kernel (conv_rows.hip): 256-wide tiles while two workgroups still fit a CU's LDS (W <= 14)
+        int rbn = bn ? bn : (a.W + 2 <= 16 ? 256 : 128);
+        int rc = conv_rows_launch(a, st, bm, rbn);
+        if (rc == MI355_EINVAL && !bn) rc = conv_rows_launch(a, st, bm, 128);
+        if (rc != MI355_EINVAL) return rc;
+    }
     // N-tile mode: PATCH when a 16-wide patch wastes little (W >= 24) -- its halo is (TH+2)x18 cells instead of two
     // full image rows; FLAT for the small maps where a patch would be mostly padding.
     bool patch = a.ksize == 3 && a.W >= 24 && a.H >= 8;

@@ -1,0 +1,401 @@
+// conv_rows.hip -- the MFMA implicit-GEMM INT8 convolution for layers whose input channels come in 64-byte chunks
+// (every 3x3 s1 / 1x1 layer of yolov3-tiny from the 4th conv on, and BASELINE config[1]).  Same mathematics as
+// conv_igemm.hip (read its header for the signed-operand decomposition); what differs is the inner loop, which is
+// built so that a K-step is almost nothing but 8 ds_read_b128 + 8 V_MFMA_I32_32X32X32_I8:
+//
+//   * LDS image of the B operand = whole image ROWS of the PHWC tensor, RS cells per row (RS = 16/32/64 >= W+2,
+//     a template constant), stored per row as [16-byte piece][RS cells][16 B].  A 3x3 tap (dy,dx) is then the
+//     compile-time byte offset dy*RS*64 + dx*16 from the lane's own pixel: every B fragment address is
+//     `lane base + immediate`, no per-step address arithmetic.  Consecutive lanes read consecutive 16-byte slots
+//     (conflict-free ds_read_b128 lane groups).
+//   * the receptive-field sums  sum_k x'  (needed because V_MFMA_*_I8 is signed x signed, see conv_igemm.hip) are NOT
+//     accumulated from the fragments any more (that cost 16 v_dot4 per K-step per wave): once per channel chunk every
+//     thread reduces one LDS cell (4 ds_read_b128 + 16 v_dot4) into an LDS int32 plane S[cell]; the epilogue forms the
+//     3x3 box sum of S.  9x less VALU work than per-tap accumulation.
+//   * A operand: 3-stage DMA ring (global_load_lds_dwordx4), B operand: double-buffered per channel chunk, DMA two
+//     K-steps ahead, one s_barrier per K-step, counted vmcnt waits -- as in conv_igemm.hip.
+//
+// Measured motivation (profiles/r01_*): with per-step address arithmetic and per-tap v_dot4 the kernel issued ~67
+// VALU + 44 SALU instructions per 8 MFMAs and SQ_VALU_MFMA_COEXEC_CYCLES showed they do not overlap the matrix pipe.
+#include "kargs.h"
+
+#define DMA16(gsrc, ldst)                                                                               \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),           \
+                                     (__attribute__((address_space(3))) void *)(ldst), 16, 0, 0)
+
+__device__ __forceinline__ void rows_wait_vmcnt(int n)
+{
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+constexpr int RA_STAGES = 3;
+constexpr int RBPT_MAX = 18;  // B DMA instructions per wave per chunk load (upper bound, keeps vmcnt <= 20)
+
+// global row index (over all image blocks, pad rows included) and column of valid pixel n
+__device__ __forceinline__ void row_of_pixel(int n, int H, int W, int &grow, int &x)
+{
+    const int hw = H * W;
+    const int b = n / hw;
+    const int r = n - b * hw;
+    const int y = r / W;
+    x = r - y * W;
+    grow = b * (H + 1) + y + 1;
+}
+
+template <int BM, int BN, int WMW, int WNW, int RS, int KS>
+__global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv_rows_i8_kernel(const ConvArgs a)
+{
+    constexpr int NW = WMW * WNW, NT = 64 * NW;
+    constexpr int TM = BM / WMW, TN = BN / WNW;
+    constexpr int MS = TM / 32, NS = TN / 32;
+    constexpr int ACH = BM / 16;
+    constexpr int APT = (ACH + NW - 1) / NW;
+    constexpr int HALO = (KS == 3) ? 1 : 0;
+    constexpr int ROWB = RS * 64;       // bytes of one LDS row (64 channels)
+    constexpr int PIECEB = RS * 16;     // bytes between 16-byte pieces of a row
+    constexpr int CPR = RS / 16;        // 1 KiB DMA chunks per row
+    constexpr int OSTR = BM + 4;
+    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *ldsA = smem;                                   // [3][BM*64]
+    char *ldsB = smem + RA_STAGES * BM * 64;             // [2][rows_cap*ROWB]
+    const int bbytes = a.rows_cap * ROWB;
+    int *ldsS = reinterpret_cast<int *>(ldsB + 2 * bbytes);  // [rows_cap*RS] receptive-field partial sums per cell
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int kh = lane >> 5, lj = lane & 31;
+
+    int logical;
+    {
+        const int nb = gridDim.x, id = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = id & 7, idx = id >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mtile = logical / a.ntiles_n;
+    const int ntile = logical - mtile * a.ntiles_n;
+    const int n0 = ntile * BN;
+    const int W1 = a.W + 1, hw = a.H * a.W;
+
+    // ---- tile rows: LDS row 0 = global row (row of first pixel) - HALO
+    int gr0, x0;
+    row_of_pixel(n0, a.H, a.W, gr0, x0);
+    int gr1, x1;
+    row_of_pixel(min(n0 + BN, a.total_n) - 1, a.H, a.W, gr1, x1);
+    const int grow_first = gr0 - HALO;
+    const int nrows = gr1 - gr0 + 1 + 2 * HALO;   // <= a.rows_cap (host guarantees)
+    const int ndma = nrows * CPR;                 // B DMA instructions per chunk load for the whole workgroup
+    const int bpt = (ndma + NW - 1) / NW;         // per wave (uniform; surplus slots repeat the last one)
+
+    // ---- per-lane B base: LDS byte offset of (its pixel's row - HALO, its column - HALO) for k-half kh
+    int bbase[NS];
+    int prow[NS], pcol[NS];
+    bool nvalid[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+        const int n = n0 + wn * TN + ns * 32 + lj;
+        nvalid[ns] = n < a.total_n;
+        int gr, x;
+        row_of_pixel(nvalid[ns] ? n : a.total_n - 1, a.H, a.W, gr, x);
+        prow[ns] = gr - grow_first - HALO;  // LDS row of tap dy = 0 (top tap)
+        pcol[ns] = x + 1 - HALO;            // LDS cell of tap dx = 0 (left tap); cell 0 of a row is x = -1
+        bbase[ns] = prow[ns] * ROWB + pcol[ns] * 16 + kh * PIECEB;
+    }
+    int atab[MS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+        const int row = wm * TM + ms * 32 + lj;
+        atab[ms] = ((row >> 4) << 10) + ((row & 15) << 4) + kh * 256;
+    }
+
+    // ---- DMA helpers.  Every wave issues exactly APT (A) / bpt (B) instructions per load.
+    const int8_t *asrc[APT];
+    int adst[APT];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+        const int ch = min(wave + i * NW, ACH - 1);
+        asrc[i] = a.wp + ((size_t)(mtile * ACH + ch) * a.ksteps) * 1024 + lane * 16;
+        adst[i] = ch << 10;
+    }
+    auto issueA = [&](int g, int stage) {
+        char *st = ldsA + stage * (BM * 64);
+#pragma unroll
+        for (int i = 0; i < APT; ++i) DMA16(asrc[i] + (size_t)g * 1024, st + adst[i]);
+    };
+    // B: DMA instruction j covers LDS bytes [j*1024, j*1024+1024) of the buffer: row = j / CPR, chunk-in-row = j % CPR.
+    // Inside a row the image is [piece][RS cells][16 B]: byte o -> piece o / PIECEB, cell (o % PIECEB) / 16.
+    const long cell0 = (long)a.in_lead + (long)grow_first * W1 - 1;  // global cell of LDS (row 0, cell 0)
+    auto issueB = [&](int chunk, int parity) {
+        char *buf = ldsB + parity * bbytes;
+        const int8_t *base = a.x + (size_t)chunk * 64;
+        for (int i = 0; i < bpt; ++i) {
+            const int j = min(wave + i * NW, ndma - 1);
+            const int r = j / CPR, cj = j - r * CPR;
+            const int o = cj * 1024 + lane * 16;
+            const int p = o / PIECEB, c = (o - p * PIECEB) >> 4;
+            long f = cell0 + (long)r * W1 + c;
+            f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
+            DMA16(base + f * a.in_cs + p * 16, buf + (j << 10));
+        }
+    };
+
+    v16i acc[MS][NS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0;
+
+    // zero the S plane (visible after the first barrier of the K loop)
+    for (int i = tid; i < a.rows_cap * RS; i += NT) ldsS[i] = 0;
+
+    auto compute = [&](const char *A, const char *Bt, int tapoff) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v4i af[MS];
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const v4i *>(A + atab[ms] + h * 512);
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+                const v4i bf = *reinterpret_cast<const v4i *>(Bt + bbase[ns] + tapoff + h * 2 * PIECEB);
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
+            }
+        }
+    };
+    // per channel chunk: every thread reduces cells of the freshly landed B buffer into S
+    auto cell_sums = [&](const char *Bt) {
+        const int ncells = nrows * RS;
+        for (int id = tid; id < ncells; id += NT) {
+            const int r = id / RS, c = id - r * RS;
+            const char *p0 = Bt + r * ROWB + c * 16;
+            int t = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const v4i v = *reinterpret_cast<const v4i *>(p0 + p * PIECEB);
+                t = __builtin_amdgcn_sdot4(v[0], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(v[1], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(v[2], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(v[3], 0x01010101, t, false);
+            }
+            ldsS[id] += t;  // each cell is owned by exactly one thread: plain read-modify-write
+        }
+    };
+
+    // ---- prologue: B(0), A(0), A(1)
+    issueB(0, 0);
+    issueA(0, 0);
+    if (a.ksteps > 1) issueA(1, 1);
+
+    if constexpr (KS == 3) {
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            const bool more_chunks = chunk + 1 < a.nchunks;
+            const char *Bt = ldsB + (chunk & 1) * bbytes;
+            const int g0 = chunk * 9;
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) {
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    const int t = ty * 3 + tx;
+                    const int g = g0 + t;
+                    // queue (old -> young): A(g) [B(chunk+1) when it was issued at t==0 and this is t==1] A(g+1)
+                    if (t == 1 && more_chunks) rows_wait_vmcnt(APT + bpt);
+                    else if (t < 8 || more_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (t == 0 && more_chunks) issueB(chunk + 1, (chunk + 1) & 1);
+                    if (t < 7 || more_chunks) issueA(g + 2, (tx + 2) % 3);  // 9 taps/chunk keep the ring phase static
+                    compute(ldsA + tx * (BM * 64), Bt, ty * ROWB + tx * 16);
+                    if (t == 1) cell_sums(Bt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    } else {
+        for (int g0 = 0; g0 < a.ksteps; g0 += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int g = g0 + u;
+                if (g < a.ksteps) {
+                    // queue: A(g) B(g) A(g+1)  (B(g) was issued in step g-1 before A(g+1))
+                    if (g + 1 < a.ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (g + 1 < a.ksteps) issueB(g + 1, (g + 1) & 1);
+                    if (g + 2 < a.ksteps) issueA(g + 2, (u + 2) % 3);
+                    const char *Bt = ldsB + (g & 1) * bbytes;
+                    compute(ldsA + u * (BM * 64), Bt, 0);
+                    cell_sums(Bt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue
+    __syncthreads();  // S complete, all fragment reads done
+    int sx[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+        int t = 0;
+        const int c0 = prow[ns] * RS + pcol[ns];
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) t += ldsS[c0 + dy * RS + dx];
+        sx[ns] = t;
+    }
+    __syncthreads();  // before the LDS is reused as the [BN][BM+4] uint8 output tile
+    char *otile = smem;
+    int *celltab = reinterpret_cast<int *>(smem + BN * OSTR);
+    const int m0 = mtile * BM;
+
+    int pb_[NS], rem[NS], nl_[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+        const int nl = wn * TN + ns * 32 + lj;
+        nl_[ns] = nl;
+        const int nn = nvalid[ns] ? n0 + nl : 0;
+        const int b = nn / hw;
+        const int rem0 = nn - b * hw;
+        const int y = rem0 / a.W, xx = rem0 - y * a.W;
+        pb_[ns] = b;
+        rem[ns] = rem0;
+        if (wm == 0 && kh == 0) celltab[nl] = nvalid[ns] ? a.out_lead + (b * (a.H + 1) + (y + 1)) * W1 + xx : -1;
+    }
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;  // 4 consecutive channels held by this lane
+            const int oc0 = m0 + ocl;
+            if (oc0 >= a.n) {
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = 0x80808080u;
+                continue;
+            }
+            uint32_t packed[NS];
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) packed[ns] = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
+                const int oc = oc0 + r;
+                const int cwv = a.cw[oc], dzv = a.dzp[oc], biv = a.bias[oc];
+                const double mv = a.mval[oc], sv = a.sval[oc];
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    const int32_t accv = acc[ms][ns][grp * 4 + r] + cwv + dzv * sx[ns];
+                    uint32_t u8 = 0;
+                    if (oc < a.n) {
+                        u8 = requant_u8(accv, biv, mv, sv, a.zp_act, a.act, a.store_mode);
+                        if (nvalid[ns] && (a.acc_out || a.y_f32)) {
+                            const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
+                            if (a.acc_out) a.acc_out[ridx] = accv;
+                            if (a.y_f32) a.y_f32[ridx] = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
+                        }
+                    }
+                    packed[ns] |= (u8 ^ 0x80u) << (8 * r);
+                }
+            }
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
+        }
+    }
+    __syncthreads();
+    if (a.y) {
+        const int dwords = min(BM, a.out_cs - m0) >> 2;
+        const int total = BN * dwords;
+        for (int p = tid; p < total; p += NT) {
+            const int pix = p / dwords, d = p - pix * dwords;
+            const int cell = celltab[pix];
+            if (cell >= 0)
+                *reinterpret_cast<uint32_t *>(a.y + (size_t)cell * a.out_cs + m0 + d * 4) =
+                    *reinterpret_cast<const uint32_t *>(otile + pix * OSTR + d * 4);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WMW, int WNW, int RS, int KS>
+static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
+{
+    constexpr int NW = WMW * WNW, NT = 64 * NW;
+    constexpr int HALO = (KS == 3) ? 1 : 0;
+    if (a.mpad % BM) return MI355_EINVAL;
+    a.mtiles = a.mpad / BM;
+    a.ntiles_n = (a.total_n + BN - 1) / BN;
+    // rows spanned by BN consecutive pixels: pixel rows + one pad row per image boundary crossed, + halo rows
+    a.rows_cap = (BN - 2 + a.W) / a.W + 1 + (BN - 2 + a.H * a.W) / (a.H * a.W) + 2 * HALO;
+    const int ndma = a.rows_cap * (RS / 16);
+    if ((ndma + NW - 1) / NW > RBPT_MAX) return MI355_EINVAL;
+    size_t lds = (size_t)RA_STAGES * BM * 64 + 2 * (size_t)a.rows_cap * RS * 64 + (size_t)a.rows_cap * RS * 4;
+    const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
+    if (lds_epi > lds) lds = lds_epi;
+    if (lds > 160 * 1024) return MI355_EINVAL;
+    auto kern = conv_rows_i8_kernel<BM, BN, WMW, WNW, RS, KS>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return MI355_EHIP;
+    }
+    dim3 grid(a.ntiles_n * a.mtiles), block(NT);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
+template <int RS, int KS>
+static int rows_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
+{
+    if (bm == 128 && bn == 256) return rows_launch_cfg<128, 256, 2, 4, RS, KS>(a, st);
+    if (bm == 128 && bn == 128) return rows_launch_cfg<128, 128, 2, 2, RS, KS>(a, st);
+    if (bm == 64 && bn == 256) return rows_launch_cfg<64, 256, 1, 4, RS, KS>(a, st);
+    if (bm == 64 && bn == 128) return rows_launch_cfg<64, 128, 1, 4, RS, KS>(a, st);
+    if (bm == 32 && bn == 256) return rows_launch_cfg<32, 256, 1, 4, RS, KS>(a, st);
+    if (bm == 32 && bn == 128) return rows_launch_cfg<32, 128, 1, 4, RS, KS>(a, st);
+    return MI355_EINVAL;
+}
+
+// returns MI355_EINVAL when the shape is outside this kernel's domain (caller falls back to conv_igemm.hip)
+int conv_rows_launch(ConvArgs &a, hipStream_t st, int bm, int bn)
+{
+    if (a.cb != 64) return MI355_EINVAL;
+    const int need = a.W + 2;
+    if (a.ksize == 3) {
+        if (need <= 16) return rows_launch_tile<16, 3>(a, st, bm, bn);
+        if (need <= 32) return rows_launch_tile<32, 3>(a, st, bm, bn);
+        if (need <= 64) return rows_launch_tile<64, 3>(a, st, bm, bn);
+    } else {
+        if (need <= 16) return rows_launch_tile<16, 1>(a, st, bm, bn);
+        if (need <= 32) return rows_launch_tile<32, 1>(a, st, bm, bn);
+        if (need <= 64) return rows_launch_tile<64, 1>(a, st, bm, bn);
+    }
+    return MI355_EINVAL;
+}

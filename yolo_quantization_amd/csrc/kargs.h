@@ -20,6 +20,7 @@ struct ConvArgs {
     int mpad;
     int bchunks, bpt;        // LDS B buffer size in KiB chunks; DMA instructions per wave per chunk load
     int tiles_x, tiles_y;    // PATCH mode tiling of one image
+    int rows_cap;            // conv_rows: LDS rows per B buffer
 };
 
 struct AuxArgs {
@@ -60,6 +61,7 @@ struct LayoutArgs {
 };
 
 int conv_igemm_launch(ConvArgs &a, hipStream_t st);
+int conv_rows_launch(ConvArgs &a, hipStream_t st, int bm, int bn);
 int conv_first_launch(AuxArgs &a, hipStream_t st);
 int conv_ref_f32_launch(AuxArgs &a, hipStream_t st);
 int maxpool_launch(const PoolArgs &a, hipStream_t st);
