@@ -18,6 +18,7 @@
 // Measured motivation (profiles/r01_*): with per-step address arithmetic and per-tap v_dot4 the kernel issued ~67
 // VALU + 44 SALU instructions per 8 MFMAs and SQ_VALU_MFMA_COEXEC_CYCLES showed they do not overlap the matrix pipe.
 #include "kargs.h"
+#include <type_traits>
 
 #define DMA16(gsrc, ldst)                                                                               \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),           \
@@ -51,7 +52,9 @@ __device__ __forceinline__ void rows_wait_vmcnt(int n)
     }
 }
 
-constexpr int RA_STAGES = 3;
+// A ring depth: 3 for the plain 1x1 loop, 4 for the software-pipelined 3x3 loop (fragments of step g+1 are read
+// while the MFMAs of step g run, so A(g), A(g+1) are being read while A(g+2), A(g+3) are in flight)
+template <int KS> constexpr int ra_stages() { return KS == 3 ? 4 : 3; }
 constexpr int RBPT_MAX = 18;  // B DMA instructions per wave per chunk load (upper bound, keeps vmcnt <= 20)
 
 // global row index (over all image blocks, pad rows included) and column of valid pixel n
@@ -78,10 +81,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
     constexpr int PIECEB = RS * 16;     // bytes between 16-byte pieces of a row
     constexpr int CPR = RS / 16;        // 1 KiB DMA chunks per row
     constexpr int OSTR = BM + 4;
+    constexpr int RA_STAGES = ra_stages<KS>();
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *ldsA = smem;                                   // [3][BM*64]
+    char *ldsA = smem;                                   // [RA_STAGES][BM*64]
     char *ldsB = smem + RA_STAGES * BM * 64;             // [2][rows_cap*ROWB]
     const int bbytes = a.rows_cap * ROWB;
     int *ldsS = reinterpret_cast<int *>(ldsB + 2 * bbytes);  // [rows_cap*RS] receptive-field partial sums per cell
@@ -210,36 +214,115 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         }
     };
 
-    // ---- prologue: B(0), A(0), A(1)
-    issueB(0, 0);
-    issueA(0, 0);
-    if (a.ksteps > 1) issueA(1, 1);
-
     if constexpr (KS == 3) {
+        // ---- software-pipelined 3x3 loop.  Fragment registers are two half-sets (k-half 0 / k-half 1 of a K-step):
+        //        step g:  wait A(g+1) landed; s_barrier; issue DMA A(g+3) [B(chunk+1)]
+        //                 ds_read H1(g)      ||  MFMA H0(g)      (H0(g) was read during step g-1)
+        //                 ds_read H0(g+1)    ||  MFMA H1(g)
+        //      so every LDS read is in flight under 4 MFMAs (128 matrix-pipe cycles) of the same wave.
+        v4i a0[MS], b0[NS], a1[MS], b1[NS];
+        // Fragment reads are issued as inline asm so that hipcc does not account for them: its own bookkeeping puts an
+        // s_waitcnt lgkmcnt(0) in front of the first MFMA after ANY ds_read, which would serialise the read of the
+        // next half-set behind the current MFMAs.  We count instead: LDS returns in order, every load_half issues
+        // exactly MS+NS reads, and each MFMA group is preceded by lgkmcnt(MS+NS) (the younger half-set may still fly).
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+        unsigned aaddr[MS], baddr[NS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) aaddr[ms] = lds0 + atab[ms];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) baddr[ns] = lds0 + RA_STAGES * BM * 64 + bbase[ns];
+#define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+        auto load_half = [&](v4i(&af)[MS], v4i(&bf)[NS], unsigned aoff, unsigned boff, auto tap_c, auto h_c) {
+            constexpr int TAPOFF = decltype(tap_c)::value, H = decltype(h_c)::value;
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+                const unsigned ad = aaddr[ms] + aoff;
+                LDS_READ128(af[ms], ad, H * 512);
+            }
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+                const unsigned ad = baddr[ns] + boff;
+                LDS_READ128(bf[ns], ad, TAPOFF + H * 2 * PIECEB);
+            }
+        };
+        auto mfma_half = [&](const v4i(&af)[MS], const v4i(&bf)[NS]) {
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf[ns], acc[ms][ns], 0, 0, 0);
+        };
+        // prologue: B(0), A(0), A(1), A(2); retire all but A(2); first half-set
+        issueB(0, 0);
+        issueA(0, 0);
+        if (a.ksteps > 1) issueA(1, 1);
+        if (a.ksteps > 2) issueA(2, 2);
+        if (a.ksteps > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_half(a0, b0, 0u, 0u, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         for (int chunk = 0; chunk < a.nchunks; ++chunk) {
             const bool more_chunks = chunk + 1 < a.nchunks;
             const char *Bt = ldsB + (chunk & 1) * bbytes;
+            const unsigned bo_cur = (chunk & 1) * bbytes, bo_nxt = ((chunk + 1) & 1) * bbytes;
             const int g0 = chunk * 9;
-#pragma unroll
-            for (int ty = 0; ty < 3; ++ty) {
-#pragma unroll
-                for (int tx = 0; tx < 3; ++tx) {
-                    const int t = ty * 3 + tx;
-                    const int g = g0 + t;
-                    // queue (old -> young): A(g) [B(chunk+1) when it was issued at t==0 and this is t==1] A(g+1)
+            const int cph = chunk & 3;  // ring phase of tap 0: (9*chunk) % 4 == chunk % 4
+            auto step = [&](auto t_c) {
+                constexpr int t = decltype(t_c)::value;
+                constexpr int ty = t / 3, tx = t % 3;
+                constexpr int TAP = ty * ROWB + tx * 16;
+                constexpr int TAPN = ((t + 1) / 3) * ROWB + ((t + 1) % 3) * 16;
+                const int g = g0 + t;
+                if (g > 0) {
+                    // queue (old -> young): A(g+1) [B(chunk+1) if it was issued in the previous step] A(g+2)
+                    const bool a2 = (t < 7) || more_chunks;  // A(g+2) exists
                     if (t == 1 && more_chunks) rows_wait_vmcnt(APT + bpt);
-                    else if (t < 8 || more_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
+                    else if (a2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
-                    if (t == 0 && more_chunks) issueB(chunk + 1, (chunk + 1) & 1);
-                    if (t < 7 || more_chunks) issueA(g + 2, (tx + 2) % 3);  // 9 taps/chunk keep the ring phase static
-                    compute(ldsA + tx * (BM * 64), Bt, ty * ROWB + tx * 16);
-                    if (t == 1) cell_sums(Bt);
+                }
+                if (t == 0 && more_chunks) issueB(chunk + 1, (chunk + 1) & 1);
+                if (t < 6 || more_chunks) issueA(g + 3, (cph + t + 3) & 3);
+                __builtin_amdgcn_sched_barrier(0);
+                load_half(a1, b1, (unsigned)(((cph + t) & 3) * (BM * 64)), bo_cur, std::integral_constant<int, TAP>{},
+                          std::integral_constant<int, 1>{});
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");  // H0(g) landed
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_half(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t < 8) {
+                    load_half(a0, b0, (unsigned)(((cph + t + 1) & 3) * (BM * 64)), bo_cur,
+                              std::integral_constant<int, TAPN>{}, std::integral_constant<int, 0>{});
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");  // H1(g) landed
+                } else if (more_chunks) {
+                    load_half(a0, b0, (unsigned)(((cph + 9) & 3) * (BM * 64)), bo_nxt, std::integral_constant<int, 0>{},
+                              std::integral_constant<int, 0>{});
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_half(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 1) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // our reads are invisible to hipcc's counters
+                    cell_sums(Bt);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+            step(std::integral_constant<int, 8>{});
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef LDS_READ128
     } else {
+        issueB(0, 0);
+        issueA(0, 0);
+        if (a.ksteps > 1) issueA(1, 1);
         for (int g0 = 0; g0 < a.ksteps; g0 += 3) {
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -356,7 +439,7 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     a.rows_cap = (BN - 2 + a.W) / a.W + 1 + (BN - 2 + a.H * a.W) / (a.H * a.W) + 2 * HALO;
     const int ndma = a.rows_cap * (RS / 16);
     if ((ndma + NW - 1) / NW > RBPT_MAX) return MI355_EINVAL;
-    size_t lds = (size_t)RA_STAGES * BM * 64 + 2 * (size_t)a.rows_cap * RS * 64 + (size_t)a.rows_cap * RS * 4;
+    size_t lds = (size_t)ra_stages<KS>() * BM * 64 + 2 * (size_t)a.rows_cap * RS * 64 + (size_t)a.rows_cap * RS * 4;
     const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
     if (lds_epi > lds) lds = lds_epi;
     if (lds > 160 * 1024) return MI355_EINVAL;
