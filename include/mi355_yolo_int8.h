@@ -127,6 +127,9 @@ int mi355_conv_forward(const mi355_conv_desc *desc, const mi355_tensor *x, const
 
 /* Tile configuration override for benchmarking (0 = auto). */
 int mi355_conv_set_tile(int bm, int bn);
+/* Timing-ablation switches for kernel development (bit 0: no DMA in the K loop, 1: no s_barrier, 2: no MFMA,
+ * 4: no cell sums).  Results are WRONG when non-zero; never set outside tools/conv_microbench.py --ablate. */
+int mi355_debug_flags(int flags);
 
 /* ---- glue layers ---------------------------------------------------------------------------------------- */
 /* forward_maxpool_layer_quant (ref: src/maxpool_layer.c:109-172): window offset -pad/2, OOB taps = uint8 0 */

@@ -69,9 +69,17 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--tile", type=int, nargs=2); ap.add_argument("--mode", choices=["flat", "patch"])
     ap.add_argument("--net", action="store_true"); ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--ablate", action="store_true", help="timing ablation of the K loop (results are wrong)")
     a = ap.parse_args()
     binding.init(0)
-    if a.net:
+    if a.ablate:
+        S = binding.shim()
+        for flags, name in [(0, "full"), (1, "no-dma"), (2, "no-barrier"), (4, "no-mfma"), (16, "no-cellsum"), (3, "no-dma,no-barrier"), (5, "no-dma,no-mfma"), (7, "only-lds-reads"), (15, "nothing-in-loop"), (32, "no-epilogue"), (47, "empty-kernel"), (63, "empty-kernel-no-cellsum"), (15 + 64, "epi-no-requant"), (15 + 128, "epi-no-copyout"), (15 + 64 + 128, "epi-neither")]:
+            S.mi355_debug_flags(flags)
+            r = run(a.c, a.n, a.hw, a.k, a.batch, a.iters, tuple(a.tile) if a.tile else None, a.mode)
+            print(name, r["us"], "us", r["tops"], "TOPS")
+        S.mi355_debug_flags(0)
+    elif a.net:
         for c, n, hw, k in NET:
             print(json.dumps(run(c, n, hw, k, 64, a.iters)))
     elif a.sweep:

@@ -27,6 +27,11 @@ struct ConvBlobHeader {
     int32_t first;      // 1: first-layer (c==3) packing: wp = [n][9] dwords (ky,kx)(c0,c1,c2,0) plain uint8
     uint64_t off_wp, off_cw, off_dzp, off_bias, off_mval, off_sval;  // byte offsets from blob start
     uint64_t total;
+    uint64_t off_shift;  // int32[mpad]: right shift s when shift_value == 2^-s exactly for every channel (pow2 == 1)
+    int32_t pow2;        // 1: every shift_value is an exact power of two 2^-s with 0 <= s <= 31 (the reference's case)
+    int32_t pad_;
+    uint64_t off_mprime; // f64[mpad]: M_value * shift_value (exact product when pow2)
+    uint64_t off_cwb;    // int32[mpad]: cw + biases_int32 (the two per-channel additive constants folded)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -55,6 +60,32 @@ __device__ __forceinline__ uint32_t requant_u8(int32_t acc, int32_t bias, double
     }
     if (store_mode == MI355_STORE_SATURATE) v = v < 0 ? 0 : (v > 255 ? 255 : v);
     return (uint32_t)v & 0xFFu;  // uint8_t store: modular
+}
+
+// Fast form (valid when every shift_value is an exact power of two 2^-s, which is how the reference builds it:
+// M0_right_shift_value = pow(2, -shift), src/blas.c:315).  With d = fl((acc+bias) * M_value):
+//     q = trunc(trunc(d) * 2^-s) = trunc(d * 2^-s)          (nested truncation toward zero by an integer divisor)
+//       = trunc(fl((acc+bias) * (M_value * 2^-s)))          (scaling by a power of two commutes with rounding)
+// so ONE double multiply by the pre-folded Mp = M_value * shift_value and ONE truncating convert give the
+// reference's q bit for bit.  `accb` already contains acc + cw + dz*sx + biases_int32.  Activation / store mode
+// are compile-time constants.  LEAKY: round((double)q * 0.1) == -((|q| + 5) / 10) for every negative int32 q
+// (exhaustively verified); the division uses a 24-bit multiply when |q| + 5 < 2^16 and v_mul_hi otherwise.
+template <int ACT, bool SAT>
+__device__ __forceinline__ uint32_t requant_u8_fast(int32_t accb, double Mp, int zp_act)
+{
+    const int32_t q = (int32_t)((double)accb * Mp);
+    int32_t v;
+    if (ACT == MI355_ACT_LEAKY) {
+        const uint32_t x = (0u - (uint32_t)q) + 5u;
+        const uint32_t d10 = x < 65536u ? (__umul24(x, 0xCCCDu) >> 19) : x / 10u;
+        v = q < 0 ? zp_act - (int32_t)d10 : q + zp_act;
+    } else if (ACT == MI355_ACT_RELU6) {
+        v = q <= 0 ? zp_act : q + zp_act;
+    } else {
+        v = q + zp_act;
+    }
+    if (SAT) v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    return (uint32_t)v & 0xFFu;
 }
 
 // cell index of pixel n (n enumerates b,y,x) in a PHWC tensor

@@ -446,6 +446,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------------------
 static int g_force_bm = 0, g_force_bn = 0, g_force_patch = -1, g_force_generic = 0, g_no_rows = 0;
+static int g_debug = 0;
+extern "C" int mi355_debug_flags(int flags)
+{
+    g_debug = flags;
+    return MI355_OK;
+}
 extern "C" int mi355_conv_set_tile(int bm, int bn)
 {
     // bn > 0: force tile; bn encodes the N-tile mode in bit 30 (patch) / bit 29 (flat) for benchmarking
@@ -486,7 +492,9 @@ static int launch_cfg(ConvArgs &a, hipStream_t st)
     if (lds_epi > lds) lds = lds_epi;
     if (lds > 160 * 1024) return MI355_EINVAL;
     auto kern = conv_igemm_i8_kernel<BM, BN, WMW, WNW, PATCH, KMODE>;
-    if (lds > 64 * 1024) {
+    static size_t lds_attr = 0;  // per kernel instantiation: raise the dynamic-LDS limit once, not per launch
+    if (lds > 64 * 1024 && lds > lds_attr) {
+        lds_attr = lds;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return MI355_EHIP;
@@ -524,6 +532,7 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
 {
     int bm = g_force_bm, bn = g_force_bn;
     if (!bm) bm = a.n >= 128 ? 128 : (a.n > 32 ? 64 : 32);
+    a.debug = g_debug;
     if (a.cb == 64 && !g_force_generic && !g_no_rows && g_force_patch < 0) {
         // row-image kernel (conv_rows.hip): 256-wide tiles while two workgroups still fit a CU's LDS (W <= 14)
         int rbn = bn ? bn : (a.W + 2 <= 16 ? 256 : 128);

@@ -89,6 +89,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
     char *ldsB = smem + RA_STAGES * BM * 64;             // [2][rows_cap*ROWB]
     const int bbytes = a.rows_cap * ROWB;
     int *ldsS = reinterpret_cast<int *>(ldsB + 2 * bbytes);  // [rows_cap*RS] receptive-field partial sums per cell
+    // per-channel epilogue parameters of this M tile, staged once (the epilogue would otherwise issue 5 dependent
+    // global loads per output channel per lane): doubles first (8-byte aligned), then the three int planes
+    double *ldsPM = reinterpret_cast<double *>(smem + a.lds_param_off);  // [BM] M_value, [BM] shift_value
+    int *ldsPI = reinterpret_cast<int *>(ldsPM + 3 * BM);                  // [BM] cw, dzp, bias, cw+bias
+    // ldsPM: [BM] M_value, [BM] shift_value, [BM] M_value*shift_value
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -177,8 +182,18 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0;
 
-    // zero the S plane (visible after the first barrier of the K loop)
+    // zero the S plane, stage the epilogue parameters (both visible after the first barrier of the K loop)
     for (int i = tid; i < a.rows_cap * RS; i += NT) ldsS[i] = 0;
+    for (int i = tid; i < BM; i += NT) {
+        const int oc = mtile * BM + i;  // parameter arrays are padded to mpad
+        ldsPM[i] = a.mval[oc];
+        ldsPM[BM + i] = a.sval[oc];
+        ldsPI[i] = a.cw[oc];
+        ldsPI[BM + i] = a.dzp[oc];
+        ldsPI[2 * BM + i] = a.bias[oc];
+        ldsPI[3 * BM + i] = a.cwb[oc];
+        ldsPM[2 * BM + i] = a.mprime[oc];
+    }
 
     auto compute = [&](const char *A, const char *Bt, int tapoff) {
 #pragma unroll
@@ -279,18 +294,20 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
                     if (t == 1 && more_chunks) rows_wait_vmcnt(APT + bpt);
                     else if (a2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
+                    if (!(a.debug & 2)) __builtin_amdgcn_s_barrier();
                 }
-                if (t == 0 && more_chunks) issueB(chunk + 1, (chunk + 1) & 1);
-                if (t < 6 || more_chunks) issueA(g + 3, (cph + t + 3) & 3);
+                if (t == 0 && more_chunks && !(a.debug & 1)) issueB(chunk + 1, (chunk + 1) & 1);
+                if ((t < 6 || more_chunks) && !(a.debug & 1)) issueA(g + 3, (cph + t + 3) & 3);
                 __builtin_amdgcn_sched_barrier(0);
+                if (!(a.debug & 8))
                 load_half(a1, b1, (unsigned)(((cph + t) & 3) * (BM * 64)), bo_cur, std::integral_constant<int, TAP>{},
                           std::integral_constant<int, 1>{});
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");  // H0(g) landed
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_half(a0, b0);
+                if (!(a.debug & 4)) mfma_half(a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (t < 8) {
+                if (a.debug & 8) {
+                } else if (t < 8) {
                     load_half(a0, b0, (unsigned)(((cph + t + 1) & 3) * (BM * 64)), bo_cur,
                               std::integral_constant<int, TAPN>{}, std::integral_constant<int, 0>{});
                     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");  // H1(g) landed
@@ -302,9 +319,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_half(a1, b1);
+                if (!(a.debug & 4)) mfma_half(a1, b1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (t == 1) {
+                if (t == 1 && !(a.debug & 16)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // our reads are invisible to hipcc's counters
                     cell_sums(Bt);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -343,6 +360,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         }
     }
 
+    if (a.debug & 32) {  // timing ablation: no epilogue (keep the accumulators alive)
+        if (acc[0][0][0] == 0x7fffffff && a.y) a.y[tid] = 1;
+        return;
+    }
     // ---- epilogue
     __syncthreads();  // S complete, all fragment reads done
     int sx[NS];
@@ -374,54 +395,114 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         rem[ns] = rem0;
         if (wm == 0 && kh == 0) celltab[nl] = nvalid[ns] ? a.out_lead + (b * (a.H + 1) + (y + 1)) * W1 + xx : -1;
     }
+    // Fast path: whole M tile inside n, no parity dumps, power-of-two shifts (always true for the reference's prep):
+    // activation and store mode become compile-time constants and the per-output code is branch free.
+    const bool fast = !a.acc_out && !a.y_f32 && (m0 + BM <= a.n) && a.hdr->pow2 == 1;
+    auto epi_fast = [&](auto act_c, auto sat_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool SAT = decltype(sat_c)::value != 0;
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
+        for (int ms = 0; ms < MS; ++ms) {
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;  // 4 consecutive channels held by this lane
-            const int oc0 = m0 + ocl;
-            if (oc0 >= a.n) {
+            for (int grp = 0; grp < 4; ++grp) {
+                const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;
+                const int4 dz4 = *reinterpret_cast<const int4 *>(ldsPI + BM + ocl);
+                const int4 cb4 = *reinterpret_cast<const int4 *>(ldsPI + 3 * BM + ocl);
+                const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, cbv[4] = {cb4.x, cb4.y, cb4.z, cb4.w};
+                uint32_t packed[NS];
 #pragma unroll
-                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = 0x80808080u;
-                continue;
-            }
-            uint32_t packed[NS];
+                for (int ns = 0; ns < NS; ++ns) packed[ns] = 0;
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) packed[ns] = 0;
+                for (int r = 0; r < 4; ++r) {
+                    const double mp = ldsPM[2 * BM + ocl + r];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
-                const int oc = oc0 + r;
-                const int cwv = a.cw[oc], dzv = a.dzp[oc], biv = a.bias[oc];
-                const double mv = a.mval[oc], sv = a.sval[oc];
-#pragma unroll
-                for (int ns = 0; ns < NS; ++ns) {
-                    const int32_t accv = acc[ms][ns][grp * 4 + r] + cwv + dzv * sx[ns];
-                    uint32_t u8 = 0;
-                    if (oc < a.n) {
-                        u8 = requant_u8(accv, biv, mv, sv, a.zp_act, a.act, a.store_mode);
-                        if (nvalid[ns] && (a.acc_out || a.y_f32)) {
-                            const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
-                            if (a.acc_out) a.acc_out[ridx] = accv;
-                            if (a.y_f32) a.y_f32[ridx] = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
-                        }
+                    for (int ns = 0; ns < NS; ++ns) {
+                        // |dz| <= 128 and |sx| < 2^23 (K <= 64K): 24-bit multiply, full rate
+                        const int32_t accb = acc[ms][ns][grp * 4 + r] + cbv[r] + __mul24(dzv[r], sx[ns]);
+                        const uint32_t u8 = requant_u8_fast<ACT, SAT>(accb, mp, a.zp_act);
+                        packed[ns] |= (u8 ^ 0x80u) << (8 * r);
                     }
-                    packed[ns] |= (u8 ^ 0x80u) << (8 * r);
                 }
-            }
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
+                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
+            }
+        }
+    };
+    using std::integral_constant;
+    if (a.debug & 64) {
+    } else if (fast) {
+        const bool sat = a.store_mode == MI355_STORE_SATURATE;
+        if (a.act == MI355_ACT_LEAKY) {
+            if (sat) epi_fast(integral_constant<int, MI355_ACT_LEAKY>{}, integral_constant<int, 1>{});
+            else epi_fast(integral_constant<int, MI355_ACT_LEAKY>{}, integral_constant<int, 0>{});
+        } else if (a.act == MI355_ACT_RELU6) {
+            if (sat) epi_fast(integral_constant<int, MI355_ACT_RELU6>{}, integral_constant<int, 1>{});
+            else epi_fast(integral_constant<int, MI355_ACT_RELU6>{}, integral_constant<int, 0>{});
+        } else {
+            if (sat) epi_fast(integral_constant<int, MI355_ACT_LINEAR>{}, integral_constant<int, 1>{});
+            else epi_fast(integral_constant<int, MI355_ACT_LINEAR>{}, integral_constant<int, 0>{});
+        }
+    } else {
+    #pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+    #pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;  // 4 consecutive channels held by this lane
+                const int oc0 = m0 + ocl;
+                if (oc0 >= a.n) {
+    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = 0x80808080u;
+                    continue;
+                }
+                uint32_t packed[NS];
+    #pragma unroll
+                for (int ns = 0; ns < NS; ++ns) packed[ns] = 0;
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
+                    const int oc = oc0 + r;
+                    const int cwv = ldsPI[ocl + r], dzv = ldsPI[BM + ocl + r], biv = ldsPI[2 * BM + ocl + r];
+                    const double mv = ldsPM[ocl + r], sv = ldsPM[BM + ocl + r];
+    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        const int32_t accv = acc[ms][ns][grp * 4 + r] + cwv + dzv * sx[ns];
+                        uint32_t u8 = 0;
+                        if (oc < a.n) {
+                            u8 = requant_u8(accv, biv, mv, sv, a.zp_act, a.act, a.store_mode);
+                            if (nvalid[ns] && (a.acc_out || a.y_f32)) {
+                                const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
+                                if (a.acc_out) a.acc_out[ridx] = accv;
+                                if (a.y_f32) a.y_f32[ridx] = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
+                            }
+                        }
+                        packed[ns] |= (u8 ^ 0x80u) << (8 * r);
+                    }
+                }
+    #pragma unroll
+                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
+            }
         }
     }
     __syncthreads();
-    if (a.y) {
+    if (a.y && !(a.debug & 128)) {
         const int dwords = min(BM, a.out_cs - m0) >> 2;
-        const int total = BN * dwords;
-        for (int p = tid; p < total; p += NT) {
-            const int pix = p / dwords, d = p - pix * dwords;
-            const int cell = celltab[pix];
-            if (cell >= 0)
-                *reinterpret_cast<uint32_t *>(a.y + (size_t)cell * a.out_cs + m0 + d * 4) =
-                    *reinterpret_cast<const uint32_t *>(otile + pix * OSTR + d * 4);
+        if (dwords == BM / 4) {  // common case: constant divisor
+#pragma unroll 4
+            for (int p = tid; p < BN * (BM / 4); p += NT) {
+                const int pix = p / (BM / 4), d = p % (BM / 4);
+                const int cell = celltab[pix];
+                if (cell >= 0)
+                    *reinterpret_cast<uint32_t *>(a.y + (size_t)cell * a.out_cs + m0 + d * 4) =
+                        *reinterpret_cast<const uint32_t *>(otile + pix * OSTR + d * 4);
+            }
+        } else {
+            const int total = BN * dwords;
+            for (int p = tid; p < total; p += NT) {
+                const int pix = p / dwords, d = p - pix * dwords;
+                const int cell = celltab[pix];
+                if (cell >= 0)
+                    *reinterpret_cast<uint32_t *>(a.y + (size_t)cell * a.out_cs + m0 + d * 4) =
+                        *reinterpret_cast<const uint32_t *>(otile + pix * OSTR + d * 4);
+            }
         }
     }
 }
@@ -442,9 +523,14 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     size_t lds = (size_t)ra_stages<KS>() * BM * 64 + 2 * (size_t)a.rows_cap * RS * 64 + (size_t)a.rows_cap * RS * 4;
     const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
     if (lds_epi > lds) lds = lds_epi;
+    lds = (lds + 15) & ~(size_t)15;
+    a.lds_param_off = (int)lds;  // beyond both the K-loop buffers and the epilogue tile
+    lds += (size_t)BM * 40;
     if (lds > 160 * 1024) return MI355_EINVAL;
     auto kern = conv_rows_i8_kernel<BM, BN, WMW, WNW, RS, KS>;
-    if (lds > 64 * 1024) {
+    static size_t lds_attr = 0;  // per kernel instantiation: raise the dynamic-LDS limit once, not per launch
+    if (lds > 64 * 1024 && lds > lds_attr) {
+        lds_attr = lds;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return MI355_EHIP;

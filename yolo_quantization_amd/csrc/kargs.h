@@ -21,6 +21,12 @@ struct ConvArgs {
     int bchunks, bpt;        // LDS B buffer size in KiB chunks; DMA instructions per wave per chunk load
     int tiles_x, tiles_y;    // PATCH mode tiling of one image
     int rows_cap;            // conv_rows: LDS rows per B buffer
+    const int32_t *shift;    // per-channel right shift (valid when hdr->pow2)
+    const double *mprime;    // M_value * shift_value
+    const int32_t *cwb;      // cw + bias
+    const ConvBlobHeader *hdr;
+    int lds_param_off;       // conv_rows: byte offset of the staged per-channel epilogue parameters in LDS
+    int debug;               // timing-ablation switches (results are wrong when non-zero): see mi355_debug_flags
 };
 
 struct AuxArgs {

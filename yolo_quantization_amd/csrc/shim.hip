@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <math.h>
 
 
 static thread_local char g_err[512] = "";
@@ -233,6 +234,9 @@ static int blob_layout(int n, int c, int ksize, ConvBlobHeader *h)
     h->off_bias = off; off = align16(off + (size_t)h->mpad * 4);
     h->off_mval = off; off = align16(off + (size_t)h->mpad * 8);
     h->off_sval = off; off = align16(off + (size_t)h->mpad * 8);
+    h->off_shift = off; off = align16(off + (size_t)h->mpad * 4);
+    h->off_mprime = off; off = align16(off + (size_t)h->mpad * 8);
+    h->off_cwb = off; off = align16(off + (size_t)h->mpad * 4);
     h->total = off;
     return MI355_OK;
 }
@@ -252,6 +256,12 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
     if (!wq || !zp_w || !biases_int32 || !M_value || !shift_value || !blob) return einval("conv_pack: null");
     char *base = (char *)blob;
     memset(base, 0, (size_t)h.total);
+    h.pow2 = 1;
+    for (int oc = 0; oc < n; ++oc) {
+        int e = 0;
+        const double m = frexp(shift_value[oc], &e);  // shift_value = m * 2^e, m in [0.5,1)
+        if (m != 0.5 || e > 1 || e < -30) h.pow2 = 0;   // 2^-s == 0.5 * 2^(1-s)  ->  s = 1 - e in [0,31]
+    }
     memcpy(base, &h, sizeof(h));
     int32_t *cw = (int32_t *)(base + h.off_cw), *dzp = (int32_t *)(base + h.off_dzp);
     int32_t *bias = (int32_t *)(base + h.off_bias);
@@ -264,11 +274,18 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
         bias[oc] = biases_int32[oc];
         mval[oc] = M_value[oc];
         sval[oc] = shift_value[oc];
+        if (h.pow2) {
+            int e = 0;
+            frexp(shift_value[oc], &e);
+            ((int32_t *)(base + h.off_shift))[oc] = 1 - e;
+        }
         const int d = 128 - (int)zp_w[oc];
         dzp[oc] = d;
         long sw = 0;
         for (int k = 0; k < K; ++k) sw += (int)wq[(size_t)oc * K + k] - 128;
         cw[oc] = (int32_t)(128 * sw + 128L * K * d);  // 128*sum(w') + 128*K*d   (|.| < 2^28 for K <= 9216)
+        ((int32_t *)(base + h.off_cwb))[oc] = (int32_t)((uint32_t)cw[oc] + (uint32_t)biases_int32[oc]);
+        ((double *)(base + h.off_mprime))[oc] = M_value[oc] * shift_value[oc];
     }
     if (h.first) {
         uint32_t *wp = (uint32_t *)(base + h.off_wp);
@@ -356,6 +373,10 @@ int mi355_conv_forward(const mi355_conv_desc *d, const mi355_tensor *x, const vo
     a.total_n = total_n;
     a.zp_act = d->zp_act; a.act = d->activation; a.store_mode = d->store_mode; a.s_act = d->s_act;
     a.mpad = h.mpad;
+    a.shift = (const int32_t *)(base + h.off_shift);
+    a.mprime = (const double *)(base + h.off_mprime);
+    a.cwb = (const int32_t *)(base + h.off_cwb);
+    a.hdr = (const ConvBlobHeader *)base;  // device copy: the kernel reads the data-dependent pow2 flag from it
     int rc = conv_igemm_launch(a, st);
     if (rc == MI355_EINVAL) return einval("conv_forward: no tile configuration fits this shape");
     if (rc != MI355_OK) return hip_fail(hipGetLastError(), "conv_igemm launch");
