@@ -162,6 +162,7 @@ int network_profile_read(network *net, float *ms_sum /* [n+1] */);
 size_t network_packed_size(network *net);
 void network_export_packed(network *net, void *buf);
 void network_import_packed(network *net, const void *buf, size_t bytes);
+void network_import_packed_host(network *net, const void *buf, size_t bytes); /* host half only (no device) */
 /* same exchange with the buffer already on the device (what bench.py hands over after torch.distributed.broadcast) */
 void network_import_packed_gpu(network *net, const void *dev_buf, size_t bytes);
 

@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 from yolo_quantization_amd import binding  # noqa: E402
 
 PEAK = 256 * 4 * 2048 * 2.4e9 / 1e12
+SHIFT = 13  # requantised values of random data then stay in the few-hundred range, like a real net's
 
 NET = [(16, 32, 208, 3), (32, 64, 104, 3), (64, 128, 52, 3), (128, 256, 26, 3), (256, 512, 13, 3), (512, 1024, 13, 3),
        (1024, 256, 13, 1), (512, 30, 13, 1), (256, 128, 13, 1), (384, 256, 26, 3), (256, 30, 26, 1)]
@@ -30,7 +31,7 @@ def run(c, n, hw, k, batch, iters, tile=None, mode=None, check=False):
     wq = np.random.default_rng(2).integers(0, 256, (n, c * k * k), dtype=np.uint8)
     zp_w = np.random.default_rng(3).integers(100, 157, n, dtype=np.uint8)
     bias = np.zeros(n, np.int32)
-    mv = np.full(n, 0.75); sv = np.full(n, 2.0 ** -9)
+    mv = np.full(n, 0.75); sv = np.full(n, 2.0 ** -SHIFT)
     xt = binding.DevTensor.from_nchw(x, 0)
     y = binding.DevTensor(batch, hw, hw, n, 23)
     blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, k, bias, mv, sv))
@@ -69,12 +70,14 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--tile", type=int, nargs=2); ap.add_argument("--mode", choices=["flat", "patch"])
     ap.add_argument("--net", action="store_true"); ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--shift", type=int, default=13)
     ap.add_argument("--ablate", action="store_true", help="timing ablation of the K loop (results are wrong)")
     a = ap.parse_args()
+    SHIFT = a.shift
     binding.init(0)
     if a.ablate:
         S = binding.shim()
-        for flags, name in [(0, "full"), (1, "no-dma"), (2, "no-barrier"), (4, "no-mfma"), (16, "no-cellsum"), (3, "no-dma,no-barrier"), (5, "no-dma,no-mfma"), (7, "only-lds-reads"), (15, "nothing-in-loop"), (32, "no-epilogue"), (47, "empty-kernel"), (63, "empty-kernel-no-cellsum"), (15 + 64, "epi-no-requant"), (15 + 128, "epi-no-copyout"), (15 + 64 + 128, "epi-neither")]:
+        for flags, name in [(0, "full"), (1, "no-dma"), (2, "no-barrier"), (4, "no-mfma"), (16, "no-cellsum"), (3, "no-dma,no-barrier"), (5, "no-dma,no-mfma"), (7, "only-lds-reads"), (15, "nothing-in-loop"), (32, "no-epilogue"), (47, "empty-kernel"), (63, "empty-kernel-no-cellsum"), (11, "only-mfma"), (9, "mfma+barrier"), (3, "lds+mfma"), (15 + 64, "epi-no-requant"), (15 + 128, "epi-no-copyout"), (15 + 64 + 128, "epi-neither")]:
             S.mi355_debug_flags(flags)
             r = run(a.c, a.n, a.hw, a.k, a.batch, a.iters, tuple(a.tile) if a.tile else None, a.mode)
             print(name, r["us"], "us", r["tops"], "TOPS")

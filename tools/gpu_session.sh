@@ -18,7 +18,16 @@ if [[ $what == all || $what == prof ]]; then
   rm -rf gpurun_out/prof
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r01 -- \
       python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err" )
-  find gpurun_out/prof -name "*stats*" | head
-  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && head -30 "$f"
+  db=$(find gpurun_out/prof -name "*results.db" | head -1)
+  [ -n "$db" ] && python tools/rocpd_summary.py "$db" gpurun_out/kernel_stats.md | head -40
+fi
+if [[ $what == all || $what == pmc ]]; then
+  # HBM traffic of every kernel of one bench step: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one
+  # pass), kernel-trace only.
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmc_$ctr
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OLDPWD/gpurun_out/pmc_$ctr" -o p -- \
+        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/pmc_$ctr.json" 2> "$OLDPWD/gpurun_out/pmc_$ctr.err" )
+  done
+  python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_traffic.json | head -30
 fi

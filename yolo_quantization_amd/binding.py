@@ -232,6 +232,7 @@ def host():
         L.network_export_packed.argtypes = [vp, vp]
         L.network_import_packed.argtypes = [vp, vp, C.c_size_t]
         L.network_import_packed_gpu.argtypes = [vp, vp, C.c_size_t]
+        L.network_import_packed_host.argtypes = [vp, vp, C.c_size_t]
         L.quant_multi_smaller_than_one_to_scale_and_shift.argtypes = [C.c_float, vp, vp]
         L.quant_image_with_min_max.argtypes = [ci, vp, vp, vp, vp]
         for n in ("dnq_net_n", "dnq_net_batch", "dnq_net_inputs"):
@@ -358,6 +359,10 @@ class Net:
     def import_packed(self, buf):
         buf = np.ascontiguousarray(buf, np.uint8)
         self.H.network_import_packed(self.h, buf.ctypes.data, buf.nbytes)
+
+    def import_packed_host(self, buf):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        self.H.network_import_packed_host(self.h, buf.ctypes.data, buf.nbytes)
 
     def import_packed_gpu(self, dev_ptr, nbytes):
         self.H.network_import_packed_gpu(self.h, dev_ptr, nbytes)

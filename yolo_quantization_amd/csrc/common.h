@@ -70,12 +70,17 @@ __device__ __forceinline__ uint32_t requant_u8(int32_t acc, int32_t bias, double
 // reference's q bit for bit.  `accb` already contains acc + cw + dz*sx + biases_int32.  Activation / store mode
 // are compile-time constants.  LEAKY: round((double)q * 0.1) == -((|q| + 5) / 10) for every negative int32 q
 // (exhaustively verified); the division uses a 24-bit multiply when |q| + 5 < 2^16 and v_mul_hi otherwise.
+// (An FP32 estimate of q with an FP64 fallback for lanes near an integer boundary was tried and measured slower than
+// this single FP64 multiply: the epilogue is bound by instruction count, not by the FP64 rate -- profiles/r01 notes.)
+__device__ __forceinline__ int32_t requant_q_exact(int32_t accb, double Mp) { return (int32_t)((double)accb * Mp); }
+// Stage 2: activation, zero point, store mode (compile-time), uint8 wrap.
 template <int ACT, bool SAT>
-__device__ __forceinline__ uint32_t requant_u8_fast(int32_t accb, double Mp, int zp_act)
+__device__ __forceinline__ uint32_t requant_finish(int32_t q, int zp_act)
 {
-    const int32_t q = (int32_t)((double)accb * Mp);
     int32_t v;
     if (ACT == MI355_ACT_LEAKY) {
+        // round((double)q * 0.1) == -((|q| + 5) / 10) for every negative int32 q (exhaustively verified); the division is
+        // a 24-bit multiply when |q| + 5 < 2^16 and v_mul_hi otherwise
         const uint32_t x = (0u - (uint32_t)q) + 5u;
         const uint32_t d10 = x < 65536u ? (__umul24(x, 0xCCCDu) >> 19) : x / 10u;
         v = q < 0 ? zp_act - (int32_t)d10 : q + zp_act;

@@ -20,6 +20,14 @@
 #include "kargs.h"
 #include <type_traits>
 
+// timing-ablation switches (tools/conv_microbench.py --ablate) exist only in builds made with -DMI355_ABLATE;
+// in the product build DBG(x) is the constant 0 and every switch folds away.
+#ifdef MI355_ABLATE
+#define DBG(bit) ((a.debug & (bit)) != 0)
+#else
+#define DBG(bit) (false)
+#endif
+
 #define DMA16(gsrc, ldst)                                                                               \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),           \
                                      (__attribute__((address_space(3))) void *)(ldst), 16, 0, 0)
@@ -294,19 +302,19 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
                     if (t == 1 && more_chunks) rows_wait_vmcnt(APT + bpt);
                     else if (a2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (!(a.debug & 2)) __builtin_amdgcn_s_barrier();
+                    if (!DBG(2)) __builtin_amdgcn_s_barrier();
                 }
-                if (t == 0 && more_chunks && !(a.debug & 1)) issueB(chunk + 1, (chunk + 1) & 1);
-                if ((t < 6 || more_chunks) && !(a.debug & 1)) issueA(g + 3, (cph + t + 3) & 3);
+                if (t == 0 && more_chunks && !DBG(1)) issueB(chunk + 1, (chunk + 1) & 1);
+                if ((t < 6 || more_chunks) && !DBG(1)) issueA(g + 3, (cph + t + 3) & 3);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(a.debug & 8))
+                if (!DBG(8))
                 load_half(a1, b1, (unsigned)(((cph + t) & 3) * (BM * 64)), bo_cur, std::integral_constant<int, TAP>{},
                           std::integral_constant<int, 1>{});
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");  // H0(g) landed
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(a.debug & 4)) mfma_half(a0, b0);
+                if (!DBG(4)) mfma_half(a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (a.debug & 8) {
+                if (DBG(8)) {
                 } else if (t < 8) {
                     load_half(a0, b0, (unsigned)(((cph + t + 1) & 3) * (BM * 64)), bo_cur,
                               std::integral_constant<int, TAPN>{}, std::integral_constant<int, 0>{});
@@ -319,9 +327,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(a.debug & 4)) mfma_half(a1, b1);
+                if (!DBG(4)) mfma_half(a1, b1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (t == 1 && !(a.debug & 16)) {
+                if (t == 1 && !DBG(16)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // our reads are invisible to hipcc's counters
                     cell_sums(Bt);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         }
     }
 
-    if (a.debug & 32) {  // timing ablation: no epilogue (keep the accumulators alive)
+    if (DBG(32)) {  // timing ablation: no epilogue (keep the accumulators alive)
         if (acc[0][0][0] == 0x7fffffff && a.y) a.y[tid] = 1;
         return;
     }
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
                     for (int ns = 0; ns < NS; ++ns) {
                         // |dz| <= 128 and |sx| < 2^23 (K <= 64K): 24-bit multiply, full rate
                         const int32_t accb = acc[ms][ns][grp * 4 + r] + cbv[r] + __mul24(dzv[r], sx[ns]);
-                        const uint32_t u8 = requant_u8_fast<ACT, SAT>(accb, mp, a.zp_act);
+                        const uint32_t u8 = requant_finish<ACT, SAT>(requant_q_exact(accb, mp), a.zp_act);
                         packed[ns] |= (u8 ^ 0x80u) << (8 * r);
                     }
                 }
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         }
     };
     using std::integral_constant;
-    if (a.debug & 64) {
+    if (DBG(64)) {
     } else if (fast) {
         const bool sat = a.store_mode == MI355_STORE_SATURATE;
         if (a.act == MI355_ACT_LEAKY) {
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         }
     }
     __syncthreads();
-    if (a.y && !(a.debug & 128)) {
+    if (a.y && !DBG(128)) {
         const int dwords = min(BM, a.out_cs - m0) >> 2;
         if (dwords == BM / 4) {  // common case: constant divisor
 #pragma unroll 4

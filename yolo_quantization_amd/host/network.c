@@ -370,7 +370,7 @@ typedef struct { float s_act, s_in; int32_t zp_act, zp_in; uint64_t blob_bytes; 
 
 size_t network_packed_size(network *net)
 {
-    if (!net->prepared) error("network_packed_size before prep");
+    if (!net->layers[0].blob_host) error("network_packed_size before prep");
     size_t sz = sizeof(pack_head) + (size_t)net->n * sizeof(pack_rec);
     for (int i = 0; i < net->n; ++i) sz += (net->layers[i].blob_bytes + 15) & ~(size_t)15;
     return sz;
@@ -399,7 +399,7 @@ void network_export_packed(network *net, void *buf)
     }
 }
 
-void network_import_packed(network *net, const void *buf, size_t bytes)
+void network_import_packed_host(network *net, const void *buf, size_t bytes)
 {
     const char *p = buf;
     pack_head h;
@@ -422,6 +422,11 @@ void network_import_packed(network *net, const void *buf, size_t bytes)
             p += (r.blob_bytes + 15) & ~(size_t)15;
         }
     }
+}
+
+void network_import_packed(network *net, const void *buf, size_t bytes)
+{
+    network_import_packed_host(net, buf, bytes);
     alloc_network_device(net);
     for (int i = 0; i < net->n; ++i)
         if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, 0);
