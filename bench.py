@@ -46,6 +46,22 @@ def conv_layer_work(info, batch):
     return ops, byt
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
+    produced by tools/gpu_session.sh pmc + tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950
+    FETCH_SIZE x2 correction).  None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    rows = [r for r in json.load(open(files[-1])) if "conv_rows_i8_kernel" in r["kernel"] or "conv_igemm_i8_kernel" in r["kernel"]]
+    n = sum(r["launches"] for r in rows)
+    if not n:
+        return None
+    tot = sum(((r["hbm_read_bytes_per_launch"] or 0) + (r["hbm_write_bytes_per_launch"] or 0)) * r["launches"] for r in rows)
+    return tot / n
+
+
 def cpu_baseline(cfg, wts, nimg):
     """The reference itself (oracle/_ref/libdarknet_ref.so, Makefile-default build, 1 thread) timed on this box's host
     cores on a bounded sample; falls back to the CPU restatement ('port') if the prebuilt reference is absent."""
@@ -96,9 +112,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"  # exercise the RCCL start-up path on one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from yolo_quantization_amd import binding, synth
@@ -117,7 +135,7 @@ def main():
         net = binding.Net(args.cfg, None, batch=B, gpu=local_rank, use_graph=args.graph)
         size_t = torch.zeros(1, dtype=torch.int64, device=dev)
     bcast_ms = 0.0
-    if world > 1:
+    if world > 1 or force_dist:
         dist.broadcast(size_t, 0)
         nbytes = int(size_t.item())
         blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -128,7 +146,10 @@ def main():
         dist.broadcast(blob, 0)
         torch.cuda.synchronize()
         bcast_ms = (time.time() - t0) * 1e3
-        if rank != 0:
+        if rank != 0 or force_dist:
+            if force_dist and rank == 0:  # single-rank self test: re-import what was exported
+                net.close()
+                net = binding.Net(args.cfg, None, batch=B, gpu=local_rank, use_graph=args.graph)
             net.import_packed_gpu(blob.data_ptr(), nbytes)
 
     # ---- synthetic input, resident in HBM in the reference layout before the timed region
@@ -137,7 +158,7 @@ def main():
     net.sync()
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
         net.sync()
@@ -179,9 +200,10 @@ def main():
             layers.append(row)
         nlaunch = sum(1 for inf in net.info if inf["type"] == binding.T_CONV and inf["c"] % 16 == 0)
         achieved = mf_ops / (mf_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_igemm_i8_kernel (12 launches/step: all convs with c%16==0)",
+        roof = {"bound": "mfma", "kernel": "conv_rows_i8_kernel / conv_igemm_i8_kernel (MFMA implicit GEMM, 12 launches/step: all convs with c%16==0)",
                 "achieved": round(achieved, 2), "peak": round(PEAK_INT8_TOPS, 1), "unit": "TOP/s",
-                "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": pmc_traffic_per_launch(),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/*_pmc_traffic.json)",
                 "ops_per_launch_avg": mf_ops / nlaunch, "ms_per_launch_avg": round(mf_ms / nlaunch, 5),
                 "input_layout_ms": round(float(ms[0]) / nprof, 5)}
         if args.layers:
@@ -213,7 +235,7 @@ def main():
     except OSError:
         pass
     net.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
