@@ -90,6 +90,7 @@ struct layer {
     int32_t *output_int32_gpu;     /* reference layout; allocated only when net->dump_int32 */
     float *output_gpu;             /* reference layout float (quant_stop convs, yolo) */
     uint8_t *output_uint8_nchw_gpu; /* scratch for pull_layer_output */
+    int fuse_next_pool; /* this conv and the 2x2/2 maxpool after it run as one kernel (set by the prep) */
     int prepared;
 };
 
@@ -115,6 +116,9 @@ struct network {
     /* knobs (CLI: -accum exact|ref-f32, -parity wrap|saturate) */
     int accum_mode, store_mode;
     int dump_int32; /* keep int32 accumulators of every conv (parity runs) */
+    int fuse_maxpool; /* 1 (default): conv + following 2x2/2 maxpool fused, the pre-pool tensor is not stored.
+                         0: every layer writes its own tensor like the reference (per-layer parity dumps) */
+    const mi355_tensor *fused_pool_t; /* executor -> conv forward_gpu: pooled output tensor of the fused pair */
     int verbose;
     int prepared;
     void *graph; /* hipGraph of the layer loop, built lazily when use_graph */

@@ -125,6 +125,13 @@ typedef struct mi355_conv_desc {
 int mi355_conv_forward(const mi355_conv_desc *desc, const mi355_tensor *x, const void *blob, const uint8_t *w_u8,
                        const uint8_t *zp_w, const mi355_tensor *y, int32_t *acc_out, float *y_f32, void *stream);
 
+/* The same convolution fused with the size-2 / stride-2 maxpool that follows it (ref: forward_maxpool_layer_quant,
+ * src/maxpool_layer.c:109-172, window offset 0 on even maps): writes ypool (B, H/2, W/2, n) directly and, when y is
+ * non-NULL, the pre-pool tensor as well.  3x3 convs on even H, W only, exact accumulation mode; returns MI355_EINVAL
+ * otherwise and the caller runs the two layers separately.  Results are identical to conv_forward + maxpool_forward. */
+int mi355_conv_pool_forward(const mi355_conv_desc *desc, const mi355_tensor *x, const void *blob, const mi355_tensor *y,
+                            const mi355_tensor *ypool, void *stream);
+
 /* Tile configuration override for benchmarking (0 = auto). */
 int mi355_conv_set_tile(int bm, int bn);
 /* Timing-ablation switches for kernel development (bit 0: no DMA in the K loop, 1: no s_barrier, 2: no MFMA,

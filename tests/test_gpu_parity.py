@@ -178,6 +178,64 @@ def test_layout_roundtrip_and_pads():
             assert (padcell == (77 ^ 0x80)).all()
 
 
+@pytest.mark.parametrize("c,n,H,W,act", [(3, 16, 20, 36, "leaky"), (16, 32, 24, 40, "leaky"), (32, 64, 16, 16, "relu6"),
+                                         (48, 32, 10, 34, "linear")])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+def test_conv_fused_maxpool_equals_conv_then_pool(c, n, H, W, act, store):
+    """mi355_conv_pool_forward == conv + requant + 2x2/2 maxpool of the oracle (pre-pool tensor too), including
+    wrap-on-store values inside pooling windows (max is taken AFTER the uint8 wrap, as the reference does)."""
+    import ctypes as C
+    rng = np.random.default_rng(c * 100 + n + H)
+    B = 3
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3, 2.0 ** -9 if c == 3 else 2.0 ** -11, 2.0 ** -6 if c == 3 else 2.0 ** -7)
+    zp_in, zp_act = 9, 23
+    xt = binding.DevTensor.from_nchw(x, zp_in)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv))
+    y = binding.DevTensor(B, H, W, n, zp_act)
+    yp = binding.DevTensor(B, H // 2, W // 2, n, zp_act)
+    d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT[act], store, binding.ACC_EXACT, zp_in, zp_act, 1.0)
+    binding.check(binding.shim().mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, y.ref(), yp.ref(), None), "conv_pool")
+    acc, u8 = _oracle_layer(x, wq, zp_w, 3, zp_in, bias, mv, sv, zp_act, oracle.ACT[act], store, oracle.ACC_EXACT)
+    u8 = u8.reshape(B, n, H, W)
+    want_pool = np.stack([oracle.maxpool_u8(u8[b], 2, 2, 1) for b in range(B)])
+    assert np.array_equal(y.to_nchw(), u8), "pre-pool tensor"
+    assert np.array_equal(yp.to_nchw(), want_pool), "pooled tensor"
+    # and without the pre-pool store
+    yp2 = binding.DevTensor(B, H // 2, W // 2, n, zp_act)
+    binding.check(binding.shim().mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, None, yp2.ref(), None), "conv_pool")
+    assert np.array_equal(yp2.to_nchw(), want_pool)
+
+
+def test_fused_maxpool_net_equals_unfused(cfg_dir, tmp_path):
+    """Whole yolov3-tiny, batch 3: the throughput configuration (conv+maxpool fused where possible, pre-pool tensors
+    not stored) yields byte-identical tensors on every layer that is stored in both configurations."""
+    cfg = os.path.join(cfg_dir, "yolov3-tiny_quant.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=1234)
+    xs = synth.synth_image_u8(3, 416, 416, seed=21, batch=3)
+    outs = {}
+    for fuse in (False, True):
+        net = binding.Net(cfg, wts, batch=3, fuse_maxpool=fuse)
+        net.prepare_fixed(1.0 / 255.0, 0)
+        net.push_input(xs)
+        net.forward(); net.sync()
+        outs[fuse] = [net.pull(i) for i in range(net.n)]
+        info = net.info
+        net.close()
+    fused_convs = 0
+    for i, inf in enumerate(info):
+        nxt = info[i + 1] if i + 1 < len(info) else None
+        skipped = (inf["type"] == binding.T_CONV and nxt and nxt["type"] == binding.T_MAXPOOL and inf["size"] == 3
+                   and nxt["size"] == 2 and nxt["stride"] == 2 and inf["c"] % 64 != 0)
+        if skipped:
+            fused_convs += 1
+            continue  # its own tensor is not stored in the fused configuration
+        for k in outs[True][i]:
+            assert np.array_equal(outs[True][i][k], outs[False][i][k]), (i, k)
+    assert fused_convs == 3
+
+
 # ------------------------------------------------------------------------------------------------ whole networks
 def _run_host_net(cfg, wts, x_u8_batch, accum, store=binding.STORE_WRAP, graph=False, dump_int32=True):
     B = x_u8_batch.shape[0]

@@ -75,6 +75,8 @@ def shim():
         L.mi355_conv_pack.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.mi355_conv_forward.argtypes = [C.POINTER(ConvDesc), C.POINTER(Tensor), vp, vp, vp, C.POINTER(Tensor), vp, vp, vp]
         L.mi355_conv_set_tile.argtypes = [ci, ci]
+        L.mi355_conv_pool_forward.argtypes = [C.POINTER(ConvDesc), C.POINTER(Tensor), vp, C.POINTER(Tensor), C.POINTER(Tensor), vp]
+        L.mi355_debug_flags.argtypes = [ci]
         L.mi355_maxpool_forward.argtypes = [C.POINTER(Tensor), C.POINTER(Tensor), ci, ci, ci, vp]
         L.mi355_upsample_forward.argtypes = [C.POINTER(Tensor), C.POINTER(Tensor), ci, vp]
         L.mi355_route_forward.argtypes = [C.POINTER(C.POINTER(Tensor)), ci, C.POINTER(Tensor), vp]
@@ -263,7 +265,7 @@ class Net:
     """The darknet host network (libdarknet_q.so): load_network -> prep -> forward_network_gpu."""
 
     def __init__(self, cfg, weights=None, batch=1, gpu=0, accum=ACC_EXACT, store=STORE_WRAP, dump_int32=False,
-                 use_graph=False):
+                 use_graph=False, fuse_maxpool=True):
         H = host()
         self.H = H
         self.h = H.load_network(cfg.encode(), weights.encode() if weights else None, 0)
@@ -272,6 +274,7 @@ class Net:
         H.dnq_net_set(self.h, b"store_mode", store)
         H.dnq_net_set(self.h, b"dump_int32", int(dump_int32))
         H.dnq_net_set(self.h, b"use_graph", int(use_graph))
+        H.dnq_net_set(self.h, b"fuse_maxpool", int(fuse_maxpool))
         if batch != H.dnq_net_batch(self.h):
             H.set_batch_network(self.h, batch)
         self.n = H.dnq_net_n(self.h)

@@ -93,6 +93,83 @@ __device__ __forceinline__ uint32_t requant_finish(int32_t q, int zp_act)
     return (uint32_t)v & 0xFFu;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Group form used by the conv epilogues: 4 consecutive channels (one packed dword) x NS pixels held by a lane.
+// accb[r][ns] = accumulator + cw + bias + dz*sx;  mp[r] = folded multiplier.  Returns the BIASED packed bytes
+// (uint8 ^ 0x80).  ~13 VALU instructions per output: accb is formed by the caller (2), cvt/mul/cvt (3), activation
+// (LEAKY: 7, branch free: v = zp + max(q,0) - ((max(-q,0)+5)*0xCCCD >> 19), exact while max(-q,0)+5 < 2^16; a
+// wave-uniform fallback recomputes the group with a true division otherwise), v_perm packing (0.75) + one xor.
+// ---------------------------------------------------------------------------------------------------------
+template <int ACT, bool SAT, int NS>
+__device__ __forceinline__ void requant_values(const int32_t (&accb)[4][NS], const double (&mp)[4], int zp_act,
+                                               int32_t (&v)[4][NS])
+{
+    bool big = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+            const int32_t q = requant_q_exact(accb[r][ns], mp[r]);
+            if (ACT == MI355_ACT_LEAKY) {
+                const int32_t nq = max(0 - q, 0);
+                big |= nq > 65530;
+                const uint32_t d10 = __umul24((uint32_t)nq + 5u, 0xCCCDu) >> 19;
+                v[r][ns] = zp_act + max(q, 0) - (int32_t)d10;
+            } else if (ACT == MI355_ACT_RELU6) {
+                v[r][ns] = zp_act + max(q, 0);
+            } else {
+                v[r][ns] = zp_act + q;
+            }
+        }
+    if (ACT == MI355_ACT_LEAKY && __builtin_amdgcn_ballot_w64(big) != 0) {  // never taken on sane data; keeps exactness
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+                const int32_t q = requant_q_exact(accb[r][ns], mp[r]);
+                const uint32_t x = (0u - (uint32_t)q) + 5u;
+                v[r][ns] = q < 0 ? zp_act - (int32_t)(x / 10u) : q + zp_act;
+            }
+    }
+    if (SAT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) v[r][ns] = min(max(v[r][ns], 0), 255);
+    }
+}
+
+// low bytes of four ints -> one dword, biased (^0x80): 3 v_perm + 1 v_xor
+__device__ __forceinline__ uint32_t pack4_biased(int32_t v0, int32_t v1, int32_t v2, int32_t v3)
+{
+    const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0400u);
+    const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)v3, (uint32_t)v2, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;
+}
+
+template <int ACT, bool SAT, int NS>
+__device__ __forceinline__ void requant_group(const int32_t (&accb)[4][NS], const double (&mp)[4], int zp_act,
+                                              uint32_t (&packed)[NS])
+{
+    int32_t v[4][NS];
+    requant_values<ACT, SAT, NS>(accb, mp, zp_act, v);
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) packed[ns] = pack4_biased(v[0][ns], v[1][ns], v[2][ns], v[3][ns]);
+}
+
+// bytewise signed max of two dwords holding 4 biased (x ^ 0x80) activations each: max_u8 on the raw values ==
+// max_s8 on the biased ones (maxpool, ref src/maxpool_layer.c:134-146).
+__device__ __forceinline__ uint32_t max_s8x4(uint32_t p, uint32_t q)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int a = (int)(int8_t)(p >> (8 * i)), b = (int)(int8_t)(q >> (8 * i));
+        r |= ((uint32_t)(a > b ? a : b) & 0xFFu) << (8 * i);
+    }
+    return r;
+}
+
 // cell index of pixel n (n enumerates b,y,x) in a PHWC tensor
 __device__ __forceinline__ int cell_of_pixel(int n, int H, int W, int lead)
 {

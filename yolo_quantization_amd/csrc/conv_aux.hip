@@ -99,6 +99,106 @@ __global__ __launch_bounds__(256) void conv_ref_f32_kernel(const AuxArgs a)
     }
 }
 
+// First layer fused with the 2x2 / stride-2 maxpool that follows it in every yolo cfg: one thread per POOLED pixel
+// computes the four pre-pool pixels (4x4 input window), requantises them (compile-time activation / store mode,
+// folded multiplier) and writes the bytewise max.  Removes the 2.77 MB/image pre-pool write + re-read.  The pre-pool
+// tensor is still written when `a.y` is given (parity runs keep the reference's per-layer tensors).
+template <int ACT, bool SAT>
+__global__ __launch_bounds__(256) void conv_first_pool_u8_kernel(const AuxArgs a)
+{
+    extern __shared__ uint32_t wl[];  // [n][9] weights (c0,c1,c2,0) per tap
+    for (int i = threadIdx.x; i < a.n * 9; i += blockDim.x) wl[i] = a.wfirst[i];
+    __syncthreads();
+    const int OH = a.H >> 1, OW = a.W >> 1;
+    const int total = a.B * OH * OW;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int b = idx / (OH * OW), rem = idx - b * (OH * OW);
+    const int oy = rem / OW, ox = rem - oy * OW;
+    const int W1 = a.W + 1;
+    const int cell00 = a.in_lead + (b * (a.H + 1) + (2 * oy + 1)) * W1 + 2 * ox;  // pre-pool pixel (2oy, 2ox)
+    const uint32_t *xc = reinterpret_cast<const uint32_t *>(a.x);
+    uint32_t xin[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xin[r][c] = xc[cell00 + (r - 1) * W1 + (c - 1)];
+    int32_t sumx[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t = __builtin_amdgcn_udot4(xin[(p >> 1) + k / 3][(p & 1) + k % 3], 0x00010101u, t, false);
+        sumx[p] = (int32_t)t;
+    }
+    const size_t pcell = a.pool_lead + ((size_t)b * (OH + 1) + (oy + 1)) * (OW + 1) + ox;
+    for (int oc0 = 0; oc0 < a.n; oc0 += 4) {  // n % 4 == 0 (checked by the launcher)
+        int32_t accb[4][4];
+        double mp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = oc0 + r;
+            const int zpw = 128 - a.dzp[oc];
+            const int bias = a.bias[oc];
+            mp[r] = a.mprime[oc];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint32_t s1 = 0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    s1 = __builtin_amdgcn_udot4(wl[oc * 9 + k], xin[(p >> 1) + k / 3][(p & 1) + k % 3], s1, false);
+                accb[r][p] = (int32_t)s1 - zpw * sumx[p] + bias;
+            }
+        }
+        int32_t v[4][4];
+        if (a.hdr->pow2 == 1) {
+            requant_values<ACT, SAT, 4>(accb, mp, a.zp_act, v);
+        } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    v[r][p] = (int32_t)requant_u8(accb[r][p], 0, a.mval[oc0 + r], a.sval[oc0 + r], a.zp_act, ACT,
+                                                  SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+        }
+        int32_t m[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)  // uint8 wrap first, then the unsigned max of the window
+            m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
+        *reinterpret_cast<uint32_t *>(a.ypool + pcell * a.pool_cs + oc0) = pack4_biased(m[0], m[1], m[2], m[3]);
+        if (a.y) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const size_t ocell = a.out_lead + ((size_t)b * (a.H + 1) + (2 * oy + (p >> 1) + 1)) * W1 + 2 * ox + (p & 1);
+                *reinterpret_cast<uint32_t *>(a.y + ocell * a.out_cs + oc0) = pack4_biased(v[0][p], v[1][p], v[2][p], v[3][p]);
+            }
+        }
+    }
+}
+
+template <int ACT>
+static int conv_first_pool_launch_act(AuxArgs &a, hipStream_t st)
+{
+    const int bs = 256;
+    const int total = a.B * (a.H / 2) * (a.W / 2);
+    const int grid = (total + bs - 1) / bs;
+    const size_t lds = a.n * 9 * sizeof(uint32_t);
+    if (a.store_mode == MI355_STORE_SATURATE)
+        hipLaunchKernelGGL((conv_first_pool_u8_kernel<ACT, true>), dim3(grid), dim3(bs), lds, st, a);
+    else
+        hipLaunchKernelGGL((conv_first_pool_u8_kernel<ACT, false>), dim3(grid), dim3(bs), lds, st, a);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
+// returns MI355_EINVAL when the fused form does not apply (caller runs the two layers separately)
+int conv_first_pool_launch(AuxArgs &a, hipStream_t st)
+{
+    if ((a.H & 1) || (a.W & 1) || (a.n & 3) || a.acc_out || a.y_f32) return MI355_EINVAL;
+    if (a.act == MI355_ACT_LEAKY) return conv_first_pool_launch_act<MI355_ACT_LEAKY>(a, st);
+    if (a.act == MI355_ACT_RELU6) return conv_first_pool_launch_act<MI355_ACT_RELU6>(a, st);
+    return conv_first_pool_launch_act<MI355_ACT_LINEAR>(a, st);
+}
+
 int conv_first_launch(AuxArgs &a, hipStream_t st)
 {
     const int bs = 256;

@@ -28,6 +28,7 @@
 //   * epilogue: corrections + FP64 requantise (exact reference op order) in registers, uint8 tile transposed through
 //     LDS so that every pixel's channel run is written with 16-byte stores.
 #include "kargs.h"
+#include <type_traits>
 
 #define DMA16(gsrc, ldst)                                                                               \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),           \
@@ -388,56 +389,136 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         rem[ns] = y * a.W + xx;
         if (wm == 0 && kh == 0) celltab[nl] = nvalid[ns] ? a.out_lead + (b * (a.H + 1) + (y + 1)) * W1 + xx : -1;
     }
+    // Fast path: whole M tile inside n, no parity dumps, power-of-two shifts (always true for the reference's prep):
+    // compile-time activation / store mode, folded single-multiply requantise (csrc/common.h requant_group).
+    const bool fast = !a.acc_out && !a.y_f32 && (m0 + BM <= a.n) && a.hdr->pow2 == 1;
+    auto epi_fast = [&](auto act_c, auto sat_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool SAT = decltype(sat_c)::value != 0;
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
+        for (int ms = 0; ms < MS; ++ms) {
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;  // 4 consecutive channels held by this lane
-            const int oc0 = m0 + ocl;
-            if (oc0 >= a.n) {
+            for (int grp = 0; grp < 4; ++grp) {
+                const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;
+                const int oc0 = m0 + ocl;
+                const int4 dz4 = *reinterpret_cast<const int4 *>(a.dzp + oc0);
+                const int4 cb4 = *reinterpret_cast<const int4 *>(a.cwb + oc0);
+                const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, cbv[4] = {cb4.x, cb4.y, cb4.z, cb4.w};
+                int32_t accb[4][NS];
+                double mp[4];
 #pragma unroll
-                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = 0x80808080u;
-                continue;
-            }
-            uint32_t packed[NS];
+                for (int r = 0; r < 4; ++r) {
+                    mp[r] = a.mprime[oc0 + r];
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) packed[ns] = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
-                const int oc = oc0 + r;
-                const int cwv = a.cw[oc], dzv = a.dzp[oc], biv = a.bias[oc];
-                const double mv = a.mval[oc], sv = a.sval[oc];
-#pragma unroll
-                for (int ns = 0; ns < NS; ++ns) {
-                    const int32_t accv = acc[ms][ns][grp * 4 + r] + cwv + dzv * sx[ns];
-                    uint32_t u8 = 0;
-                    if (oc < a.n) {
-                        u8 = requant_u8(accv, biv, mv, sv, a.zp_act, a.act, a.store_mode);
-                        if (nvalid[ns] && (a.acc_out || a.y_f32)) {
-                            const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
-                            if (a.acc_out) a.acc_out[ridx] = accv;
-                            if (a.y_f32) a.y_f32[ridx] = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
-                        }
-                    }
-                    packed[ns] |= (u8 ^ 0x80u) << (8 * r);
+                    for (int ns = 0; ns < NS; ++ns)
+                        accb[r][ns] = acc[ms][ns][grp * 4 + r] + cbv[r] + __mul24(dzv[r], sx[ns]);
                 }
-            }
+                uint32_t packed[NS];
+                requant_group<ACT, SAT, NS>(accb, mp, a.zp_act, packed);
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
+                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
+            }
+        }
+    };
+    using std::integral_constant;
+    if (fast) {
+        const bool sat = a.store_mode == MI355_STORE_SATURATE;
+        if (a.act == MI355_ACT_LEAKY) {
+            if (sat) epi_fast(integral_constant<int, MI355_ACT_LEAKY>{}, integral_constant<int, 1>{});
+            else epi_fast(integral_constant<int, MI355_ACT_LEAKY>{}, integral_constant<int, 0>{});
+        } else if (a.act == MI355_ACT_RELU6) {
+            if (sat) epi_fast(integral_constant<int, MI355_ACT_RELU6>{}, integral_constant<int, 1>{});
+            else epi_fast(integral_constant<int, MI355_ACT_RELU6>{}, integral_constant<int, 0>{});
+        } else {
+            if (sat) epi_fast(integral_constant<int, MI355_ACT_LINEAR>{}, integral_constant<int, 1>{});
+            else epi_fast(integral_constant<int, MI355_ACT_LINEAR>{}, integral_constant<int, 0>{});
+        }
+    } else {
+    #pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+    #pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;  // 4 consecutive channels held by this lane
+                const int oc0 = m0 + ocl;
+                if (oc0 >= a.n) {
+    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = 0x80808080u;
+                    continue;
+                }
+                uint32_t packed[NS];
+    #pragma unroll
+                for (int ns = 0; ns < NS; ++ns) packed[ns] = 0;
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
+                    const int oc = oc0 + r;
+                    const int cwv = a.cw[oc], dzv = a.dzp[oc], biv = a.bias[oc];
+                    const double mv = a.mval[oc], sv = a.sval[oc];
+    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        const int32_t accv = acc[ms][ns][grp * 4 + r] + cwv + dzv * sx[ns];
+                        uint32_t u8 = 0;
+                        if (oc < a.n) {
+                            u8 = requant_u8(accv, biv, mv, sv, a.zp_act, a.act, a.store_mode);
+                            if (nvalid[ns] && (a.acc_out || a.y_f32)) {
+                                const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
+                                if (a.acc_out) a.acc_out[ridx] = accv;
+                                if (a.y_f32) a.y_f32[ridx] = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
+                            }
+                        }
+                        packed[ns] |= (u8 ^ 0x80u) << (8 * r);
+                    }
+                }
+    #pragma unroll
+                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
+            }
         }
     }
     __syncthreads();
+    const int dwords = min(BM, a.out_cs - m0) >> 2;  // dwords of this M tile inside the output cell
     if (a.y) {
         // dword-granular copy-out: consecutive lanes -> consecutive dwords of a pixel's channel run (coalesced,
         // conflict-free LDS reads)
-        const int dwords = min(BM, a.out_cs - m0) >> 2;  // dwords of this M tile inside the output cell
-        const int total = BN * dwords;
-        for (int p = tid; p < total; p += NT) {
-            const int pix = p / dwords, d = p - pix * dwords;
-            const int cell = celltab[pix];
-            if (cell >= 0)
-                *reinterpret_cast<uint32_t *>(a.y + (size_t)cell * a.out_cs + m0 + d * 4) =
-                    *reinterpret_cast<const uint32_t *>(otile + pix * OSTR + d * 4);
+        if (dwords == BM / 4) {
+            for (int p = tid; p < BN * (BM / 4); p += NT) {
+                const int pix = p / (BM / 4), d = p % (BM / 4);
+                const int cell = celltab[pix];
+                if (cell >= 0)
+                    *reinterpret_cast<uint32_t *>(a.y + (size_t)cell * a.out_cs + m0 + d * 4) =
+                        *reinterpret_cast<const uint32_t *>(otile + pix * OSTR + d * 4);
+            }
+        } else {
+            const int total = BN * dwords;
+            for (int p = tid; p < total; p += NT) {
+                const int pix = p / dwords, d = p - pix * dwords;
+                const int cell = celltab[pix];
+                if (cell >= 0)
+                    *reinterpret_cast<uint32_t *>(a.y + (size_t)cell * a.out_cs + m0 + d * 4) =
+                        *reinterpret_cast<const uint32_t *>(otile + pix * OSTR + d * 4);
+            }
+        }
+    }
+    if constexpr (PATCH) {
+        // fused forward_maxpool_layer_quant (ref: src/maxpool_layer.c:109-172) for size 2 / stride 2 / offset 0 on even
+        // maps: the TH x 16 patch starts on even coordinates, so it holds complete 2x2 windows; bytewise max of the
+        // four (biased) uint8 values, written straight into the pooled PHWC tensor.
+        if (a.ypool) {
+            const int OH = a.H >> 1, OW = a.W >> 1;
+            const int pdw = min(BM, a.pool_cs - m0) >> 2;
+            const int total = (TH / 2) * 8 * pdw;
+            for (int p = tid; p < total; p += NT) {
+                const int pp = p / pdw, d = p - pp * pdw;
+                const int pr = pp >> 3, pc = pp & 7;
+                const int oy = (py0 >> 1) + pr, ox = (px0 >> 1) + pc;
+                if (oy < OH && ox < OW) {
+                    const char *src = otile + ((2 * pr) * 16 + 2 * pc) * OSTR + d * 4;
+                    uint32_t m = max_s8x4(*reinterpret_cast<const uint32_t *>(src),
+                                          *reinterpret_cast<const uint32_t *>(src + OSTR));
+                    m = max_s8x4(m, *reinterpret_cast<const uint32_t *>(src + 16 * OSTR));
+                    m = max_s8x4(m, *reinterpret_cast<const uint32_t *>(src + 17 * OSTR));
+                    const size_t cell = a.pool_lead + ((size_t)pb * (OH + 1) + (oy + 1)) * (OW + 1) + ox;
+                    *reinterpret_cast<uint32_t *>(a.ypool + cell * a.pool_cs + m0 + d * 4) = m;
+                }
+            }
         }
     }
 }
@@ -533,7 +614,7 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
     int bm = g_force_bm, bn = g_force_bn;
     if (!bm) bm = a.n >= 128 ? 128 : (a.n > 32 ? 64 : 32);
     a.debug = g_debug;
-    if (a.cb == 64 && !g_force_generic && !g_no_rows && g_force_patch < 0) {
+    if (a.cb == 64 && !g_force_generic && !g_no_rows && g_force_patch < 0 && !a.ypool) {
         // row-image kernel (conv_rows.hip): 256-wide tiles while two workgroups still fit a CU's LDS (W <= 14)
         int rbn = bn ? bn : (a.W + 2 <= 16 ? 256 : 128);
         int rc = conv_rows_launch(a, st, bm, rbn);
@@ -544,6 +625,7 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
     // full image rows; FLAT for the small maps where a patch would be mostly padding.
     bool patch = a.ksize == 3 && a.W >= 24 && a.H >= 8;
     if (g_force_patch >= 0) patch = g_force_patch == 1;
+    if (a.ypool) patch = true;  // the fused 2x2 maxpool needs 2-D patches (complete windows)
     if (!bn) {
         bn = 256;
         long tiles;
@@ -556,7 +638,7 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
     int rc = launch_any(a, st, bm, bn, patch);
     if (rc == MI355_EINVAL && !(g_force_bm || g_force_bn)) {
         // staging budget exceeded (very wide rows in FLAT mode): fall back to the other mode / narrower tile
-        rc = launch_any(a, st, bm, 128, a.ksize == 3 ? !patch : false);
+        rc = launch_any(a, st, bm, 128, a.ypool ? true : (a.ksize == 3 ? !patch : false));
     }
     return rc;
 }

@@ -417,20 +417,17 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
                 const int4 dz4 = *reinterpret_cast<const int4 *>(ldsPI + BM + ocl);
                 const int4 cb4 = *reinterpret_cast<const int4 *>(ldsPI + 3 * BM + ocl);
                 const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, cbv[4] = {cb4.x, cb4.y, cb4.z, cb4.w};
-                uint32_t packed[NS];
-#pragma unroll
-                for (int ns = 0; ns < NS; ++ns) packed[ns] = 0;
+                int32_t accb[4][NS];
+                double mp[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double mp = ldsPM[2 * BM + ocl + r];
+                    mp[r] = ldsPM[2 * BM + ocl + r];
 #pragma unroll
-                    for (int ns = 0; ns < NS; ++ns) {
-                        // |dz| <= 128 and |sx| < 2^23 (K <= 64K): 24-bit multiply, full rate
-                        const int32_t accb = acc[ms][ns][grp * 4 + r] + cbv[r] + __mul24(dzv[r], sx[ns]);
-                        const uint32_t u8 = requant_finish<ACT, SAT>(requant_q_exact(accb, mp), a.zp_act);
-                        packed[ns] |= (u8 ^ 0x80u) << (8 * r);
-                    }
+                    for (int ns = 0; ns < NS; ++ns)  // |dz| <= 128, |sx| < 2^23 (K <= 64K): 24-bit multiply, full rate
+                        accb[r][ns] = acc[ms][ns][grp * 4 + r] + cbv[r] + __mul24(dzv[r], sx[ns]);
                 }
+                uint32_t packed[NS];
+                requant_group<ACT, SAT, NS>(accb, mp, a.zp_act, packed);
 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
             }

@@ -7,20 +7,6 @@
 //   yolo_logistic       ref: src/yolo_layer.c:132-146
 #include "kargs.h"
 
-// bytewise signed max of two dwords holding 4 biased (x ^ 0x80) activations each:
-// max_u8 on the raw values == max_s8 on the biased ones.
-__device__ __forceinline__ uint32_t max_s8x4(uint32_t p, uint32_t q)
-{
-    uint32_t r = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int a = (int)(int8_t)(p >> (8 * i)), b = (int)(int8_t)(q >> (8 * i));
-        r |= ((uint32_t)(a > b ? a : b) & 0xFFu) << (8 * i);
-    }
-    return r;
-}
-
-
 __global__ __launch_bounds__(256) void maxpool_u8_kernel(const PoolArgs a)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

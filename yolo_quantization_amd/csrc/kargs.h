@@ -25,6 +25,8 @@ struct ConvArgs {
     const double *mprime;    // M_value * shift_value
     const int32_t *cwb;      // cw + bias
     const ConvBlobHeader *hdr;
+    uint8_t *ypool;          // fused 2x2/2 maxpool output (PHWC, biased) or null
+    int pool_cs, pool_lead;
     int lds_param_off;       // conv_rows: byte offset of the staged per-channel epilogue parameters in LDS
     int debug;               // timing-ablation switches (results are wrong when non-zero): see mi355_debug_flags
 };
@@ -45,6 +47,10 @@ struct AuxArgs {
     int zp_in, zp_act, act, store_mode;
     float s_act;
     int total_n;
+    const double *mprime;    // folded M_value * shift_value
+    uint8_t *ypool;          // fused 2x2/2 maxpool output or null
+    int pool_cs, pool_lead;
+    const ConvBlobHeader *hdr;  // device copy of the blob header (data-dependent pow2 flag)
 };
 
 struct PoolArgs {
@@ -69,6 +75,7 @@ struct LayoutArgs {
 int conv_igemm_launch(ConvArgs &a, hipStream_t st);
 int conv_rows_launch(ConvArgs &a, hipStream_t st, int bm, int bn);
 int conv_first_launch(AuxArgs &a, hipStream_t st);
+int conv_first_pool_launch(AuxArgs &a, hipStream_t st);
 int conv_ref_f32_launch(AuxArgs &a, hipStream_t st);
 int maxpool_launch(const PoolArgs &a, hipStream_t st);
 int copy_cells_launch(const CopyArgs &a, hipStream_t st);

@@ -322,8 +322,9 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
 }
 
 // ------------------------------------------------------------------------------------------------ convolution
-int mi355_conv_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const uint8_t *w_u8,
-                       const uint8_t *zp_w, const mi355_tensor *y, int32_t *acc_out, float *y_f32, void *stream)
+static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const uint8_t *w_u8,
+                             const uint8_t *zp_w, const mi355_tensor *y, const mi355_tensor *ypool, int32_t *acc_out,
+                             float *y_f32, void *stream)
 {
     if (!d || !x || !x->data || !blob) return einval("conv_forward: null");
     if (d->stride != 1) return einval("conv_forward: stride must be 1 (3x3 s1 / 1x1 of yolov3-tiny)");
@@ -331,6 +332,11 @@ int mi355_conv_forward(const mi355_conv_desc *d, const mi355_tensor *x, const vo
     if (x->C != d->c) return einval("conv_forward: x.C != desc.c");
     if (y && (y->C != d->n || y->B != x->B || y->H != x->H || y->W != x->W || !y->data))
         return einval("conv_forward: y shape");
+    if (ypool) {
+        if ((x->H & 1) || (x->W & 1) || ypool->C != d->n || ypool->B != x->B || ypool->H != x->H / 2 ||
+            ypool->W != x->W / 2 || !ypool->data || d->ksize != 3 || d->accum_mode != MI355_ACC_EXACT || acc_out || y_f32)
+            return einval("conv_pool_forward: fused 2x2/2 maxpool needs a 3x3 conv on an even map, exact mode, no dumps");
+    }
     ConvBlobHeader h;
     if (blob_layout(d->n, d->c, d->ksize, &h) != MI355_OK) return einval("conv_forward: shape");
     const char *base = (const char *)blob;
@@ -351,11 +357,16 @@ int mi355_conv_forward(const mi355_conv_desc *d, const mi355_tensor *x, const vo
         a.B = x->B; a.H = x->H; a.W = x->W; a.c = d->c; a.n = d->n; a.ksize = d->ksize; a.pad = d->pad;
         a.zp_in = d->zp_in; a.zp_act = d->zp_act; a.act = d->activation; a.store_mode = d->store_mode;
         a.s_act = d->s_act; a.total_n = total_n;
+        a.mprime = (const double *)(base + h.off_mprime); a.hdr = (const ConvBlobHeader *)base;
+        a.ypool = ypool ? (uint8_t *)ypool->data : nullptr; a.pool_cs = ypool ? ypool->cs : 0;
+        a.pool_lead = ypool ? ypool->lead : 0;
         if (d->accum_mode == MI355_ACC_REF_F32) {
+            if (ypool) return einval("conv_pool_forward: not in ref-f32 mode");
             if (!w_u8 || !zp_w) return einval("conv_forward: ref-f32 mode needs the raw weights_uint8 / zp_w");
             return conv_ref_f32_launch(a, st);
         }
         if (x->cs != 4) return einval("conv_forward: first layer expects a cs==4 image tensor");
+        if (ypool) return conv_first_pool_launch(a, st) == MI355_OK ? MI355_OK : einval("conv_pool_forward: shape not fusable");
         return conv_first_launch(a, st);
     }
     if (x->cs % 16) return einval("conv_forward: x.cs must be a multiple of 16");
@@ -373,6 +384,8 @@ int mi355_conv_forward(const mi355_conv_desc *d, const mi355_tensor *x, const vo
     a.total_n = total_n;
     a.zp_act = d->zp_act; a.act = d->activation; a.store_mode = d->store_mode; a.s_act = d->s_act;
     a.mpad = h.mpad;
+    a.ypool = ypool ? (uint8_t *)ypool->data : nullptr; a.pool_cs = ypool ? ypool->cs : 0;
+    a.pool_lead = ypool ? ypool->lead : 0;
     a.shift = (const int32_t *)(base + h.off_shift);
     a.mprime = (const double *)(base + h.off_mprime);
     a.cwb = (const int32_t *)(base + h.off_cwb);
@@ -381,6 +394,19 @@ int mi355_conv_forward(const mi355_conv_desc *d, const mi355_tensor *x, const vo
     if (rc == MI355_EINVAL) return einval("conv_forward: no tile configuration fits this shape");
     if (rc != MI355_OK) return hip_fail(hipGetLastError(), "conv_igemm launch");
     return rc;
+}
+
+int mi355_conv_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const uint8_t *w_u8,
+                       const uint8_t *zp_w, const mi355_tensor *y, int32_t *acc_out, float *y_f32, void *stream)
+{
+    return conv_forward_impl(d, x, blob, w_u8, zp_w, y, nullptr, acc_out, y_f32, stream);
+}
+
+int mi355_conv_pool_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const mi355_tensor *y,
+                            const mi355_tensor *ypool, void *stream)
+{
+    if (!ypool) return einval("conv_pool_forward: ypool is null");
+    return conv_forward_impl(d, x, blob, nullptr, nullptr, y, ypool, nullptr, nullptr, stream);
 }
 
 // -------------------------------------------------------------------------------------------------------- glue

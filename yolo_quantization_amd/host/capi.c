@@ -16,6 +16,7 @@ int dnq_net_set(network *net, const char *key, int val)
     if (!strcmp(key, "accum_mode")) net->accum_mode = val;
     else if (!strcmp(key, "store_mode")) net->store_mode = val;
     else if (!strcmp(key, "dump_int32")) net->dump_int32 = val;
+    else if (!strcmp(key, "fuse_maxpool")) net->fuse_maxpool = val;
     else if (!strcmp(key, "use_graph")) net->use_graph = val;
     else if (!strcmp(key, "gpu_index")) net->gpu_index = val;
     else if (!strcmp(key, "verbose")) net->verbose = val;

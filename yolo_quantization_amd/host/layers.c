@@ -42,6 +42,11 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
     d.zp_in = l.input_data_uint8_zero_point[0];
     d.zp_act = l.activ_data_uint8_zero_point[0];
     d.s_act = l.activ_data_uint8_scales[0];
+    if (net.fused_pool_t) { /* this conv + the 2x2/2 maxpool after it as one kernel; the pre-pool tensor is not stored */
+        check_mi355(mi355_conv_pool_forward(&d, net.cur_t, l.blob_gpu, NULL, net.fused_pool_t, net.stream),
+                    "mi355_conv_pool_forward");
+        return;
+    }
     check_mi355(mi355_conv_forward(&d, net.cur_t, l.blob_gpu, l.weights_uint8_gpu, l.weight_zero_point_gpu, &l.out_t,
                                    net.dump_int32 ? l.output_int32_gpu : NULL,
                                    l.quant_stop_flag ? l.output_gpu : NULL, net.stream),

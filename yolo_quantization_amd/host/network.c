@@ -53,6 +53,8 @@ const char *get_layer_string(LAYER_TYPE t)
     return "?";
 }
 
+static void plan_fusion(network *net);
+
 /* ------------------------------------------------------------------------------------------------- host prep */
 void quant_multi_smaller_than_one_to_scale_and_shift(float real_multiplier, int32_t *quantized_multiplier,
                                                      int *right_shift)
@@ -208,9 +210,29 @@ void quantization_prep_host(network *net, float in_scale, uint8_t in_zp)
     }
 }
 
+/* conv i + maxpool i+1 can run as one kernel when the pool is the reference's size-2 / stride-2 / offset-0 window on an
+ * even map, the conv is 3x3 and nothing else (a route) reads the conv's own output */
+static void plan_fusion(network *net)
+{
+    for (int i = 0; i < net->n; ++i) net->layers[i].fuse_next_pool = 0;
+    for (int i = 0; i + 1 < net->n; ++i) {
+        layer *c = &net->layers[i], *p = &net->layers[i + 1];
+        if (c->type != CONVOLUTIONAL || p->type != MAXPOOL) continue;
+        if (c->size != 3 || c->quant_stop_flag || p->size != 2 || p->stride != 2 || p->pad / 2 != 0) continue;
+        if ((c->out_h & 1) || (c->out_w & 1) || (c->c != 3 && c->c % 16)) continue;
+        if (c->c % 64 == 0) continue; /* 64-byte-chunk layers use the row-image kernel, which has no fused form yet */
+        int used = 0;
+        for (int j = 0; j < net->n; ++j)
+            if (net->layers[j].type == ROUTE)
+                for (int k = 0; k < net->layers[j].n; ++k) used |= net->layers[j].input_layers[k] == i;
+        if (!used) c->fuse_next_pool = 1;
+    }
+}
+
 void quantization_weights_and_activations_fixed_input(network *net, float in_scale, uint8_t in_zp)
 {
     quantization_prep_host(net, in_scale, in_zp);
+    plan_fusion(net);
     alloc_network_device(net);
     for (int i = 0; i < net->n; ++i)
         if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, 1);
@@ -301,8 +323,17 @@ static void run_layers(network *netp)
     for (int i = 0; i < net.n; ++i) {
         net.index = i;
         layer l = net.layers[i];
+        const int fuse = l.fuse_next_pool && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
+        net.fused_pool_t = fuse ? &netp->layers[i + 1].out_t : NULL;
         l.forward_gpu(l, net);
         if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
+        if (fuse) { /* the maxpool layer already ran inside the conv kernel: hand its tensor on and skip it */
+            ++i;
+            net.cur_t = &netp->layers[i].out_t;
+            net.cur_f32_gpu = NULL;
+            if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
+            continue;
+        }
         if (l.layer_quant_flag && !net.train) { /* ref src/network.c:248-250 */
             net.cur_t = &netp->layers[i].out_t;
             net.cur_f32_gpu = l.output_gpu;
@@ -427,6 +458,7 @@ void network_import_packed_host(network *net, const void *buf, size_t bytes)
 void network_import_packed(network *net, const void *buf, size_t bytes)
 {
     network_import_packed_host(net, buf, bytes);
+    plan_fusion(net);
     alloc_network_device(net);
     for (int i = 0; i < net->n; ++i)
         if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, 0);

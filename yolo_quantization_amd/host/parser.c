@@ -270,6 +270,7 @@ network *parse_network_cfg(char *filename, int close_quantization)
     net->outputs = net->layers[net->n - 1].outputs;
     net->input = calloc((size_t)net->inputs * net->batch, sizeof(float));
     net->input_uint8 = calloc((size_t)net->inputs * net->batch, sizeof(uint8_t));
+    net->fuse_maxpool = 1;
     net->accum_mode = MI355_ACC_EXACT;
     net->store_mode = MI355_STORE_WRAP;
     return net;
