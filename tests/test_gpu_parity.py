@@ -222,12 +222,14 @@ def test_fused_maxpool_net_equals_unfused(cfg_dir, tmp_path):
         net.forward(); net.sync()
         outs[fuse] = [net.pull(i) for i in range(net.n)]
         info = net.info
+        fused_flags = [net.is_fused(i) for i in range(net.n)]
         net.close()
     fused_convs = 0
     for i, inf in enumerate(info):
         nxt = info[i + 1] if i + 1 < len(info) else None
         skipped = (inf["type"] == binding.T_CONV and nxt and nxt["type"] == binding.T_MAXPOOL and inf["size"] == 3
                    and nxt["size"] == 2 and nxt["stride"] == 2 and inf["c"] % 64 != 0)
+        assert skipped == fused_flags[i]
         if skipped:
             fused_convs += 1
             continue  # its own tensor is not stored in the fused configuration
@@ -248,7 +250,7 @@ def _run_host_net(cfg, wts, x_u8_batch, accum, store=binding.STORE_WRAP, graph=F
         net.forward()
     net.sync()
     outs = [net.pull(i) for i in range(net.n)]
-    info = net.info
+    info = [dict(inf, fused=net.is_fused(i)) for i, inf in enumerate(net.info)]
     net.close()
     return outs, info
 
@@ -354,9 +356,10 @@ def test_yolov3_tiny_batch64_properties(cfg_dir, tmp_path):
     xb[1::2] = synth.synth_image_u8(3, 416, 416, seed=8)  # two distinct images interleaved
     outs, info = _run_host_net(cfg, wts, xb, binding.ACC_EXACT, graph=True, dump_int32=False)
     one, _ = _run_host_net(cfg, wts, x[None], binding.ACC_EXACT)
+    assert sum(inf["fused"] for inf in info) == 3  # L0, L2, L4 run fused with their maxpools in this configuration
     for i, inf in enumerate(info):
-        if inf["type"] == binding.T_YOLO:
-            continue
+        if inf["type"] == binding.T_YOLO or inf["fused"]:
+            continue  # a fused conv's own (pre-pool) tensor is not stored
         per = inf["outputs"]
         u = outs[i]["u8"].reshape(64, per)
         assert np.array_equal(u[0], one[i]["u8"]), f"layer {i}: slot 0 != batch-1 run"

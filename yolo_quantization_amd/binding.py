@@ -248,6 +248,7 @@ def host():
             getattr(L, n).restype = vp
             getattr(L, n).argtypes = [vp, ci]
         L.dnq_layer_prep.argtypes = [vp, ci] + [vp] * 6
+        L.dnq_layer_is_fused.argtypes = [vp, ci]
         _host = L
     return _host
 
@@ -333,6 +334,10 @@ class Net:
         if ty == T_YOLO or self.info[i]["quant_stop"]:
             out["f32"] = _as(self.H.dnq_layer_f32(self.h, i), cnt, C.c_float).copy()
         return out
+
+    def is_fused(self, i):
+        """conv i runs fused with the maxpool after it: its own uint8 tensor is not stored."""
+        return bool(self.H.dnq_layer_is_fused(self.h, i))
 
     def prep(self, i):
         n = max(self.info[i]["n"], 1)
