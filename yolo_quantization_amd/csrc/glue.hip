@@ -7,6 +7,8 @@
 //   yolo_logistic       ref: src/yolo_layer.c:132-146
 #include "kargs.h"
 
+static inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
+
 __global__ __launch_bounds__(256) void maxpool_u8_kernel(const PoolArgs a)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,6 +77,33 @@ __global__ __launch_bounds__(256) void nchw_to_phwc_kernel(const LayoutArgs a)
     *reinterpret_cast<uint32_t *>(a.t + cell * a.cs + g * 4) = v;
 }
 
+// 3-channel network input, W % 4 == 0: one thread converts 4 consecutive pixels -- three coalesced dword loads (one per
+// colour plane) and one 16-byte store of four (c0,c1,c2,0) cells.  4x fewer, 4x wider memory instructions than the
+// generic converter (this kernel is on the timed path: the reference hands over [B][3][H][W] uint8).
+__global__ __launch_bounds__(256) void nchw3_to_phwc4_kernel(const LayoutArgs a)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int wq = a.W >> 2;
+    const long total = (long)a.B * a.H * wq;
+    if (idx >= total) return;
+    const int xq = (int)(idx % wq);
+    const int y = (int)((idx / wq) % a.H);
+    const int b = (int)(idx / ((long)wq * a.H));
+    const long hw = (long)a.H * a.W;
+    const long pix = (long)y * a.W + xq * 4;
+    const uint32_t p0 = *reinterpret_cast<const uint32_t *>(a.nchw + ((long)b * 3 + 0) * hw + pix);
+    const uint32_t p1 = *reinterpret_cast<const uint32_t *>(a.nchw + ((long)b * 3 + 1) * hw + pix);
+    const uint32_t p2 = *reinterpret_cast<const uint32_t *>(a.nchw + ((long)b * 3 + 2) * hw + pix);
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        o[i] = ((p0 >> (8 * i)) & 0xFFu) | (((p1 >> (8 * i)) & 0xFFu) << 8) | (((p2 >> (8 * i)) & 0xFFu) << 16);
+    const long cell = a.lead + ((long)b * (a.H + 1) + (y + 1)) * (a.W + 1) + xq * 4;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(a.t + cell * 4);
+    // cell addresses are only 4-byte aligned in general ((W+1) is odd): four dword stores, still coalesced across lanes
+    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+}
+
 __global__ __launch_bounds__(256) void phwc_to_nchw_kernel(const LayoutArgs a)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,7 +138,6 @@ __global__ __launch_bounds__(256) void yolo_logistic_kernel(const float *in, flo
     out[idx] = (e == 2 || e == 3) ? v : (float)(1. / (1. + exp(-(double)v)));
 }
 
-static inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
 
 int maxpool_launch(const PoolArgs &a, hipStream_t st)
 {
@@ -125,6 +153,11 @@ int copy_cells_launch(const CopyArgs &a, hipStream_t st)
 }
 int nchw_to_phwc_launch(const LayoutArgs &a, hipStream_t st)
 {
+    if (a.C == 3 && a.cs == 4 && (a.W & 3) == 0 && (((size_t)a.nchw) & 3) == 0) {
+        const long total = (long)a.B * a.H * (a.W >> 2);
+        hipLaunchKernelGGL(nchw3_to_phwc4_kernel, dim3(nblk(total)), dim3(256), 0, st, a);
+        return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+    }
     const long total = (long)a.B * ((a.C + 3) / 4) * a.H * a.W;
     hipLaunchKernelGGL(nchw_to_phwc_kernel, dim3(nblk(total)), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
