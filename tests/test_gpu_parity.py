@@ -78,14 +78,36 @@ def test_conv_mfma_bit_exact(case, store):
     if store == binding.STORE_WRAP:
         sat = np.stack([oracle.requant(acc[b], bias, mv, sv, zp_act, oracle.ACT[act], oracle.STORE_SATURATE) for b in range(B)])
         assert (sat != u8).any(), "case should exercise out-of-range (wrap != saturate) elements"
+    # the throughput path: no dumps requested -> the kernels take their specialised (branch-free) epilogue
+    fast = binding.conv_forward(xt, wq, zp_w, k, bias, mv, sv, zp_in, zp_act, 0.05, binding.ACT[act], store,
+                                binding.ACC_EXACT, want_acc=False)
+    assert np.array_equal(fast["u8"].reshape(B, n, H * W), u8), "uint8 activations, fast epilogue"
 
 
-@pytest.mark.parametrize("bm,bn", [(128, 256), (128, 128), (64, 256), (64, 128), (32, 256), (32, 128)])
-def test_conv_every_tile_config(bm, bn):
-    """Force each compiled tile configuration on a shape it supports."""
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+@pytest.mark.parametrize("c,n,k,H,W", [(64, 128, 3, 13, 13), (256, 64, 1, 26, 26), (32, 32, 3, 20, 20), (3, 16, 3, 24, 24)])
+def test_conv_fast_epilogue_huge_requantised_values(c, n, k, H, W, store):
+    """Multipliers close to 1: |q| reaches 10^5..10^6, far outside the range of the 24-bit leaky shortcut, so the
+    wave-uniform exact fallback of the fast epilogue has to produce the reference's bytes."""
+    rng = np.random.default_rng(c + n + k)
+    x = rng.integers(0, 256, (2, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, k, 2.0 ** -3, 2.0 ** -1)
+    xt = binding.DevTensor.from_nchw(x, 17)
+    got = binding.conv_forward(xt, wq, zp_w, k, bias, mv, sv, 17, 23, 1.0, binding.ACT["leaky"], store, want_acc=False)
+    acc, u8 = _oracle_layer(x, wq, zp_w, k, 17, bias, mv, sv, 23, oracle.LEAKY, store, oracle.ACC_EXACT)
+    assert np.abs(acc).max() * mv.max() * sv.max() > 45000
+    assert np.array_equal(got["u8"].reshape(2, n, H * W), u8)
+
+
+@pytest.mark.parametrize("bm,bn,nt", [(128, 256, 0), (128, 128, 0), (64, 256, 0), (64, 128, 0), (32, 256, 0), (32, 128, 0),
+                                      (128, 384, 0), (128, 384, 3), (128, 384, 7), (128, 256, 5), (64, 128, 13)])
+def test_conv_every_tile_config(bm, bn, nt):
+    """Force each compiled tile configuration (and, for the row-image kernel, uneven N-tile counts: tiles narrower
+    than their capacity leave whole 32-column sub-tiles idle) on a shape it supports."""
     n = {128: 256, 64: 64, 32: 32}[bm]
     B, c, H, W, k = 2, 64, 20, 19, 3
-    rng = np.random.default_rng(bm * 7 + bn)
+    bm |= nt << 16
+    rng = np.random.default_rng((bm & 0xFFFF) * 7 + bn + nt)
     x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
     wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, k)
     xt = binding.DevTensor.from_nchw(x, 23)

@@ -24,7 +24,7 @@ NET = [(16, 32, 208, 3), (32, 64, 104, 3), (64, 128, 52, 3), (128, 256, 26, 3), 
        (1024, 256, 13, 1), (512, 30, 13, 1), (256, 128, 13, 1), (384, 256, 26, 3), (256, 30, 26, 1)]
 
 
-def run(c, n, hw, k, batch, iters, tile=None, mode=None, check=False):
+def run(c, n, hw, k, batch, iters, tile=None, mode=None, check=False, nt=0):
     S = binding.shim()
     rng = np.random.default_rng(1)
     x = rng.integers(0, 256, (batch, c, hw, hw), dtype=np.uint8)
@@ -38,6 +38,7 @@ def run(c, n, hw, k, batch, iters, tile=None, mode=None, check=False):
     d = binding.ConvDesc(n, c, k, 1, k // 2, binding.ACT["leaky"], 0, 0, 0, 23, 1.0)
     if tile or mode:
         bm, bn = tile if tile else (0, 0)
+        bm |= nt << 16
         flag = (1 << 30) if mode == "patch" else ((1 << 29) if mode == "flat" else 0)
         S.mi355_conv_set_tile(bm, bn | flag)
     st = C.c_void_p(); binding.check(S.mi355_stream_create(C.byref(st)))
@@ -60,7 +61,7 @@ def run(c, n, hw, k, batch, iters, tile=None, mode=None, check=False):
     ops = 2.0 * n * c * k * k * hw * hw * batch
     byt = x.size + wq.size + n * hw * hw * batch
     return {"c": c, "n": n, "hw": hw, "k": k, "batch": batch, "us": round(t * 1e6, 2), "tops": round(ops / t / 1e12, 1),
-            "frac_mfma_peak": round(ops / t / 1e12 / PEAK, 4), "gbs": round(byt / t / 1e9, 1), "tile": tile, "mode": mode}
+            "frac_mfma_peak": round(ops / t / 1e12 / PEAK, 4), "gbs": round(byt / t / 1e9, 1), "tile": tile, "mode": mode, "nt": nt}
 
 
 if __name__ == "__main__":
@@ -70,7 +71,8 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--tile", type=int, nargs=2); ap.add_argument("--mode", choices=["flat", "patch"])
     ap.add_argument("--net", action="store_true"); ap.add_argument("--sweep", action="store_true")
-    ap.add_argument("--shift", type=int, default=13)
+    ap.add_argument("--shift", type=int, default=13); ap.add_argument("--plan", action="store_true")
+    ap.add_argument("--nt", type=int, default=0); ap.add_argument("--timeline", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="timing ablation of the K loop (results are wrong)")
     a = ap.parse_args()
     SHIFT = a.shift
@@ -82,6 +84,50 @@ if __name__ == "__main__":
             r = run(a.c, a.n, a.hw, a.k, a.batch, a.iters, tuple(a.tile) if a.tile else None, a.mode)
             print(name, r["us"], "us", r["tops"], "TOPS")
         S.mi355_debug_flags(0)
+    elif a.timeline:  # per-workgroup phase timestamps (needs the -DMI355_ABLATE build)
+        S = binding.shim()
+        r = run(a.c, a.n, a.hw, a.k, a.batch, 1, tuple(a.tile) if a.tile else None, a.mode, nt=a.nt)
+        S.mi355_stream_sync(None)
+        ts = np.zeros((6, 4096), np.int64)
+        S.mi355_debug_read_ts.argtypes = [C.c_void_p]
+        assert S.mi355_debug_read_ts(ts.ctypes.data) == 0
+        nb = int((ts[0] > 0).sum())
+        t = ts[:, :nb].astype(np.float64) / 100.0  # us
+        t0 = t[0].min()
+        print(json.dumps(r))
+        print(f"blocks {nb}; kernel span first-start..last-end {t[5].max() - t0:.2f} us; start skew p50 {np.median(t[0]) - t0:.2f} max {t[0].max() - t0:.2f}")
+        names = ["setup(index math, acc zero, params)", "first DMA wait", "K loop", "epilogue requant", "copy-out"]
+        for i, nm in enumerate(names):
+            d = t[i + 1] - t[i]
+            print(f"  {nm:40s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
+        d = t[5] - t[0]
+        print(f"  {'whole workgroup':40s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
+        order = np.argsort(t[0])
+        late = order[256:] if nb > 256 else []
+        if len(late):
+            print(f"  second-round blocks: {len(late)}, start p50 {np.median(t[0][late]) - t0:.2f} us")
+    elif a.plan:  # rows-kernel tile plan sweep: capacity x tile count, per conv shape of the net
+        for c, n, hw, k in NET:
+            if c % 64:
+                continue
+            bm = 128 if n >= 128 else (64 if n > 32 else 32)
+            mt = (n + bm - 1) // bm
+            total = 64 * hw * hw
+            print(json.dumps({"auto": run(c, n, hw, k, 64, a.iters)}))
+            for bn in (384, 256, 128):
+                if bn == 384 and bm != 128:
+                    continue
+                nt0 = -(-total // bn)
+                cands = {nt0}
+                for blocks in (256, 512, 768, 1024, 1536, 2048):
+                    if blocks // mt >= nt0:
+                        cands.add(blocks // mt)
+                for nt in sorted(cands)[:4]:
+                    try:
+                        r = run(c, n, hw, k, 64, a.iters, (bm, bn), None, nt=nt)
+                        print(json.dumps({"c": c, "n": n, "hw": hw, "bn": bn, "nt": nt, "blocks": nt * mt, "us": r["us"], "tops": r["tops"]}))
+                    except Exception as e:  # noqa: BLE001
+                        print(json.dumps({"c": c, "n": n, "hw": hw, "bn": bn, "nt": nt, "error": str(e)[:80]}))
     elif a.net:
         for c, n, hw, k in NET:
             print(json.dumps(run(c, n, hw, k, 64, a.iters)))
@@ -93,4 +139,4 @@ if __name__ == "__main__":
                 except Exception as e:  # noqa: BLE001
                     print(json.dumps({"tile": [bm, bn], "mode": mode, "error": str(e)[:100]}))
     else:
-        print(json.dumps(run(a.c, a.n, a.hw, a.k, a.batch, a.iters, tuple(a.tile) if a.tile else None, a.mode)))
+        print(json.dumps(run(a.c, a.n, a.hw, a.k, a.batch, a.iters, tuple(a.tile) if a.tile else None, a.mode, nt=a.nt)))

@@ -229,6 +229,7 @@ def host():
         L.pull_layer_output.argtypes = [vp, ci]
         L.network_profile_begin.argtypes = [vp, ci]
         L.network_profile_read.argtypes = [vp, vp]
+        L.network_profile_set_stride.argtypes = [vp, ci]
         L.network_packed_size.restype = C.c_size_t
         L.network_packed_size.argtypes = [vp]
         L.network_export_packed.argtypes = [vp, vp]
@@ -348,7 +349,8 @@ class Net:
         return dict(biases_int32=b, M_value=mv, shift_value=sv, M0=m0, shift=sh, s_in=q[0], zp_in=int(q[1]),
                     s_act=q[2], zp_act=int(q[3]))
 
-    def profile_begin(self, max_steps):
+    def profile_begin(self, max_steps, stride=1):
+        self.H.network_profile_set_stride(self.h, stride)
         self.H.network_profile_begin(self.h, max_steps)
 
     def profile_read(self):

@@ -96,32 +96,40 @@ __device__ __forceinline__ uint32_t requant_finish(int32_t q, int zp_act)
 // ---------------------------------------------------------------------------------------------------------
 // Group form used by the conv epilogues: 4 consecutive channels (one packed dword) x NS pixels held by a lane.
 // accb[r][ns] = accumulator + cw + bias + dz*sx;  mp[r] = folded multiplier.  Returns the BIASED packed bytes
-// (uint8 ^ 0x80).  ~13 VALU instructions per output: accb is formed by the caller (2), cvt/mul/cvt (3), activation
-// (LEAKY: 7, branch free: v = zp + max(q,0) - ((max(-q,0)+5)*0xCCCD >> 19), exact while max(-q,0)+5 < 2^16; a
-// wave-uniform fallback recomputes the group with a true division otherwise), v_perm packing (0.75) + one xor.
+// (uint8 ^ 0x80).  ~11 VALU instructions per output, all full rate on gfx950 (tools/ubench/valu_rate.hip): accb is
+// formed by the caller (1-2), cvt/mul/cvt (3), activation (LEAKY: 5 + a running minimum, see requant_values),
+// v_perm packing (0.75) + one xor.
 // ---------------------------------------------------------------------------------------------------------
 template <int ACT, bool SAT, int NS>
 __device__ __forceinline__ void requant_values(const int32_t (&accb)[4][NS], const double (&mp)[4], int zp_act,
                                                int32_t (&v)[4][NS])
 {
-    bool big = false;
+    // LEAKY, branch free in 5 VALU instructions per output.  With p = max(q,0), nq = p - q (= max(-q,0)), C = 0xCCCD:
+    //     zp + p - floor((nq+5)*C / 2^19)  ==  ((zp + p) * 2^19 + (2^19 - 1 - 5C) - nq*C) >> 19      (arithmetic shift)
+    // because -floor(t/N) == floor((N - 1 - t)/N).  (nq+5)*C >> 19 == (nq+5)/10 while nq + 5 < 2^16; the int32 form
+    // holds while nq <= 40000; p << 19 may wrap in WRAP mode, which only drops bits above the stored byte.  Lanes
+    // outside that range (never on sane data) send the whole wave through the division form below.
+    const int kleaky = (zp_act << 19) + ((1 << 19) - 1 - 5 * 0xCCCD);
+    int32_t qmin = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
-            const int32_t q = requant_q_exact(accb[r][ns], mp[r]);
+            int32_t q = requant_q_exact(accb[r][ns], mp[r]);
             if (ACT == MI355_ACT_LEAKY) {
-                const int32_t nq = max(0 - q, 0);
-                big |= nq > 65530;
-                const uint32_t d10 = __umul24((uint32_t)nq + 5u, 0xCCCDu) >> 19;
-                v[r][ns] = zp_act + max(q, 0) - (int32_t)d10;
+                qmin = min(qmin, q);
+                if (SAT) q = min(q, 2047);  // zp + 2047 saturates anyway; keeps p << 19 inside int32
+                const int32_t p = max(q, 0);
+                const int32_t nq = p - q;
+                const int32_t m = __mul24(nq, -0xCCCD) + kleaky;
+                v[r][ns] = (int32_t)(((uint32_t)p << 19) + (uint32_t)m) >> 19;
             } else if (ACT == MI355_ACT_RELU6) {
                 v[r][ns] = zp_act + max(q, 0);
             } else {
                 v[r][ns] = zp_act + q;
             }
         }
-    if (ACT == MI355_ACT_LEAKY && __builtin_amdgcn_ballot_w64(big) != 0) {  // never taken on sane data; keeps exactness
+    if (ACT == MI355_ACT_LEAKY && __builtin_amdgcn_ballot_w64(qmin < -40000) != 0) {  // keeps exactness on any data
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll

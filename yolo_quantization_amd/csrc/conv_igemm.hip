@@ -526,7 +526,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
 // ---------------------------------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------------------
-static int g_force_bm = 0, g_force_bn = 0, g_force_patch = -1, g_force_generic = 0, g_no_rows = 0;
+static int g_force_nt = 0, g_force_bm = 0, g_force_bn = 0, g_force_patch = -1, g_force_generic = 0, g_no_rows = 0;
 static int g_debug = 0;
 extern "C" int mi355_debug_flags(int flags)
 {
@@ -539,7 +539,8 @@ extern "C" int mi355_conv_set_tile(int bm, int bn)
     g_force_patch = (bn & (1 << 30)) ? 1 : ((bn & (1 << 29)) ? 0 : -1);
     g_force_generic = (bn & (1 << 28)) ? 1 : 0;  // bit 28: force the generic K loop (tests)
     g_no_rows = (bn & (1 << 27)) ? 1 : 0;        // bit 27: do not use conv_rows.hip
-    g_force_bm = bm;
+    g_force_bm = bm & 0xFFFF;
+    g_force_nt = (bm >> 16) & 0x7FFF;            // bm bits 16..30: force the N-tile count of conv_rows.hip
     g_force_bn = bn & 0xFFFF;
     return MI355_OK;
 }
@@ -615,11 +616,43 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
     if (!bm) bm = a.n >= 128 ? 128 : (a.n > 32 ? 64 : 32);
     a.debug = g_debug;
     if (a.cb == 64 && !g_force_generic && !g_no_rows && g_force_patch < 0 && !a.ypool) {
-        // row-image kernel (conv_rows.hip): 256-wide tiles while two workgroups still fit a CU's LDS (W <= 14)
-        int rbn = bn ? bn : (a.W + 2 <= 16 ? 256 : 128);
-        int rc = conv_rows_launch(a, st, bm, rbn);
-        if (rc == MI355_EINVAL && !bn) rc = conv_rows_launch(a, st, bm, 128);
+        // row-image kernel (conv_rows.hip).  Tile plan: N tiles split the pixel range evenly; pick the tile capacity
+        // (384 / 256 / 128 columns) and the tile count that minimise  rounds x (fixed + K-steps x step time)  where a
+        // round is one workgroup per CU for the 8-wave configurations and two for the 4-wave one (measured model,
+        // profiles/r01_ablation.md: ~10 us fixed per workgroup, ~0.2 us + 0.04 us per MFMA of the busiest wave per step).
+        int best_bn = 0, best_nt = 0;
+        if (bn) {
+            best_bn = bn; best_nt = g_force_nt;
+        } else {
+            double best = 1e30;
+            const int mt = (a.mpad + bm - 1) / bm;
+            const int cands[3] = {384, 256, 128};
+            for (int ci = 0; ci < 3; ++ci) {
+                const int cbn = cands[ci];
+                if (cbn == 384 && bm != 128) continue;
+                const int nt0 = (a.total_n + cbn - 1) / cbn;
+                const long blocks0 = (long)mt * nt0;
+                // the 128-column configurations fit two workgroups per CU, but one per CU is faster while that is enough
+                const int slots = (cbn == 128 && blocks0 > 256) ? 512 : 256;
+                const int rounds = (int)((blocks0 + slots - 1) / slots);
+                int nt = (int)(((long)rounds * slots) / mt);  // fill the last round with more, narrower tiles
+                if (nt < nt0) nt = nt0;
+                const int px = (a.total_n + nt - 1) / nt;
+                const int waves_n = (cbn == 128 && bm == 128) ? 2 : 4;
+                const int sub = ((px + 31) / 32 + waves_n - 1) / waves_n;   // sub-tiles of the busiest wave
+                const int ms = (bm >= 64) ? 2 : 1;
+                const double step = 0.2 + 0.04 * (2.0 * ms * sub);
+                // narrow tiles re-load the weights and the halo rows more often (3x3); for 1x1 they are the cheapest
+                const double shape = (cbn == 128) ? (a.ksize == 3 ? 1.15 : 0.85) : 1.0;
+                const double cost = rounds * (10.0 + a.ksteps * step) * shape + 0.005 * cbn;
+                if (cost < best) { best = cost; best_bn = cbn; best_nt = nt; }
+            }
+        }
+        a.ntiles_n = best_nt;
+        int rc = conv_rows_launch(a, st, bm, best_bn);
+        if (rc == MI355_EINVAL && !bn) { a.ntiles_n = 0; rc = conv_rows_launch(a, st, bm, 128); }
         if (rc != MI355_EINVAL) return rc;
+        a.ntiles_n = 0;
     }
     // N-tile mode: PATCH when a 16-wide patch wastes little (W >= 24) -- its halo is (TH+2)x18 cells instead of two
     // full image rows; FLAT for the small maps where a patch would be mostly padding.

@@ -24,8 +24,21 @@
 // in the product build DBG(x) is the constant 0 and every switch folds away.
 #ifdef MI355_ABLATE
 #define DBG(bit) ((a.debug & (bit)) != 0)
+// phase timestamps (100 MHz wall clock) of wave 0 of every workgroup: tools/conv_microbench.py --timeline
+#define TS_PHASES 6
+#define TS_BLOCKS 4096
+__device__ long long g_rows_ts[TS_PHASES][TS_BLOCKS];
+#define TS(k)                                                                                   \
+    do {                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < TS_BLOCKS) g_rows_ts[k][blockIdx.x] = wall_clock64(); \
+    } while (0)
+extern "C" int mi355_debug_read_ts(long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rows_ts), sizeof(long long) * TS_PHASES * TS_BLOCKS) == hipSuccess ? 0 : -5;
+}
 #else
 #define DBG(bit) (false)
+#define TS(k) do { } while (0)
 #endif
 
 #define DMA16(gsrc, ldst)                                                                               \
@@ -77,7 +90,7 @@ __device__ __forceinline__ void row_of_pixel(int n, int H, int W, int &grow, int
 }
 
 template <int BM, int BN, int WMW, int WNW, int RS, int KS>
-__global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv_rows_i8_kernel(const ConvArgs a)
+__global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8 && BN <= 256) ? 4 : 2) void conv_rows_i8_kernel(const ConvArgs a)
 {
     constexpr int NW = WMW * WNW, NT = 64 * NW;
     constexpr int TM = BM / WMW, TN = BN / WNW;
@@ -85,7 +98,6 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
     constexpr int ACH = BM / 16;
     constexpr int APT = (ACH + NW - 1) / NW;
     constexpr int HALO = (KS == 3) ? 1 : 0;
-    constexpr int ROWB = RS * 64;       // bytes of one LDS row (64 channels)
     constexpr int PIECEB = RS * 16;     // bytes between 16-byte pieces of a row
     constexpr int CPR = RS / 16;        // 1 KiB DMA chunks per row
     constexpr int OSTR = BM + 4;
@@ -94,8 +106,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ldsA = smem;                                   // [RA_STAGES][BM*64]
-    char *ldsB = smem + RA_STAGES * BM * 64;             // [2][rows_cap*ROWB]
-    const int bbytes = a.rows_cap * ROWB;
+    char *ldsB = smem + RA_STAGES * BM * 64;             // [2][rows_cap*rowb]
+    // bytes between LDS rows: RS*64 of data + a skew of (W mod 16) cells, so that the pixel after a row's last one
+    // lands in the next 16-byte bank slot -- a wave's 32 consecutive pixels then never collide across a row wrap
+    // (tools/ubench/lds_conflict.hip: 2.1x slower ds_read_b128 for W = 13 without it)
+    const int rowb = a.rowb;
+    const int bbytes = a.rows_cap * rowb;
     int *ldsS = reinterpret_cast<int *>(ldsB + 2 * bbytes);  // [rows_cap*RS] receptive-field partial sums per cell
     // per-channel epilogue parameters of this M tile, staged once (the epilogue would otherwise issue 5 dependent
     // global loads per output channel per lane): doubles first (8-byte aligned), then the three int planes
@@ -108,6 +124,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WNW, wn = wave % WNW;
     const int kh = lane >> 5, lj = lane & 31;
+    TS(0);
 
     int logical;
     {
@@ -117,14 +134,17 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
     }
     const int mtile = logical / a.ntiles_n;
     const int ntile = logical - mtile * a.ntiles_n;
-    const int n0 = ntile * BN;
+    // N tiles split the flattened pixel range evenly (tile widths differ by at most one pixel and never exceed BN):
+    // the host picks ntiles_n so that mtiles * ntiles_n fills whole rounds of workgroups over the 256 CUs.
+    const int n0 = (int)(((long)ntile * a.total_n) / a.ntiles_n);
+    const int n_end = (int)(((long)(ntile + 1) * a.total_n) / a.ntiles_n);
     const int W1 = a.W + 1, hw = a.H * a.W;
 
     // ---- tile rows: LDS row 0 = global row (row of first pixel) - HALO
     int gr0, x0;
     row_of_pixel(n0, a.H, a.W, gr0, x0);
     int gr1, x1;
-    row_of_pixel(min(n0 + BN, a.total_n) - 1, a.H, a.W, gr1, x1);
+    row_of_pixel(n_end - 1, a.H, a.W, gr1, x1);
     const int grow_first = gr0 - HALO;
     const int nrows = gr1 - gr0 + 1 + 2 * HALO;   // <= a.rows_cap (host guarantees)
     const int ndma = nrows * CPR;                 // B DMA instructions per chunk load for the whole workgroup
@@ -136,14 +156,18 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
     bool nvalid[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-        const int n = n0 + wn * TN + ns * 32 + lj;
-        nvalid[ns] = n < a.total_n;
+        const int n = n0 + (ns * WNW + wn) * 32 + lj;  // 32-column sub-tiles are dealt round-robin to the N waves
+        nvalid[ns] = n < n_end;
         int gr, x;
-        row_of_pixel(nvalid[ns] ? n : a.total_n - 1, a.H, a.W, gr, x);
+        row_of_pixel(nvalid[ns] ? n : n_end - 1, a.H, a.W, gr, x);
         prow[ns] = gr - grow_first - HALO;  // LDS row of tap dy = 0 (top tap)
         pcol[ns] = x + 1 - HALO;            // LDS cell of tap dx = 0 (left tap); cell 0 of a row is x = -1
-        bbase[ns] = prow[ns] * ROWB + pcol[ns] * 16 + kh * PIECEB;
+        bbase[ns] = prow[ns] * rowb + pcol[ns] * 16 + kh * PIECEB;
     }
+    // number of this wave's sub-tiles that hold at least one pixel of the tile (the others skip their MFMAs)
+    int ns_active = 0;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) ns_active += (n0 + (ns * WNW + wn) * 32 < n_end) ? 1 : 0;
     int atab[MS];
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
@@ -178,17 +202,26 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
             const int p = o / PIECEB, c = (o - p * PIECEB) >> 4;
             long f = cell0 + (long)r * W1 + c;
             f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
-            DMA16(base + f * a.in_cs + p * 16, buf + (j << 10));
+            DMA16(base + f * a.in_cs + p * 16, buf + r * rowb + (cj << 10));
         }
     };
 
+    // accumulators start at the per-channel constant cw + bias (blob plane cwb), so the epilogue does not add it:
+    // register grp*4+r of a 32x32 tile holds channel row 8*grp + 4*kh + r (parameter planes are padded to mpad)
     v16i acc[MS][NS];
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns)
+        for (int grp = 0; grp < 4; ++grp) {
+            const int4 c4 = *reinterpret_cast<const int4 *>(a.cwb + mtile * BM + wm * TM + ms * 32 + 8 * grp + 4 * kh);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0;
+            for (int ns = 0; ns < NS; ++ns) {
+                acc[ms][ns][grp * 4 + 0] = c4.x;
+                acc[ms][ns][grp * 4 + 1] = c4.y;
+                acc[ms][ns][grp * 4 + 2] = c4.z;
+                acc[ms][ns][grp * 4 + 3] = c4.w;
+            }
+        }
 
     // zero the S plane, stage the epilogue parameters (both visible after the first barrier of the K loop)
     for (int i = tid; i < a.rows_cap * RS; i += NT) ldsS[i] = 0;
@@ -210,12 +243,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const v4i *>(A + atab[ms] + h * 512);
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-                const v4i bf = *reinterpret_cast<const v4i *>(Bt + bbase[ns] + tapoff + h * 2 * PIECEB);
+            for (int ns = 0; ns < NS; ++ns)
+                if (ns < ns_active) {
+                    const v4i bf = *reinterpret_cast<const v4i *>(Bt + bbase[ns] + tapoff + h * 2 * PIECEB);
 #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
-            }
+                    for (int ms = 0; ms < MS; ++ms)
+                        acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
+                }
         }
     };
     // per channel chunk: every thread reduces cells of the freshly landed B buffer into S
@@ -223,7 +257,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         const int ncells = nrows * RS;
         for (int id = tid; id < ncells; id += NT) {
             const int r = id / RS, c = id - r * RS;
-            const char *p0 = Bt + r * ROWB + c * 16;
+            const char *p0 = Bt + r * rowb + c * 16;
             int t = 0;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -271,11 +305,14 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         auto mfma_half = [&](const v4i(&af)[MS], const v4i(&bf)[NS]) {
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
+                if (ns < ns_active) {  // wave-uniform: sub-tiles beyond the tile's width do no work
 #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf[ns], acc[ms][ns], 0, 0, 0);
+                    for (int ms = 0; ms < MS; ++ms)
+                        acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf[ns], acc[ms][ns], 0, 0, 0);
+                }
         };
         // prologue: B(0), A(0), A(1), A(2); retire all but A(2); first half-set
+        TS(1);
         issueB(0, 0);
         issueA(0, 0);
         if (a.ksteps > 1) issueA(1, 1);
@@ -283,6 +320,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         if (a.ksteps > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        TS(2);
         load_half(a0, b0, 0u, 0u, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         for (int chunk = 0; chunk < a.nchunks; ++chunk) {
             const bool more_chunks = chunk + 1 < a.nchunks;
@@ -293,8 +331,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
             auto step = [&](auto t_c) {
                 constexpr int t = decltype(t_c)::value;
                 constexpr int ty = t / 3, tx = t % 3;
-                constexpr int TAP = ty * ROWB + tx * 16;
-                constexpr int TAPN = ((t + 1) / 3) * ROWB + ((t + 1) % 3) * 16;
+                // tap offset = ty * rowb (scalar, folded into the buffer offset) + tx * 16 (instruction immediate)
+                constexpr int TAP = tx * 16;
+                constexpr int TYN = (t + 1) / 3;
+                constexpr int TAPN = ((t + 1) % 3) * 16;
                 const int g = g0 + t;
                 if (g > 0) {
                     // queue (old -> young): A(g+1) [B(chunk+1) if it was issued in the previous step] A(g+2)
@@ -308,7 +348,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
                 if ((t < 6 || more_chunks) && !DBG(1)) issueA(g + 3, (cph + t + 3) & 3);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!DBG(8))
-                load_half(a1, b1, (unsigned)(((cph + t) & 3) * (BM * 64)), bo_cur, std::integral_constant<int, TAP>{},
+                load_half(a1, b1, (unsigned)(((cph + t) & 3) * (BM * 64)), bo_cur + ty * rowb, std::integral_constant<int, TAP>{},
                           std::integral_constant<int, 1>{});
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");  // H0(g) landed
                 __builtin_amdgcn_sched_barrier(0);
@@ -316,7 +356,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
                 __builtin_amdgcn_sched_barrier(0);
                 if (DBG(8)) {
                 } else if (t < 8) {
-                    load_half(a0, b0, (unsigned)(((cph + t + 1) & 3) * (BM * 64)), bo_cur,
+                    load_half(a0, b0, (unsigned)(((cph + t + 1) & 3) * (BM * 64)), bo_cur + TYN * rowb,
                               std::integral_constant<int, TAPN>{}, std::integral_constant<int, 0>{});
                     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");  // H1(g) landed
                 } else if (more_chunks) {
@@ -345,6 +385,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef LDS_READ128
     } else {
+        TS(1);
+        TS(2);
         issueB(0, 0);
         issueA(0, 0);
         if (a.ksteps > 1) issueA(1, 1);
@@ -368,6 +410,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         }
     }
 
+    TS(3);
     if (DBG(32)) {  // timing ablation: no epilogue (keep the accumulators alive)
         if (acc[0][0][0] == 0x7fffffff && a.y) a.y[tid] = 1;
         return;
@@ -393,7 +436,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
     int pb_[NS], rem[NS], nl_[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-        const int nl = wn * TN + ns * 32 + lj;
+        const int nl = (ns * WNW + wn) * 32 + lj;
         nl_[ns] = nl;
         const int nn = nvalid[ns] ? n0 + nl : 0;
         const int b = nn / hw;
@@ -415,8 +458,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
             for (int grp = 0; grp < 4; ++grp) {
                 const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;
                 const int4 dz4 = *reinterpret_cast<const int4 *>(ldsPI + BM + ocl);
-                const int4 cb4 = *reinterpret_cast<const int4 *>(ldsPI + 3 * BM + ocl);
-                const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, cbv[4] = {cb4.x, cb4.y, cb4.z, cb4.w};
+                const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
                 int32_t accb[4][NS];
                 double mp[4];
 #pragma unroll
@@ -424,7 +466,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
                     mp[r] = ldsPM[2 * BM + ocl + r];
 #pragma unroll
                     for (int ns = 0; ns < NS; ++ns)  // |dz| <= 128, |sx| < 2^23 (K <= 64K): 24-bit multiply, full rate
-                        accb[r][ns] = acc[ms][ns][grp * 4 + r] + cbv[r] + __mul24(dzv[r], sx[ns]);
+                        accb[r][ns] = acc[ms][ns][grp * 4 + r] + __mul24(dzv[r], sx[ns]);
                 }
                 uint32_t packed[NS];
                 requant_group<ACT, SAT, NS>(accb, mp, a.zp_act, packed);
@@ -465,11 +507,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
     #pragma unroll
                 for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
                     const int oc = oc0 + r;
-                    const int cwv = ldsPI[ocl + r], dzv = ldsPI[BM + ocl + r], biv = ldsPI[2 * BM + ocl + r];
+                    const int dzv = ldsPI[BM + ocl + r], biv = ldsPI[2 * BM + ocl + r];
                     const double mv = ldsPM[ocl + r], sv = ldsPM[BM + ocl + r];
     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns) {
-                        const int32_t accv = acc[ms][ns][grp * 4 + r] + cwv + dzv * sx[ns];
+                        const int32_t accv = acc[ms][ns][grp * 4 + r] - biv + dzv * sx[ns];  // acc started at cw + bias
                         uint32_t u8 = 0;
                         if (oc < a.n) {
                             u8 = requant_u8(accv, biv, mv, sv, a.zp_act, a.act, a.store_mode);
@@ -488,6 +530,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         }
     }
     __syncthreads();
+    TS(4);
     if (a.y && !DBG(128)) {
         const int dwords = min(BM, a.out_cs - m0) >> 2;
         if (dwords == BM / 4) {  // common case: constant divisor
@@ -510,6 +553,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
             }
         }
     }
+    TS(5);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -520,12 +564,13 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     constexpr int HALO = (KS == 3) ? 1 : 0;
     if (a.mpad % BM) return MI355_EINVAL;
     a.mtiles = a.mpad / BM;
-    a.ntiles_n = (a.total_n + BN - 1) / BN;
+    if (a.ntiles_n < (a.total_n + BN - 1) / BN) a.ntiles_n = (a.total_n + BN - 1) / BN;  // tiles must fit BN
     // rows spanned by BN consecutive pixels: pixel rows + one pad row per image boundary crossed, + halo rows
     a.rows_cap = (BN - 2 + a.W) / a.W + 1 + (BN - 2 + a.H * a.W) / (a.H * a.W) + 2 * HALO;
     const int ndma = a.rows_cap * (RS / 16);
     if ((ndma + NW - 1) / NW > RBPT_MAX) return MI355_EINVAL;
-    size_t lds = (size_t)ra_stages<KS>() * BM * 64 + 2 * (size_t)a.rows_cap * RS * 64 + (size_t)a.rows_cap * RS * 4;
+    a.rowb = RS * 64 + 16 * (a.W & 15);
+    size_t lds = (size_t)ra_stages<KS>() * BM * 64 + 2 * (size_t)a.rows_cap * a.rowb + (size_t)a.rows_cap * RS * 4;
     const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
     if (lds_epi > lds) lds = lds_epi;
     lds = (lds + 15) & ~(size_t)15;
@@ -548,6 +593,7 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
 template <int RS, int KS>
 static int rows_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
 {
+    if (bm == 128 && bn == 384) return rows_launch_cfg<128, 384, 2, 4, RS, KS>(a, st);
     if (bm == 128 && bn == 256) return rows_launch_cfg<128, 256, 2, 4, RS, KS>(a, st);
     if (bm == 128 && bn == 128) return rows_launch_cfg<128, 128, 2, 2, RS, KS>(a, st);
     if (bm == 64 && bn == 256) return rows_launch_cfg<64, 256, 1, 4, RS, KS>(a, st);

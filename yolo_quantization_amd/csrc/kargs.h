@@ -21,6 +21,7 @@ struct ConvArgs {
     int bchunks, bpt;        // LDS B buffer size in KiB chunks; DMA instructions per wave per chunk load
     int tiles_x, tiles_y;    // PATCH mode tiling of one image
     int rows_cap;            // conv_rows: LDS rows per B buffer
+    int rowb;                // conv_rows: bytes between LDS rows (row data + bank skew)
     const int32_t *shift;    // per-channel right shift (valid when hdr->pow2)
     const double *mprime;    // M_value * shift_value
     const int32_t *cwb;      // cw + bias

@@ -290,10 +290,14 @@ void network_profile_begin(network *net, int max_steps)
     }
     net->prof_cap = max_steps;
     net->prof_used = 0;
+    net->prof_calls = 0;
+    if (net->prof_stride < 1) net->prof_stride = 1;
     if (max_steps <= 0) return;
     net->prof_ev = calloc((size_t)max_steps * (net->n + 2), sizeof(void *));
     for (int i = 0; i < max_steps * (net->n + 2); ++i) check_mi355(mi355_event_create(&net->prof_ev[i]), "event create");
 }
+
+void network_profile_set_stride(network *net, int stride) { net->prof_stride = stride < 1 ? 1 : stride; }
 
 int network_profile_read(network *net, float *ms_sum)
 {
@@ -313,7 +317,7 @@ static void run_layers(network *netp)
 {
     network net = *netp;
     void **ev = NULL;
-    if (netp->prof_ev && netp->prof_used < netp->prof_cap && !netp->use_graph)
+    if (netp->prof_ev && netp->prof_used < netp->prof_cap && !netp->use_graph && netp->prof_calls++ % netp->prof_stride == 0)
         ev = netp->prof_ev + (size_t)(netp->prof_used++) * (net.n + 2);
     if (ev) check_mi355(mi355_event_record(ev[0], net.stream), "event");
     check_mi355(mi355_nchw_to_tensor(netp->input_uint8_gpu, &netp->input_t, net.stream), "input layout");
