@@ -76,7 +76,7 @@ __device__ __forceinline__ void rows_wait_vmcnt(int n)
 // A ring depth: 3 for the plain 1x1 loop, 4 for the software-pipelined 3x3 loop (fragments of step g+1 are read
 // while the MFMAs of step g run, so A(g), A(g+1) are being read while A(g+2), A(g+3) are in flight)
 template <int KS> constexpr int ra_stages() { return KS == 3 ? 4 : 3; }
-constexpr int RBPT_MAX = 18;  // B DMA instructions per wave per chunk load (upper bound, keeps vmcnt <= 20)
+constexpr int RBPT_MAX = 8;  // B DMA instructions per wave per chunk load (one VGPR of source offset each)
 
 // global row index (over all image blocks, pad rows included) and column of valid pixel n
 __device__ __forceinline__ void row_of_pixel(int n, int H, int W, int &grow, int &x)
@@ -90,7 +90,7 @@ __device__ __forceinline__ void row_of_pixel(int n, int H, int W, int &grow, int
 }
 
 template <int BM, int BN, int WMW, int WNW, int RS, int KS>
-__global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8 && BN <= 256) ? 4 : 2) void conv_rows_i8_kernel(const ConvArgs a)
+__global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const ConvArgs a)
 {
     constexpr int NW = WMW * WNW, NT = 64 * NW;
     constexpr int TM = BM / WMW, TN = BN / WNW;
@@ -175,35 +175,48 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8 && BN <= 256) ? 4 :
         atab[ms] = ((row >> 4) << 10) + ((row & 15) << 4) + kh * 256;
     }
 
-    // ---- DMA helpers.  Every wave issues exactly APT (A) / bpt (B) instructions per load.
-    const int8_t *asrc[APT];
+    // ---- DMA helpers.  Every wave issues exactly APT (A) / bpt (B) instructions per load.  Sources are kept as
+    // "wave-uniform 64-bit base + 32-bit lane offset" so that the K loop advances them on the scalar unit: VALU
+    // instructions do not overlap the matrix pipe of their own SIMD, so the loop must issue as few as possible.
+    const int8_t *abase[APT];
     int adst[APT];
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
         const int ch = min(wave + i * NW, ACH - 1);
-        asrc[i] = a.wp + ((size_t)(mtile * ACH + ch) * a.ksteps) * 1024 + lane * 16;
+        abase[i] = a.wp + ((size_t)(mtile * ACH + ch) * a.ksteps) * 1024;
         adst[i] = ch << 10;
     }
+    const unsigned lane16 = lane * 16;
     auto issueA = [&](int g, int stage) {
         char *st = ldsA + stage * (BM * 64);
 #pragma unroll
-        for (int i = 0; i < APT; ++i) DMA16(asrc[i] + (size_t)g * 1024, st + adst[i]);
+        for (int i = 0; i < APT; ++i) DMA16(abase[i] + (size_t)g * 1024 + lane16, st + adst[i]);
     };
-    // B: DMA instruction j covers LDS bytes [j*1024, j*1024+1024) of the buffer: row = j / CPR, chunk-in-row = j % CPR.
-    // Inside a row the image is [piece][RS cells][16 B]: byte o -> piece o / PIECEB, cell (o % PIECEB) / 16.
+    // B: DMA instruction j covers 1 KiB of LDS row j / CPR (chunk-in-row j % CPR).  Inside a row the image is
+    // [piece][RS cells][16 B]: byte o -> piece o / PIECEB, cell (o % PIECEB) / 16.  The lane's source offset does not
+    // depend on the channel chunk: computed once per DMA slot (bvoff), the chunk only moves the scalar base by 64 B.
     const long cell0 = (long)a.in_lead + (long)grow_first * W1 - 1;  // global cell of LDS (row 0, cell 0)
+    unsigned bvoff[RBPT_MAX];
+#pragma unroll
+    for (int i = 0; i < RBPT_MAX; ++i) {
+        const int j = min(wave + i * NW, ndma - 1);
+        const int r = j / CPR, cj = j - r * CPR;
+        const int o = cj * 1024 + lane * 16;
+        const int p = o / PIECEB, c = (o - p * PIECEB) >> 4;
+        long f = cell0 + (long)r * W1 + c;
+        f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
+        bvoff[i] = (unsigned)(f * a.in_cs + p * 16);  // < 2^32: the host rejects tensors of 4 GiB and more
+    }
     auto issueB = [&](int chunk, int parity) {
         char *buf = ldsB + parity * bbytes;
         const int8_t *base = a.x + (size_t)chunk * 64;
-        for (int i = 0; i < bpt; ++i) {
-            const int j = min(wave + i * NW, ndma - 1);
-            const int r = j / CPR, cj = j - r * CPR;
-            const int o = cj * 1024 + lane * 16;
-            const int p = o / PIECEB, c = (o - p * PIECEB) >> 4;
-            long f = cell0 + (long)r * W1 + c;
-            f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
-            DMA16(base + f * a.in_cs + p * 16, buf + r * rowb + (cj << 10));
-        }
+#pragma unroll
+        for (int i = 0; i < RBPT_MAX; ++i)
+            if (i < bpt) {
+                const int j = min(wave + i * NW, ndma - 1);
+                const int r = j / CPR, cj = j - r * CPR;
+                DMA16(base + bvoff[i], buf + r * rowb + (cj << 10));
+            }
     };
 
     // accumulators start at the per-channel constant cw + bias (blob plane cwb), so the epilogue does not add it:
@@ -282,35 +295,65 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8 && BN <= 256) ? 4 :
         // s_waitcnt lgkmcnt(0) in front of the first MFMA after ANY ds_read, which would serialise the read of the
         // next half-set behind the current MFMAs.  We count instead: LDS returns in order, every load_half issues
         // exactly MS+NS reads, and each MFMA group is preceded by lgkmcnt(MS+NS) (the younger half-set may still fly).
+        // Fragment addresses live in registers per A ring stage and per tap row, so a K-step issues no address
+        // arithmetic at all: the tap column and the k-half are instruction immediates; once per channel chunk the A
+        // table is rotated (9 K-steps = one ring phase) and the B table moves to the other buffer.
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-        unsigned aaddr[MS], baddr[NS];
+        unsigned aaddr[RA_STAGES][MS], baddr[3][NS];
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) aaddr[ms] = lds0 + atab[ms];
+        for (int st = 0; st < RA_STAGES; ++st)
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) baddr[ns] = lds0 + RA_STAGES * BM * 64 + bbase[ns];
+            for (int ms = 0; ms < MS; ++ms) aaddr[st][ms] = lds0 + st * (BM * 64) + atab[ms];
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) baddr[ty][ns] = lds0 + RA_STAGES * BM * 64 + bbase[ns] + ty * rowb;
 #define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
-        auto load_half = [&](v4i(&af)[MS], v4i(&bf)[NS], unsigned aoff, unsigned boff, auto tap_c, auto h_c) {
+        // One k-half: the MFMAs of the half-set that has landed, with the ds_reads of the NEXT half-set (and this
+        // step's DMA issue, `hook`) threaded between them.  A wave issues in order, so a burst of 5 reads in front of
+        // 6 MFMAs leaves the matrix pipe idle while the LDS queue drains (all 8 waves leave the barrier together and
+        // the two waves of a SIMD stay in phase); interleaved, every read issues under an MFMA of the same wave, and
+        // the last read is two MFMAs old when the next half starts with s_waitcnt lgkmcnt(0).
+        // Sub-tile 0 is computed unconditionally, sub-tiles >= ns_active (wave-uniform) are skipped.
+        auto half = [&](const v4i(&ca)[MS], const v4i(&cb)[NS], v4i(&na)[MS], v4i(&nb)[NS], const unsigned(&aad)[MS],
+                        const unsigned(&bad)[NS], auto tap_c, auto h_c, bool rd, auto &&hook) {
             constexpr int TAPOFF = decltype(tap_c)::value, H = decltype(h_c)::value;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (!DBG(4)) acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[0], cb[0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            hook();
+            if (rd) {
 #pragma unroll
-            for (int ms = 0; ms < MS; ++ms) {
-                const unsigned ad = aaddr[ms] + aoff;
-                LDS_READ128(af[ms], ad, H * 512);
+                for (int ms = 0; ms < MS; ++ms) LDS_READ128(na[ms], aad[ms], H * 512);
             }
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-                const unsigned ad = baddr[ns] + boff;
-                LDS_READ128(bf[ns], ad, TAPOFF + H * 2 * PIECEB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MS > 1 && !DBG(4)) acc[MS - 1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[MS - 1], cb[0], acc[MS - 1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rd) {
+                LDS_READ128(nb[0], bad[0], TAPOFF + H * 2 * PIECEB);
+                if (NS > 1) LDS_READ128(nb[NS > 1 ? 1 : 0], bad[NS > 1 ? 1 : 0], TAPOFF + H * 2 * PIECEB);
             }
-        };
-        auto mfma_half = [&](const v4i(&af)[MS], const v4i(&bf)[NS]) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
-                if (ns < ns_active) {  // wave-uniform: sub-tiles beyond the tile's width do no work
+            for (int ns = 1; ns < NS; ++ns) {
+                if (ns < ns_active && !DBG(4)) {
 #pragma unroll
                     for (int ms = 0; ms < MS; ++ms)
-                        acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf[ns], acc[ms][ns], 0, 0, 0);
+                        acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[ms], cb[ns], acc[ms][ns], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ns + 1 < NS && rd) LDS_READ128(nb[ns + 1 < NS ? ns + 1 : 0], bad[ns + 1 < NS ? ns + 1 : 0], TAPOFF + H * 2 * PIECEB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
+        auto load_half = [&](v4i(&af)[MS], v4i(&bf)[NS], const unsigned(&aad)[MS], const unsigned(&bad)[NS]) {
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) LDS_READ128(af[ms], aad[ms], 0);
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) LDS_READ128(bf[ns], bad[ns], 0);
+        };
+        auto nohook = [] {};
         // prologue: B(0), A(0), A(1), A(2); retire all but A(2); first half-set
         TS(1);
         issueB(0, 0);
@@ -321,19 +364,18 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8 && BN <= 256) ? 4 :
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         TS(2);
-        load_half(a0, b0, 0u, 0u, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        load_half(a0, b0, aaddr[0], baddr[0]);
         for (int chunk = 0; chunk < a.nchunks; ++chunk) {
             const bool more_chunks = chunk + 1 < a.nchunks;
             const char *Bt = ldsB + (chunk & 1) * bbytes;
-            const unsigned bo_cur = (chunk & 1) * bbytes, bo_nxt = ((chunk + 1) & 1) * bbytes;
             const int g0 = chunk * 9;
             const int cph = chunk & 3;  // ring phase of tap 0: (9*chunk) % 4 == chunk % 4
             auto step = [&](auto t_c) {
                 constexpr int t = decltype(t_c)::value;
                 constexpr int ty = t / 3, tx = t % 3;
-                // tap offset = ty * rowb (scalar, folded into the buffer offset) + tx * 16 (instruction immediate)
+                // tap = row table entry ty + the immediate tx * 16; aaddr[s] is ring stage (cph + s) & 3
                 constexpr int TAP = tx * 16;
-                constexpr int TYN = (t + 1) / 3;
+                constexpr int TYN = ((t + 1) % 9) / 3;
                 constexpr int TAPN = ((t + 1) % 3) * 16;
                 const int g = g0 + t;
                 if (g > 0) {
@@ -344,31 +386,34 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8 && BN <= 256) ? 4 :
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (!DBG(2)) __builtin_amdgcn_s_barrier();
                 }
-                if (t == 0 && more_chunks && !DBG(1)) issueB(chunk + 1, (chunk + 1) & 1);
-                if ((t < 6 || more_chunks) && !DBG(1)) issueA(g + 3, (cph + t + 3) & 3);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!DBG(8))
-                load_half(a1, b1, (unsigned)(((cph + t) & 3) * (BM * 64)), bo_cur + ty * rowb, std::integral_constant<int, TAP>{},
-                          std::integral_constant<int, 1>{});
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");  // H0(g) landed
-                __builtin_amdgcn_sched_barrier(0);
-                if (!DBG(4)) mfma_half(a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (DBG(8)) {
-                } else if (t < 8) {
-                    load_half(a0, b0, (unsigned)(((cph + t + 1) & 3) * (BM * 64)), bo_cur + TYN * rowb,
-                              std::integral_constant<int, TAPN>{}, std::integral_constant<int, 0>{});
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");  // H1(g) landed
-                } else if (more_chunks) {
-                    load_half(a0, b0, (unsigned)(((cph + 9) & 3) * (BM * 64)), bo_nxt, std::integral_constant<int, 0>{},
-                              std::integral_constant<int, 0>{});
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");
+                // first k-half: MFMA H0(g) | read H1(g) | DMA A(g+3) [+ B(chunk+1) on the chunk's first step]
+                half(a0, b0, a1, b1, aaddr[t & 3], baddr[ty], std::integral_constant<int, TAP>{}, std::integral_constant<int, 1>{},
+                     !DBG(8), [&] {
+                         if (t == 0 && more_chunks && !DBG(1)) issueB(chunk + 1, (chunk + 1) & 1);
+                         if ((t < 6 || more_chunks) && !DBG(1)) issueA(g + 3, (cph + t + 3) & 3);
+                     });
+                // second k-half: MFMA H1(g) | read H0(g+1)
+                if (t < 8) {
+                    half(a1, b1, a0, b0, aaddr[(t + 1) & 3], baddr[TYN], std::integral_constant<int, TAPN>{},
+                         std::integral_constant<int, 0>{}, !DBG(8), nohook);
                 } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (more_chunks) {
+                        // next chunk: 9 K-steps advance the A ring by one phase; B fragments come from the other buffer
+                        const int bdelta = (chunk & 1) ? -bbytes : bbytes;
+#pragma unroll
+                        for (int ms = 0; ms < MS; ++ms) {
+                            const unsigned a0s = aaddr[0][ms];
+                            aaddr[0][ms] = aaddr[1][ms]; aaddr[1][ms] = aaddr[2][ms]; aaddr[2][ms] = aaddr[3][ms];
+                            aaddr[3][ms] = a0s;
+                        }
+#pragma unroll
+                        for (int yy = 0; yy < 3; ++yy)
+#pragma unroll
+                            for (int ns = 0; ns < NS; ++ns) baddr[yy][ns] += bdelta;
+                    }
+                    half(a1, b1, a0, b0, aaddr[0], baddr[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{},
+                         more_chunks && !DBG(8), nohook);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!DBG(4)) mfma_half(a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
                 if (t == 1 && !DBG(16)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // our reads are invisible to hipcc's counters
                     cell_sums(Bt);
@@ -569,6 +614,7 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     a.rows_cap = (BN - 2 + a.W) / a.W + 1 + (BN - 2 + a.H * a.W) / (a.H * a.W) + 2 * HALO;
     const int ndma = a.rows_cap * (RS / 16);
     if ((ndma + NW - 1) / NW > RBPT_MAX) return MI355_EINVAL;
+    if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     a.rowb = RS * 64 + 16 * (a.W & 15);
     size_t lds = (size_t)ra_stages<KS>() * BM * 64 + 2 * (size_t)a.rows_cap * a.rowb + (size_t)a.rows_cap * RS * 4;
     const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
