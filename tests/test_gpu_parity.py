@@ -105,7 +105,7 @@ def test_conv_every_tile_config(bm, bn, nt):
     """Force each compiled tile configuration (and, for the row-image kernel, uneven N-tile counts: tiles narrower
     than their capacity leave whole 32-column sub-tiles idle) on a shape it supports."""
     n = {128: 256, 64: 64, 32: 32}[bm]
-    B, c, H, W, k = 2, 64, 20, 19, 3
+    B, c, H, W, k = 2, 64, 20, 26, 3   # W >= 24: the widest row-image tiles refuse narrower maps
     bm |= nt << 16
     rng = np.random.default_rng((bm & 0xFFFF) * 7 + bn + nt)
     x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)

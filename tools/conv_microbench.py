@@ -72,11 +72,13 @@ if __name__ == "__main__":
     ap.add_argument("--tile", type=int, nargs=2); ap.add_argument("--mode", choices=["flat", "patch"])
     ap.add_argument("--net", action="store_true"); ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--shift", type=int, default=13); ap.add_argument("--plan", action="store_true")
-    ap.add_argument("--nt", type=int, default=0); ap.add_argument("--timeline", action="store_true")
+    ap.add_argument("--nt", type=int, default=0); ap.add_argument("--dbg", type=int, default=0, help="mi355_debug_flags value (512 = no chunk rotation)"); ap.add_argument("--timeline", action="store_true"); ap.add_argument("--waveprof", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="timing ablation of the K loop (results are wrong)")
     a = ap.parse_args()
     SHIFT = a.shift
     binding.init(0)
+    if a.dbg:
+        binding.shim().mi355_debug_flags(a.dbg)
     if a.ablate:
         S = binding.shim()
         for flags, name in [(0, "full"), (1, "no-dma"), (2, "no-barrier"), (4, "no-mfma"), (16, "no-cellsum"), (3, "no-dma,no-barrier"), (5, "no-dma,no-mfma"), (7, "only-lds-reads"), (15, "nothing-in-loop"), (32, "no-epilogue"), (47, "empty-kernel"), (63, "empty-kernel-no-cellsum"), (11, "only-mfma"), (9, "mfma+barrier"), (3, "lds+mfma"), (15 + 64, "epi-no-requant"), (15 + 128, "epi-no-copyout"), (15 + 64 + 128, "epi-neither")]:
@@ -106,6 +108,26 @@ if __name__ == "__main__":
         late = order[256:] if nb > 256 else []
         if len(late):
             print(f"  second-round blocks: {len(late)}, start p50 {np.median(t[0][late]) - t0:.2f} us")
+    elif a.waveprof:  # per-wave stall profile of the 3x3 K loop (needs the -DMI355_ABLATE build)
+        S = binding.shim()
+        S.mi355_debug_flags(256 | a.dbg)
+        r = run(a.c, a.n, a.hw, a.k, a.batch, 1, tuple(a.tile) if a.tile else None, a.mode, nt=a.nt)
+        S.mi355_stream_sync(None)
+        S.mi355_debug_flags(0)
+        wp = np.zeros((4096, 8, 5), np.int64)
+        S.mi355_debug_read_wp.argtypes = [C.c_void_p]
+        assert S.mi355_debug_read_wp(wp.ctypes.data) == 0
+        nb = int((wp.sum(axis=(1, 2)) > 0).sum())
+        w = wp[:nb].astype(np.float64)
+        print(json.dumps(r))
+        names = ["drain LDS reads of previous step", "s_waitcnt vmcnt (DMA landed)", "s_barrier", "k-half 0 (6 MFMA + DMA issue + 5 reads)", "k-half 1 (6 MFMA + 5 reads)"]
+        tot = w.sum(axis=2)
+        print(f"blocks {nb}; shader-clock ticks per wave in the K loop: p50 {np.median(tot):.0f}")
+        for k, nm in enumerate(names):
+            print(f"  {nm:44s} {100 * w[:, :, k].sum() / tot.sum():5.1f} %   per wave p50 {np.median(w[:, :, k]):9.0f}")
+        print("  per wave index (mean ticks):", [int(v) for v in w.mean(axis=0).sum(axis=1)])
+        for k in range(5):
+            print(f"    phase {k} by wave:", [int(v) for v in w[:, :, k].mean(axis=0)])
     elif a.plan:  # rows-kernel tile plan sweep: capacity x tile count, per conv shape of the net
         for c, n, hw, k in NET:
             if c % 64:

@@ -36,47 +36,58 @@ extern "C" int mi355_debug_read_ts(long long *host)
 {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rows_ts), sizeof(long long) * TS_PHASES * TS_BLOCKS) == hipSuccess ? 0 : -5;
 }
+// in-loop stall profile (debug bit 256): per wave, shader-clock sums of the five phases of a K-step
+#define WP_PHASES 5
+__device__ long long g_rows_wp[TS_BLOCKS][8][WP_PHASES];
+#define WP_DECL long long wp_acc[WP_PHASES] = {0, 0, 0, 0, 0}; long long wp_t = 0
+#define WP_START()                                                   \
+    do {                                                             \
+        if (DBG(256)) { wp_t = __builtin_readcyclecounter(); }       \
+    } while (0)
+#define WP_MARK(k)                                                   \
+    do {                                                             \
+        if (DBG(256)) {                                              \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+            const long long wp_n = __builtin_readcyclecounter();     \
+            wp_acc[k] += wp_n - wp_t;                                \
+            wp_t = wp_n;                                             \
+        }                                                            \
+    } while (0)
+#define WP_FLUSH()                                                                                   \
+    do {                                                                                             \
+        if (DBG(256) && lane == 0 && blockIdx.x < TS_BLOCKS && wave < 8)                             \
+            for (int k = 0; k < WP_PHASES; ++k) g_rows_wp[blockIdx.x][wave][k] = wp_acc[k];          \
+    } while (0)
+extern "C" int mi355_debug_read_wp(long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rows_wp), sizeof(long long) * TS_BLOCKS * 8 * WP_PHASES) == hipSuccess ? 0 : -5;
+}
 #else
 #define DBG(bit) (false)
 #define TS(k) do { } while (0)
+#define WP_DECL do { } while (0)
+#define WP_START() do { } while (0)
+#define WP_MARK(k) do { } while (0)
+#define WP_FLUSH() do { } while (0)
 #endif
 
 #define DMA16(gsrc, ldst)                                                                               \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),           \
                                      (__attribute__((address_space(3))) void *)(ldst), 16, 0, 0)
 
-__device__ __forceinline__ void rows_wait_vmcnt(int n)
+// A ring depth: 3 for the plain 1x1 loop, 6 for the software-pipelined 3x3 loop (fragments of step g+1 are read
+// while the MFMAs of step g run, so A(g), A(g+1) are being read while A(g+2) .. A(g+5) are in flight)
+template <int KS> constexpr int ra_stages() { return KS == 3 ? 6 : 3; }
+// B DMA slots per wave per channel-chunk load: a compile-time constant per configuration (one VGPR of source offset
+// each, issued unconditionally -- slots past a tile's last LDS row repeat its last one), so that every vmcnt wait of
+// the K loop is an immediate.  Sized for the rows a BN-pixel tile spans when the map is at least 3/4 as wide as the
+// row image (W >= 12 / 24 / 48 for RS = 16 / 32 / 64); narrower maps are refused by the launcher (other tile or kernel).
+constexpr int rows_nb_slots(int BN, int RS, int NW, int KS)
 {
-    switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
-    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
-    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
+    const int wmin = RS * 3 / 4, halo = KS == 3 ? 1 : 0;
+    const int rows = (BN - 2 + wmin) / wmin + 1 + (BN - 2 + wmin * wmin) / (wmin * wmin) + 2 * halo;
+    return (rows * (RS / 16) + NW - 1) / NW;
 }
-
-// A ring depth: 3 for the plain 1x1 loop, 4 for the software-pipelined 3x3 loop (fragments of step g+1 are read
-// while the MFMAs of step g run, so A(g), A(g+1) are being read while A(g+2), A(g+3) are in flight)
-template <int KS> constexpr int ra_stages() { return KS == 3 ? 4 : 3; }
-constexpr int RBPT_MAX = 8;  // B DMA instructions per wave per chunk load (one VGPR of source offset each)
 
 // global row index (over all image blocks, pad rows included) and column of valid pixel n
 __device__ __forceinline__ void row_of_pixel(int n, int H, int W, int &grow, int &x)
@@ -102,6 +113,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     constexpr int CPR = RS / 16;        // 1 KiB DMA chunks per row
     constexpr int OSTR = BM + 4;
     constexpr int RA_STAGES = ra_stages<KS>();
+    constexpr int NBS = rows_nb_slots(BN, RS, NW, KS);  // B DMA slots per wave per chunk
+    constexpr int SPS = (NBS + 3) / 4;                  // ... issued per K-step over a chunk's first four steps (3x3 loop)
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -148,7 +161,6 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     const int grow_first = gr0 - HALO;
     const int nrows = gr1 - gr0 + 1 + 2 * HALO;   // <= a.rows_cap (host guarantees)
     const int ndma = nrows * CPR;                 // B DMA instructions per chunk load for the whole workgroup
-    const int bpt = (ndma + NW - 1) / NW;         // per wave (uniform; surplus slots repeat the last one)
 
     // ---- per-lane B base: LDS byte offset of (its pixel's row - HALO, its column - HALO) for k-half kh
     int bbase[NS];
@@ -164,10 +176,6 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         pcol[ns] = x + 1 - HALO;            // LDS cell of tap dx = 0 (left tap); cell 0 of a row is x = -1
         bbase[ns] = prow[ns] * rowb + pcol[ns] * 16 + kh * PIECEB;
     }
-    // number of this wave's sub-tiles that hold at least one pixel of the tile (the others skip their MFMAs)
-    int ns_active = 0;
-#pragma unroll
-    for (int ns = 0; ns < NS; ++ns) ns_active += (n0 + (ns * WNW + wn) * 32 < n_end) ? 1 : 0;
     int atab[MS];
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
@@ -175,30 +183,50 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         atab[ms] = ((row >> 4) << 10) + ((row & 15) << 4) + kh * 256;
     }
 
-    // ---- DMA helpers.  Every wave issues exactly APT (A) / bpt (B) instructions per load.  Sources are kept as
-    // "wave-uniform 64-bit base + 32-bit lane offset" so that the K loop advances them on the scalar unit: VALU
-    // instructions do not overlap the matrix pipe of their own SIMD, so the loop must issue as few as possible.
-    const int8_t *abase[APT];
-    int adst[APT];
+    // ---- DMA helpers.  Every wave issues exactly APT (A) / NBS (B) instructions per load.  A K-step is bounded by
+    // the length of each wave's own instruction stream as much as by the matrix pipe (the in-order wave issues ~50
+    // scalar instructions and a dozen branches per step if the addressing is left to the compiler), so the DMA is
+    // written in its "scalar 64-bit base + 32-bit lane offset" form by hand: the lane offsets are loop invariant
+    // registers and everything that moves lives on the scalar unit.  M0 carries the LDS destination; no other code in
+    // this kernel uses M0 (all LDS-DMA goes through this macro), so it is not declared as clobbered.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+#define DMA_S(ldsdst_u32, sbase_ptr, voff_u32)                                                                   \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst_u32), "v"(voff_u32), \
+                 "s"(sbase_ptr)                                                                                  \
+                 : "memory")
+    // Channel-chunk rotation: workgroup `ntile` walks the chunks in the order rot, rot+1, .., nchunks-1, 0, .., rot-1
+    // (exact int32 accumulation does not care).  All workgroups run in lockstep, and a chunk is the same 64 bytes of
+    // every in_cs-byte cell: without the rotation the whole chip reads one quarter of the tensor's cache lines -- a few
+    // L2 channels -- at any one time, and every workgroup of an XCD wants the same new weight slab in the same instant.
+    const int rot = a.debug & 512 ? 0 : ntile % a.nchunks;
+    const int kwrap = a.ksteps / a.nchunks * a.nchunks;  // = ksteps (taps * chunks)
+    int aleft = kwrap - rot * (a.ksteps / a.nchunks);    // slabs until the walk wraps to slab 0
+    const int8_t *aptr[APT];  // next K-step slab of this wave's A chunk(s) to fetch
+    unsigned adst[APT];
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
         const int ch = min(wave + i * NW, ACH - 1);
-        abase[i] = a.wp + ((size_t)(mtile * ACH + ch) * a.ksteps) * 1024;
-        adst[i] = ch << 10;
+        aptr[i] = a.wp + ((size_t)(mtile * ACH + ch) * a.ksteps + (size_t)rot * (a.ksteps / a.nchunks)) * 1024;
+        adst[i] = lds0 + (ch << 10);
     }
     const unsigned lane16 = lane * 16;
-    auto issueA = [&](int g, int stage) {
-        char *st = ldsA + stage * (BM * 64);
+    auto issueA_next = [&](unsigned stage_off) {  // fetch the next slab into the ring stage at byte offset stage_off
+        const bool wrap = --aleft == 0;
 #pragma unroll
-        for (int i = 0; i < APT; ++i) DMA16(abase[i] + (size_t)g * 1024 + lane16, st + adst[i]);
+        for (int i = 0; i < APT; ++i) {
+            DMA_S(adst[i] + stage_off, aptr[i], lane16);
+            aptr[i] += wrap ? 1024 - (long)kwrap * 1024 : 1024;
+        }
+        if (wrap) aleft = kwrap;
     };
     // B: DMA instruction j covers 1 KiB of LDS row j / CPR (chunk-in-row j % CPR).  Inside a row the image is
-    // [piece][RS cells][16 B]: byte o -> piece o / PIECEB, cell (o % PIECEB) / 16.  The lane's source offset does not
-    // depend on the channel chunk: computed once per DMA slot (bvoff), the chunk only moves the scalar base by 64 B.
+    // [piece][RS cells][16 B]: byte o -> piece o / PIECEB, cell (o % PIECEB) / 16.  Neither the lane's source offset
+    // nor the LDS destination depends on the channel chunk: both are computed once per DMA slot, the chunk only moves
+    // the scalar base by 64 B and the buffer parity.
     const long cell0 = (long)a.in_lead + (long)grow_first * W1 - 1;  // global cell of LDS (row 0, cell 0)
-    unsigned bvoff[RBPT_MAX];
+    unsigned bvoff[NBS], bdst[NBS];
 #pragma unroll
-    for (int i = 0; i < RBPT_MAX; ++i) {
+    for (int i = 0; i < NBS; ++i) {
         const int j = min(wave + i * NW, ndma - 1);
         const int r = j / CPR, cj = j - r * CPR;
         const int o = cj * 1024 + lane * 16;
@@ -206,18 +234,21 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         long f = cell0 + (long)r * W1 + c;
         f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
         bvoff[i] = (unsigned)(f * a.in_cs + p * 16);  // < 2^32: the host rejects tensors of 4 GiB and more
+        bdst[i] = lds0 + RA_STAGES * BM * 64 + r * rowb + (cj << 10);
     }
-    auto issueB = [&](int chunk, int parity) {
-        char *buf = ldsB + parity * bbytes;
-        const int8_t *base = a.x + (size_t)chunk * 64;
+    auto issueB_slots = [&](int chunk, auto lo_c, auto hi_c) {  // slots [LO, HI) of channel chunk `chunk`
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        const unsigned boff = (chunk & 1) * bbytes;
+        int phys = chunk + rot;  // rotated walk, see above
+        if (phys >= a.nchunks) phys -= a.nchunks;
+        const int8_t *base = a.x + (size_t)phys * 64;
 #pragma unroll
-        for (int i = 0; i < RBPT_MAX; ++i)
-            if (i < bpt) {
-                const int j = min(wave + i * NW, ndma - 1);
-                const int r = j / CPR, cj = j - r * CPR;
-                DMA16(base + bvoff[i], buf + r * rowb + (cj << 10));
-            }
+        for (int i = LO; i < HI; ++i) {
+            const unsigned d = bdst[i] + boff, v = bvoff[i];  // locals: asm operands may not name captured arrays
+            DMA_S(d, base, v);
+        }
     };
+    auto issueB = [&](int chunk) { issueB_slots(chunk, std::integral_constant<int, 0>{}, std::integral_constant<int, NBS>{}); };
 
     // accumulators start at the per-channel constant cw + bias (blob plane cwb), so the epilogue does not add it:
     // register grp*4+r of a 32x32 tile holds channel row 8*grp + 4*kh + r (parameter planes are padded to mpad)
@@ -256,13 +287,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const v4i *>(A + atab[ms] + h * 512);
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
-                if (ns < ns_active) {
-                    const v4i bf = *reinterpret_cast<const v4i *>(Bt + bbase[ns] + tapoff + h * 2 * PIECEB);
+            for (int ns = 0; ns < NS; ++ns) {
+                const v4i bf = *reinterpret_cast<const v4i *>(Bt + bbase[ns] + tapoff + h * 2 * PIECEB);
 #pragma unroll
-                    for (int ms = 0; ms < MS; ++ms)
-                        acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
-                }
+                for (int ms = 0; ms < MS; ++ms)
+                    acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
+            }
         }
     };
     // per channel chunk: every thread reduces cells of the freshly landed B buffer into S
@@ -285,40 +315,46 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     };
 
     if constexpr (KS == 3) {
-        // ---- software-pipelined 3x3 loop.  Fragment registers are two half-sets (k-half 0 / k-half 1 of a K-step):
-        //        step g:  wait A(g+1) landed; s_barrier; issue DMA A(g+3) [B(chunk+1)]
-        //                 ds_read H1(g)      ||  MFMA H0(g)      (H0(g) was read during step g-1)
-        //                 ds_read H0(g+1)    ||  MFMA H1(g)
-        //      so every LDS read is in flight under 4 MFMAs (128 matrix-pipe cycles) of the same wave.
-        v4i a0[MS], b0[NS], a1[MS], b1[NS];
+        // ---- software-pipelined 3x3 loop.  R = 6 A ring stages, three fragment register sets (one k-half each):
+        //        step g:  wait A(g+1) landed; s_barrier; issue DMA A(g+5) [B(chunk+1) on a chunk's first step]
+        //                 MFMA H0(g)  ||  ds_read H0(g+1)  -> the set H1(g-1) vacated
+        //                 MFMA H1(g)  ||  ds_read H1(g+1)  -> the set H0(g) vacated
+        //      A fragment set is read one whole K-step before its MFMAs, and a DMA is issued four steps (~2 us) before
+        //      its barrier: the in-loop stall profile (tools/conv_microbench.py --waveprof) showed the previous
+        //      two-set / four-stage loop waiting 8% of its time on vmcnt and ~15% on lgkmcnt.
+        constexpr int R = RA_STAGES;
+        static_assert(R == 6, "the table rotation below assumes 9 mod R == 3");
+        v4i fa[3][MS], fb[3][NS];
         // Fragment reads are issued as inline asm so that hipcc does not account for them: its own bookkeeping puts an
-        // s_waitcnt lgkmcnt(0) in front of the first MFMA after ANY ds_read, which would serialise the read of the
-        // next half-set behind the current MFMAs.  We count instead: LDS returns in order, every load_half issues
-        // exactly MS+NS reads, and each MFMA group is preceded by lgkmcnt(MS+NS) (the younger half-set may still fly).
+        // s_waitcnt lgkmcnt(0) in front of the first MFMA after ANY ds_read.  We count instead: LDS returns in order,
+        // every k-half issues exactly MS+NS reads, and a k-half starts with lgkmcnt(MS+NS) (the set read during the
+        // previous k-half may still be in flight, the one before has landed).
         // Fragment addresses live in registers per A ring stage and per tap row, so a K-step issues no address
         // arithmetic at all: the tap column and the k-half are instruction immediates; once per channel chunk the A
-        // table is rotated (9 K-steps = one ring phase) and the B table moves to the other buffer.
-        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-        unsigned aaddr[RA_STAGES][MS], baddr[3][NS];
+        // table is rotated (9 K-steps = ring phase + 3) and the B table moves to the other buffer.
+        unsigned aaddr[R][MS], baddr[3][NS];
 #pragma unroll
-        for (int st = 0; st < RA_STAGES; ++st)
+        for (int st = 0; st < R; ++st)
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) aaddr[st][ms] = lds0 + st * (BM * 64) + atab[ms];
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) baddr[ty][ns] = lds0 + RA_STAGES * BM * 64 + bbase[ns] + ty * rowb;
+            for (int ns = 0; ns < NS; ++ns) baddr[ty][ns] = lds0 + R * BM * 64 + bbase[ns] + ty * rowb;
 #define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
-        // One k-half: the MFMAs of the half-set that has landed, with the ds_reads of the NEXT half-set (and this
-        // step's DMA issue, `hook`) threaded between them.  A wave issues in order, so a burst of 5 reads in front of
-        // 6 MFMAs leaves the matrix pipe idle while the LDS queue drains (all 8 waves leave the barrier together and
-        // the two waves of a SIMD stay in phase); interleaved, every read issues under an MFMA of the same wave, and
-        // the last read is two MFMAs old when the next half starts with s_waitcnt lgkmcnt(0).
-        // Sub-tile 0 is computed unconditionally, sub-tiles >= ns_active (wave-uniform) are skipped.
+        // One k-half: the MFMAs of the set that has landed, with the ds_reads of a later set (and this step's DMA
+        // issue, `hook`) threaded between them.  A wave issues in order, so a burst of reads in front of the MFMAs
+        // leaves the matrix pipe idle while the LDS queue drains (all 8 waves leave the barrier together and the two
+        // waves of a SIMD stay in phase); interleaved, every read issues under an MFMA of the same wave.
+        // Every sub-tile is computed, also the ones past a narrow tile's last pixel (their results are never stored):
+        // skipping them cost two branches per k-half in every wave and only ever relieved waves off the critical path.
         auto half = [&](const v4i(&ca)[MS], const v4i(&cb)[NS], v4i(&na)[MS], v4i(&nb)[NS], const unsigned(&aad)[MS],
-                        const unsigned(&bad)[NS], auto tap_c, auto h_c, bool rd, auto &&hook) {
+                        const unsigned(&bad)[NS], auto tap_c, auto h_c, auto rd_c, auto prev_rd_c, auto &&hook) {
             constexpr int TAPOFF = decltype(tap_c)::value, H = decltype(h_c)::value;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr bool RD = decltype(rd_c)::value, PREV_RD = decltype(prev_rd_c)::value;
+            const bool rd = RD && !DBG(8);
+            if (PREV_RD) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (!DBG(4)) acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[0], cb[0], acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -337,7 +373,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ns = 1; ns < NS; ++ns) {
-                if (ns < ns_active && !DBG(4)) {
+                if (!DBG(4)) {
 #pragma unroll
                     for (int ms = 0; ms < MS; ++ms)
                         acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[ms], cb[ns], acc[ms][ns], 0, 0, 0);
@@ -347,73 +383,89 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        auto load_half = [&](v4i(&af)[MS], v4i(&bf)[NS], const unsigned(&aad)[MS], const unsigned(&bad)[NS]) {
-#pragma unroll
-            for (int ms = 0; ms < MS; ++ms) LDS_READ128(af[ms], aad[ms], 0);
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) LDS_READ128(bf[ns], bad[ns], 0);
-        };
         auto nohook = [] {};
-        // prologue: B(0), A(0), A(1), A(2); retire all but A(2); first half-set
+        using std::integral_constant;
+        using std::true_type;
+        using std::false_type;
+        // prologue: B(0), A(0..4) (ksteps >= 9); A(0), A(1) (and B(0), older) landed; both k-halves of step 0 on their way
         TS(1);
-        issueB(0, 0);
-        issueA(0, 0);
-        if (a.ksteps > 1) issueA(1, 1);
-        if (a.ksteps > 2) issueA(2, 2);
-        if (a.ksteps > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issueB(0);
+#pragma unroll
+        for (int st = 0; st < R - 1; ++st) issueA_next(st * (BM * 64));
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * APT) : "memory");
         __builtin_amdgcn_s_barrier();
         TS(2);
-        load_half(a0, b0, aaddr[0], baddr[0]);
-        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-            const bool more_chunks = chunk + 1 < a.nchunks;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) LDS_READ128(fa[0][ms], aaddr[0][ms], 0);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) LDS_READ128(fb[0][ns], baddr[0][ns], 0);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) LDS_READ128(fa[1][ms], aaddr[0][ms], 512);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) LDS_READ128(fb[1][ns], baddr[0][ns], 2 * PIECEB);
+        WP_DECL;
+        WP_START();
+        // One channel chunk = 9 K-steps, fully unrolled.  LAST selects the variant for the final chunk; in both variants
+        // every "does that slab / chunk still exist" question is answered at compile time, so the steady state carries
+        // no bookkeeping branches (the previous single-variant loop spent ~50 scalar instructions and 13 branches per step).
+        auto chunk_body = [&](auto last_c, int chunk) {
+            constexpr bool LAST = decltype(last_c)::value;
             const char *Bt = ldsB + (chunk & 1) * bbytes;
-            const int g0 = chunk * 9;
-            const int cph = chunk & 3;  // ring phase of tap 0: (9*chunk) % 4 == chunk % 4
+            const bool odd = chunk & 1;  // ring stage of tap 0 is (9 * chunk) % 6 = 3 * odd
             auto step = [&](auto t_c) {
                 constexpr int t = decltype(t_c)::value;
-                constexpr int ty = t / 3, tx = t % 3;
-                // tap = row table entry ty + the immediate tx * 16; aaddr[s] is ring stage (cph + s) & 3
-                constexpr int TAP = tx * 16;
+                // fragments read in this step belong to step t+1: tap row table entry TYN + the immediate TAPN, A table
+                // entry SN (aaddr[s] is ring stage (3 * odd + s) % 6); on the chunk's last step they belong to tap 0 of
+                // the next chunk, read through the tables rotated for it
                 constexpr int TYN = ((t + 1) % 9) / 3;
                 constexpr int TAPN = ((t + 1) % 3) * 16;
-                const int g = g0 + t;
-                if (g > 0) {
-                    // queue (old -> young): A(g+1) [B(chunk+1) if it was issued in the previous step] A(g+2)
-                    const bool a2 = (t < 7) || more_chunks;  // A(g+2) exists
-                    if (t == 1 && more_chunks) rows_wait_vmcnt(APT + bpt);
-                    else if (a2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (!DBG(2)) __builtin_amdgcn_s_barrier();
-                }
-                // first k-half: MFMA H0(g) | read H1(g) | DMA A(g+3) [+ B(chunk+1) on the chunk's first step]
-                half(a0, b0, a1, b1, aaddr[t & 3], baddr[ty], std::integral_constant<int, TAP>{}, std::integral_constant<int, 1>{},
-                     !DBG(8), [&] {
-                         if (t == 0 && more_chunks && !DBG(1)) issueB(chunk + 1, (chunk + 1) & 1);
-                         if ((t < 6 || more_chunks) && !DBG(1)) issueA(g + 3, (cph + t + 3) & 3);
-                     });
-                // second k-half: MFMA H1(g) | read H0(g+1)
-                if (t < 8) {
-                    half(a1, b1, a0, b0, aaddr[(t + 1) & 3], baddr[TYN], std::integral_constant<int, TAPN>{},
-                         std::integral_constant<int, 0>{}, !DBG(8), nohook);
-                } else {
-                    if (more_chunks) {
-                        // next chunk: 9 K-steps advance the A ring by one phase; B fragments come from the other buffer
-                        const int bdelta = (chunk & 1) ? -bbytes : bbytes;
+                constexpr int SN = (t == 8) ? 0 : (t + 1) % R;
+                constexpr int C0 = (2 * t) % 3, C1 = (2 * t + 1) % 3, N0 = (2 * t + 2) % 3, N1 = (2 * t + 3) % 3;
+                constexpr bool RD = (t < 8) || !LAST;            // there is a step t+1 to read fragments for
+                constexpr bool ISSUE_A = !LAST || (t + R - 1 < 9);  // slab g+5 exists
+                // DMA queue when this step waits for A(g+1), issued four steps ago as the last DMA of its step: younger
+                // than it are the DMAs of the three steps in between -- APT A slabs per step while slab s+5 exists, and the
+                // B slots of the next chunk on a chunk's first four steps (steps < 0 are the previous chunk's steps 6..8;
+                // for chunk 0 the prologue issued the same DMAs in the same order)
+                constexpr auto n_b = [](int st) { return (LAST || st < 0 || st >= 4) ? 0 : ((st + 1) * SPS < NBS ? (st + 1) * SPS : NBS) - (st * SPS < NBS ? st * SPS : NBS); };
+                constexpr auto n_a = [](int st) { return (st < 0 || !LAST || st + R - 1 < 9) ? APT : 0; };
+                constexpr int YOUNG = n_a(t - 3) + n_b(t - 3) + n_a(t - 2) + n_b(t - 2) + n_a(t - 1) + n_b(t - 1);
+                constexpr int BLO = t * SPS < NBS ? t * SPS : NBS, BHI = (t + 1) * SPS < NBS ? (t + 1) * SPS : NBS;
+                if (t == 8 && !LAST) {
+                    const int bdelta = odd ? -bbytes : bbytes;
+#pragma unroll
+                    for (int st = 0; st < 3; ++st)
 #pragma unroll
                         for (int ms = 0; ms < MS; ++ms) {
-                            const unsigned a0s = aaddr[0][ms];
-                            aaddr[0][ms] = aaddr[1][ms]; aaddr[1][ms] = aaddr[2][ms]; aaddr[2][ms] = aaddr[3][ms];
-                            aaddr[3][ms] = a0s;
+                            const unsigned sw = aaddr[st][ms];
+                            aaddr[st][ms] = aaddr[st + 3][ms];
+                            aaddr[st + 3][ms] = sw;
                         }
 #pragma unroll
-                        for (int yy = 0; yy < 3; ++yy)
+                    for (int yy = 0; yy < 3; ++yy)
 #pragma unroll
-                            for (int ns = 0; ns < NS; ++ns) baddr[yy][ns] += bdelta;
-                    }
-                    half(a1, b1, a0, b0, aaddr[0], baddr[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{},
-                         more_chunks && !DBG(8), nohook);
+                        for (int ns = 0; ns < NS; ++ns) baddr[yy][ns] += bdelta;
                 }
+                WP_MARK(0);  // LDS reads of the previous step drained
+                if (t > 0 || chunk > 0) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");
+                    WP_MARK(1);  // DMA wait
+                    if (!DBG(2)) __builtin_amdgcn_s_barrier();
+                    WP_MARK(2);  // barrier
+                }
+                half(fa[C0], fb[C0], fa[N0], fb[N0], aaddr[SN], baddr[TYN], integral_constant<int, TAPN>{},
+                     integral_constant<int, 0>{}, integral_constant<bool, RD>{}, true_type{}, [&] {
+                         if (!LAST && t < 4 && !DBG(1))
+                             issueB_slots(chunk + 1, integral_constant<int, BLO>{}, integral_constant<int, BHI>{});
+                         if (ISSUE_A && !DBG(1)) {  // slab g+5 -> ring stage (3 * odd + t + 5) % 6
+                             constexpr unsigned E = ((t + R - 1) % R) * (BM * 64), O = ((t + R - 1 + 3) % R) * (BM * 64);
+                             issueA_next(odd ? O : E);
+                         }
+                     });
+                WP_MARK(3);  // first k-half
+                half(fa[C1], fb[C1], fa[N1], fb[N1], aaddr[SN], baddr[TYN], integral_constant<int, TAPN>{},
+                     integral_constant<int, 1>{}, integral_constant<bool, RD>{}, integral_constant<bool, RD>{}, nohook);
+                WP_MARK(4);  // second k-half
                 if (t == 1 && !DBG(16)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // our reads are invisible to hipcc's counters
                     cell_sums(Bt);
@@ -421,20 +473,21 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
-            step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
-            step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
-            step(std::integral_constant<int, 8>{});
-        }
+            step(integral_constant<int, 0>{}); step(integral_constant<int, 1>{}); step(integral_constant<int, 2>{});
+            step(integral_constant<int, 3>{}); step(integral_constant<int, 4>{}); step(integral_constant<int, 5>{});
+            step(integral_constant<int, 6>{}); step(integral_constant<int, 7>{}); step(integral_constant<int, 8>{});
+        };
+        for (int chunk = 0; chunk + 1 < a.nchunks; ++chunk) chunk_body(false_type{}, chunk);
+        chunk_body(true_type{}, a.nchunks - 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WP_FLUSH();
 #undef LDS_READ128
     } else {
         TS(1);
         TS(2);
-        issueB(0, 0);
-        issueA(0, 0);
-        if (a.ksteps > 1) issueA(1, 1);
+        issueB(0);
+        issueA_next(0);
+        if (a.ksteps > 1) issueA_next(BM * 64);
         for (int g0 = 0; g0 < a.ksteps; g0 += 3) {
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -444,8 +497,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
                     if (g + 1 < a.ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
-                    if (g + 1 < a.ksteps) issueB(g + 1, (g + 1) & 1);
-                    if (g + 2 < a.ksteps) issueA(g + 2, (u + 2) % 3);
+                    if (g + 1 < a.ksteps) issueB(g + 1);
+                    if (g + 2 < a.ksteps) issueA_next(((u + 2) % 3) * (BM * 64));
                     const char *Bt = ldsB + (g & 1) * bbytes;
                     compute(ldsA + u * (BM * 64), Bt, 0);
                     cell_sums(Bt);
@@ -613,7 +666,7 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     // rows spanned by BN consecutive pixels: pixel rows + one pad row per image boundary crossed, + halo rows
     a.rows_cap = (BN - 2 + a.W) / a.W + 1 + (BN - 2 + a.H * a.W) / (a.H * a.W) + 2 * HALO;
     const int ndma = a.rows_cap * (RS / 16);
-    if ((ndma + NW - 1) / NW > RBPT_MAX) return MI355_EINVAL;
+    if ((ndma + NW - 1) / NW > rows_nb_slots(BN, RS, NW, KS)) return MI355_EINVAL;  // map too narrow for this tile
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     a.rowb = RS * 64 + 16 * (a.W & 15);
     size_t lds = (size_t)ra_stages<KS>() * BM * 64 + 2 * (size_t)a.rows_cap * a.rowb + (size_t)a.rows_cap * RS * 4;
