@@ -134,8 +134,10 @@ int mi355_conv_pool_forward(const mi355_conv_desc *desc, const mi355_tensor *x, 
 
 /* Tile configuration override for benchmarking (0 = auto). */
 int mi355_conv_set_tile(int bm, int bn);
-/* Timing-ablation switches for kernel development (bit 0: no DMA in the K loop, 1: no s_barrier, 2: no MFMA,
- * 4: no cell sums).  Results are WRONG when non-zero; never set outside tools/conv_microbench.py --ablate. */
+/* Development switches.  Bits 0..8 are timing ablations of the K loop (no DMA / no s_barrier / no MFMA / ...), compiled
+ * in only with -DMI355_ABLATE: results are WRONG when set; tools/conv_microbench.py --ablate only.  Two bits select
+ * among equivalent kernels and leave results unchanged (tests use them to cross-check): 512 = conv_rows.hip walks the
+ * channel chunks unrotated, 1024 = fused conv+maxpool never uses conv_small.hip. */
 int mi355_debug_flags(int flags);
 
 /* ---- glue layers ---------------------------------------------------------------------------------------- */

@@ -229,6 +229,51 @@ def test_conv_fused_maxpool_equals_conv_then_pool(c, n, H, W, act, store):
     assert np.array_equal(yp2.to_nchw(), want_pool)
 
 
+@pytest.mark.parametrize("c,n,H,W,act", [(16, 32, 22, 64, "leaky"), (32, 64, 14, 70, "leaky"), (16, 64, 12, 62, "relu6"),
+                                         (32, 32, 18, 66, "linear"), (16, 32, 208, 208, "leaky")])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+@pytest.mark.parametrize("gain", ["no-wrap", "some-wrap", "much-wrap"])
+def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain):
+    """The weights-stationary few-channel kernel (conv_small.hip: 3x3, c 16|32, n 32|64, map at least 62 wide, pooled
+    output only).  It requantises only the maximum accumulator of a 2x2 window when no accumulator of the window can
+    wrap on store, and falls back to the reference's order (wrap, then max) per wave otherwise: all three regimes --
+    no wave wraps, a few do, most do -- must give the oracle's conv -> requant -> maxpool bytes.  Tiles are runs of 128
+    pooled pixels that cross rows and images (B = 3, odd pooled widths)."""
+    import ctypes as C
+    rng = np.random.default_rng(c * 1000 + n * 10 + H + len(gain))
+    B = 3 if H < 100 else 1
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    lo, hi = {"no-wrap": (2.0 ** -17, 2.0 ** -16), "some-wrap": (2.0 ** -14, 2.0 ** -12), "much-wrap": (2.0 ** -11, 2.0 ** -7)}[gain]
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3, lo, hi)
+    if gain != "much-wrap":
+        bias = (bias // 16).astype(np.int32)
+    zp_in, zp_act = 9, (23 if act != "linear" else 128)
+    xt = binding.DevTensor.from_nchw(x, zp_in)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv))
+    yp = binding.DevTensor(B, H // 2, W // 2, n, zp_act)
+    d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT[act], store, binding.ACC_EXACT, zp_in, zp_act, 1.0)
+    binding.check(binding.shim().mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, None, yp.ref(), None), "conv_pool")
+    acc, u8 = _oracle_layer(x, wq, zp_w, 3, zp_in, bias, mv, sv, zp_act, oracle.ACT[act], store, oracle.ACC_EXACT)
+    u8 = u8.reshape(B, n, H, W)
+    want_pool = np.stack([oracle.maxpool_u8(u8[b], 2, 2, 1) for b in range(B)])
+    sat = np.stack([oracle.requant(acc[b], bias, mv, sv, zp_act, oracle.ACT[act], oracle.STORE_SATURATE) for b in range(B)])
+    wrap = np.stack([oracle.requant(acc[b], bias, mv, sv, zp_act, oracle.ACT[act], oracle.STORE_WRAP) for b in range(B)])
+    frac = float((sat != wrap).mean())
+    if gain == "no-wrap":
+        assert frac == 0.0
+    elif gain == "much-wrap":
+        assert frac > 0.05
+    assert np.array_equal(yp.to_nchw(), want_pool), f"pooled tensor (wrap fraction {frac:.4f})"
+    # the generic kernel on the same call (debug switch 1024 routes around conv_small.hip) agrees as well
+    binding.shim().mi355_debug_flags(1024)
+    try:
+        yp2 = binding.DevTensor(B, H // 2, W // 2, n, zp_act)
+        binding.check(binding.shim().mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, None, yp2.ref(), None), "conv_pool")
+    finally:
+        binding.shim().mi355_debug_flags(0)
+    assert np.array_equal(yp2.to_nchw(), want_pool)
+
+
 def test_fused_maxpool_net_equals_unfused(cfg_dir, tmp_path):
     """Whole yolov3-tiny, batch 3: the throughput configuration (conv+maxpool fused where possible, pre-pool tensors
     not stored) yields byte-identical tensors on every layer that is stored in both configurations."""

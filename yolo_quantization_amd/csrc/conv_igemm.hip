@@ -528,6 +528,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
 // ---------------------------------------------------------------------------------------------------------------
 static int g_force_nt = 0, g_force_bm = 0, g_force_bn = 0, g_force_patch = -1, g_force_generic = 0, g_no_rows = 0;
 static int g_debug = 0;
+int mi355_debug_flags_get() { return g_debug; }
 extern "C" int mi355_debug_flags(int flags)
 {
     g_debug = flags;

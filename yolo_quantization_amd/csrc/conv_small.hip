@@ -1,0 +1,337 @@
+// conv_small.hip -- 3x3 s1 p1 INT8 convolution with few input channels (c = 16 or 32, n = 32 or 64) fused with the
+// 2x2 / stride-2 maxpool that follows it: layers 2 and 4 of yolov3-tiny, a quarter of the network's time when they ran
+// through the generic K loop of conv_igemm.hip.  Same mathematics as conv_igemm.hip (read its header for the signed
+// operand decomposition); built differently because K is tiny (144 / 288) and the epilogue dominates:
+//
+//   * weights stationary in registers: a wave keeps the A fragments of ALL K-steps (5 for c = 16: two taps per
+//     V_MFMA_I32_32X32X32_I8, the k-half is the tap parity; 9 for c = 32: one tap per MFMA, the k-half is the 16-channel
+//     piece) and loops over tiles persistently -- there is no A traffic and no K loop.
+//   * a tile is 128 consecutive POOLED pixels (flattened over b, y, x: no ragged edge tiles); its input is the run of
+//     whole PHWC rows that covers the 2x2 windows plus one halo row each side, DMAed (global_load_lds) into a double
+//     buffered LDS row image while the previous tile computes.
+//   * lane l of a wave owns pooled pixel 32*wave + l; the four 32-column MFMA sub-tiles of the wave are the four window
+//     positions, so the 2x2 window of every (pixel, channel) sits in ONE lane: the pool is three v_max_i32, no
+//     cross-lane traffic and no pre-pool tensor.
+//   * max-pool commutes with the requantisation: per channel the map accumulator -> stored byte is monotone as long as
+//     the byte does not wrap, and the range of accumulators that cannot wrap, [tlo, thi], is found once per workgroup
+//     (analytic guess, verified with the exact requantise function).  A window whose four accumulators lie inside it is
+//     requantised ONCE (its maximum); only waves that see an accumulator outside the range (the reference's
+//     wrap-on-store cases, src/convolutional_layer.c:737-749) take the exact four-requantisation path.  SATURATE stores
+//     are monotone everywhere.  Result bytes are identical to conv + forward_maxpool_layer_quant
+//     (ref: src/maxpool_layer.c:109-172) in every case.
+#include "kargs.h"
+#include <type_traits>
+
+#define DMA_S(ldsdst_u32, sbase_ptr, voff_u32)                                                                   \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst_u32), "v"(voff_u32), \
+                 "s"(sbase_ptr)                                                                                  \
+                 : "memory")
+
+constexpr int SM_PPB = 128;  // pooled pixels per workgroup tile (4 waves x 32 lanes)
+
+// activation + zero point of a requantised value, unwrapped (the byte is this & 0xFF or its clamp)
+template <int ACT>
+__device__ __forceinline__ long small_v_of(int32_t accb, double mp, int zp)
+{
+    const int32_t q = requant_q_exact(accb, mp);
+    if (ACT == MI355_ACT_LEAKY) {
+        if (q >= 0) return (long)zp + q;
+        const uint32_t x = (0u - (uint32_t)q) + 5u;
+        return (long)zp - (long)(x / 10u);
+    }
+    if (ACT == MI355_ACT_RELU6) return (long)zp + (q > 0 ? q : 0);
+    return (long)zp + q;
+}
+
+// [lo, hi]: accumulators (incl. bias and zero-point terms) whose stored byte does not wrap.  Any sub-range of the true
+// one is safe (it only sends more waves down the exact path), so the analytic guess is moved inwards until it verifies.
+template <int ACT>
+__device__ void small_safe_range(double mp, int zp, int32_t &lo, int32_t &hi)
+{
+    // upper end: zp + q <= 255  <=>  q <= 255 - zp, q = trunc(a * mp)
+    double gh = ((double)(256 - zp)) / mp;
+    long h = gh >= 2147483000.0 ? 2147483647L : (long)gh;
+    for (int it = 0; it < 64 && h > -2147483647L && small_v_of<ACT>((int32_t)h, mp, zp) > 255; ++it) h -= (it < 8 ? 1 : 4096);
+    if (small_v_of<ACT>((int32_t)h, mp, zp) > 255) h = -2147483647L - 1;  // give up: nothing is safe
+    hi = (int32_t)h;
+    long l;
+    if (ACT == MI355_ACT_RELU6) {
+        l = -2147483647L - 1;  // zp + max(q, 0) >= zp >= 0
+    } else {
+        const double qlo = (ACT == MI355_ACT_LEAKY) ? -(10.0 * zp + 5.0) : -(double)(zp + 1);
+        const double gl = qlo / mp;
+        l = gl <= -2147483000.0 ? -2147483647L - 1 : (long)gl;
+        for (int it = 0; it < 64 && l < 2147483647L && small_v_of<ACT>((int32_t)l, mp, zp) < 0; ++it) l += (it < 8 ? 1 : 4096);
+        if (small_v_of<ACT>((int32_t)l, mp, zp) < 0) l = 2147483647L;
+    }
+    lo = (int32_t)l;
+}
+
+template <int C, int NM, int ACT, bool SAT>
+__global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs a)
+{
+    constexpr int KST = (C == 16) ? 5 : 9;
+    constexpr int PIECES = C / 16;
+    constexpr int N = 32 * NM;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ncell = a.W + 2;        // cells of an LDS row: x = -1 .. W
+    const int pieceb = ncell * 16;    // bytes of one 16-byte piece plane of a row
+    const int rowb = a.rowb;          // bytes between LDS rows (= PIECES * pieceb)
+    const int bbytes = a.rows_cap * rowb;
+    int *ldsS = reinterpret_cast<int *>(smem + 2 * bbytes);               // [rows_cap][ncell] per-cell channel sums
+    double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier
+    int *ldsDZ = reinterpret_cast<int *>(ldsMP + N);                      // [N] 128 - zp_w
+    int *ldsCB = ldsDZ + N;                                               // [N] cw + bias
+    int *ldsLO = ldsCB + N, *ldsHI = ldsLO + N;                           // [N] wrap-safe accumulator range
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = lane >> 5, lj = lane & 31;
+    const int W1 = a.W + 1;
+    const int OH = a.H >> 1, OW = a.W >> 1, ohw = OH * OW;
+    const int total_p = a.B * ohw;
+    const int ntiles = (total_p + SM_PPB - 1) / SM_PPB;
+    const bool pow2 = a.hdr->pow2 == 1;
+
+    // ---- per-channel parameters and the wrap-safe ranges
+    if (tid < N) {
+        const double mp = a.mprime[tid];
+        ldsMP[tid] = mp;
+        ldsDZ[tid] = a.dzp[tid];
+        ldsCB[tid] = a.cwb[tid];
+        int32_t lo = -2147483647 - 1, hi = 2147483647;
+        if (!SAT) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
+        ldsLO[tid] = lo;
+        ldsHI[tid] = hi;
+    }
+
+    // ---- stationary A fragments: plane ws = [m-tile][k-step][lane][16 B]
+    v4i wf[NM][KST];
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+            wf[mt][s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(mt * KST + s) * 64 + lane) * 16);
+
+    // tap byte offsets inside the row image.  C == 16: lane-dependent (k-half = tap parity; tap 9 does not exist, its
+    // weights are zero and the lane re-reads tap 8).  C == 32: uniform per step, the k-half selects the piece plane.
+    int toff[KST];
+#pragma unroll
+    for (int s = 0; s < KST; ++s) {
+        int t = (C == 16) ? 2 * s + kh : s;
+        if (t > 8) t = 8;
+        toff[s] = (t / 3) * rowb + (t % 3) * 16;
+    }
+
+    // rows of a tile: first / last global pre-pool row (pad rows of the PHWC layout included) of its pooled pixels
+    auto tile_rows = [&](int tile, int &gr_first, int &nrows) {
+        const int p0 = tile * SM_PPB;
+        const int p1 = min(p0 + SM_PPB, total_p) - 1;
+        const int b0 = p0 / ohw, r0 = (p0 - b0 * ohw) / OW;
+        const int b1 = p1 / ohw, r1 = (p1 - b1 * ohw) / OW;
+        gr_first = b0 * (a.H + 1) + 2 * r0 + 1;
+        const int gr_last = b1 * (a.H + 1) + 2 * r1 + 2;
+        nrows = gr_last - gr_first + 3;  // + one halo row above and below
+    };
+    // DMA of a tile's rows: wave w loads LDS rows w, w+4, ..; a row piece is ceil(ncell / 64) instructions of 64 cells,
+    // the last one shifted back to end on the row's last cell (ncell >= 64, checked by the launcher)
+    const int nch = (ncell + 63) >> 6;
+    auto issue_tile = [&](int tile, int parity) {
+        int gr_first, nrows;
+        tile_rows(tile, gr_first, nrows);
+        const unsigned buf = lds0 + parity * bbytes;
+        for (int r = wave; r < nrows; r += 4) {
+            const long rowcell = (long)a.in_lead + (long)(gr_first - 1 + r) * W1 - 1;  // global cell of LDS cell 0
+            for (int k = 0; k < nch; ++k) {
+                const int c0 = min(k * 64, ncell - 64);
+                long f = rowcell + c0 + lane;
+                f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
+                const unsigned voff = (unsigned)(f * a.in_cs);
+#pragma unroll
+                for (int p = 0; p < PIECES; ++p) {
+                    const unsigned dst = buf + r * rowb + p * pieceb + c0 * 16;
+                    const unsigned v = voff + p * 16;
+                    DMA_S(dst, a.x, v);
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue_tile(tile, 0);
+    int parity = 0;
+    for (; tile < ntiles; tile += gridDim.x, parity ^= 1) {
+        int gr_first, nrows;
+        tile_rows(tile, gr_first, nrows);
+        const char *X = smem + parity * bbytes;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the tile's rows have landed (and the parameters, first time round)
+
+        // ---- per-cell channel sums S (the receptive-field sum of x' is the 3x3 box sum of S)
+        for (int r = wave; r < nrows; r += 4)
+            for (int c = lane; c < ncell; c += 64) {
+                int t = 0;
+#pragma unroll
+                for (int p = 0; p < PIECES; ++p) {
+                    const v4i v = *reinterpret_cast<const v4i *>(X + r * rowb + p * pieceb + c * 16);
+                    t = __builtin_amdgcn_sdot4(v[0], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(v[1], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(v[2], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(v[3], 0x01010101, t, false);
+                }
+                ldsS[r * ncell + c] = t;
+            }
+        __syncthreads();  // S complete; every wave is past the previous tile: its buffer may be overwritten
+        if (tile + gridDim.x < ntiles) issue_tile(tile + gridDim.x, parity ^ 1);
+
+        // ---- this lane's pooled pixel and its 2x2 window in the row image
+        const int pp = tile * SM_PPB + wave * 32 + lj;
+        const bool valid = pp < total_p;
+        const int ppc = valid ? pp : total_p - 1;
+        const int b = ppc / ohw, prem = ppc - b * ohw;
+        const int prow = prem / OW, pcol = prem - prow * OW;
+        const int lrow = b * (a.H + 1) + 2 * prow + 1 - gr_first;  // LDS row of the window's top row's top tap
+        int base[4], sx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = lrow + (j >> 1), cc = 2 * pcol + (j & 1);
+            base[j] = rr * rowb + cc * 16 + ((C == 32) ? kh * pieceb : 0);
+            int t = 0;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) t += ldsS[(rr + dy) * ncell + cc + dx];
+            sx[j] = t;
+        }
+        const size_t pcell = (size_t)a.pool_lead + ((size_t)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol;
+        uint8_t *outp = a.ypool + pcell * a.pool_cs;
+
+#pragma unroll
+        for (int mt = 0; mt < NM; ++mt) {
+            // accumulators start at cw + bias: register grp*4+r of a 32x32 tile is channel row 8*grp + 4*kh + r
+            v16i acc[4];
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + 32 * mt + 8 * grp + 4 * kh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][grp * 4 + 0] = c4.x; acc[j][grp * 4 + 1] = c4.y;
+                    acc[j][grp * 4 + 2] = c4.z; acc[j][grp * 4 + 3] = c4.w;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < KST; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4i bf = *reinterpret_cast<const v4i *>(X + base[j] + toff[s]);
+                    acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[mt][s], bf, acc[j], 0, 0, 0);
+                }
+            // ---- epilogue: window max, one requantisation per (pixel, channel), biased packed store
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int ch0 = 32 * mt + 8 * grp + 4 * kh;
+                const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
+                const int4 lo4 = *reinterpret_cast<const int4 *>(ldsLO + ch0);
+                const int4 hi4 = *reinterpret_cast<const int4 *>(ldsHI + ch0);
+                const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
+                const int lov[4] = {lo4.x, lo4.y, lo4.z, lo4.w}, hiv[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
+                int32_t accb[4][4];  // [channel r][window position j]
+                int32_t amax[4][1];
+                double mp[4];
+                bool bad = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mp[r] = ldsMP[ch0 + r];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accb[r][j] = acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
+                    const int32_t mx = max(max(accb[r][0], accb[r][1]), max(accb[r][2], accb[r][3]));
+                    const int32_t mn = min(min(accb[r][0], accb[r][1]), min(accb[r][2], accb[r][3]));
+                    bad |= (mx > hiv[r]) | (mn < lov[r]);
+                    amax[r][0] = mx;
+                }
+                int32_t m[4];
+                if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {
+                    int32_t v[4][1];
+                    requant_values<ACT, SAT, 1>(amax, mp, a.zp_act, v);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m[r] = v[r][0];
+                } else if (pow2) {  // some window of this wave wraps: the reference's order, bytes first, then the max
+                    int32_t v[4][4];
+                    requant_values<ACT, SAT, 4>(accb, mp, a.zp_act, v);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
+                } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int32_t t = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            t = max(t, (int32_t)requant_u8(accb[r][j], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
+                                                           SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
+                        m[r] = t;
+                    }
+                }
+                if (valid) *reinterpret_cast<uint32_t *>(outp + ch0) = pack4_biased(m[0], m[1], m[2], m[3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int C, int NM, int ACT>
+static int small_launch_sat(ConvArgs &a, hipStream_t st, int grid, size_t lds)
+{
+    if (a.store_mode == MI355_STORE_SATURATE) {
+        auto kern = conv_small_pool_kernel<C, NM, ACT, true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MI355_EHIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    } else {
+        auto kern = conv_small_pool_kernel<C, NM, ACT, false>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MI355_EHIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
+template <int C, int NM>
+static int small_launch_act(ConvArgs &a, hipStream_t st, int grid, size_t lds)
+{
+    if (a.act == MI355_ACT_LEAKY) return small_launch_sat<C, NM, MI355_ACT_LEAKY>(a, st, grid, lds);
+    if (a.act == MI355_ACT_RELU6) return small_launch_sat<C, NM, MI355_ACT_RELU6>(a, st, grid, lds);
+    return small_launch_sat<C, NM, MI355_ACT_LINEAR>(a, st, grid, lds);
+}
+
+bool conv_small_eligible(int n, int c, int ksize) { return ksize == 3 && (c == 16 || c == 32) && (n == 32 || n == 64); }
+
+// returns MI355_EINVAL when the shape is outside this kernel's domain (the caller falls back to conv_igemm.hip)
+int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
+{
+    const int c = a.cb * a.nchunks;
+    if (!conv_small_eligible(a.n, c, a.ksize) || !a.ypool || a.y || a.acc_out || a.y_f32 || !a.ws) return MI355_EINVAL;
+    if ((a.H & 1) || (a.W & 1) || a.W + 2 < 64 || a.in_cs != c) return MI355_EINVAL;
+    if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
+    const int OH = a.H / 2, OW = a.W / 2;
+    const long total_p = (long)a.B * OH * OW;
+    const int ntiles = (int)((total_p + SM_PPB - 1) / SM_PPB);
+    // rows of a 128-pooled-pixel run: pooled rows it can touch, two image rows each, one pad row per image boundary
+    // crossed, one halo row above and below
+    a.rows_cap = 2 * ((SM_PPB - 2 + OW) / OW + 1) + (SM_PPB - 2 + OH * OW) / (OH * OW) + 2;
+    a.rowb = (a.W + 2) * c;
+    size_t lds = 2 * (size_t)a.rows_cap * a.rowb + (size_t)a.rows_cap * (a.W + 2) * 4;
+    lds = (lds + 15) & ~(size_t)15;
+    a.lds_param_off = (int)lds;
+    lds += (size_t)a.n * 24;
+    if (lds > 160 * 1024) return MI355_EINVAL;
+    const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
+    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    if (c == 16 && a.n == 32) return small_launch_act<16, 1>(a, st, grid, lds);
+    if (c == 16 && a.n == 64) return small_launch_act<16, 2>(a, st, grid, lds);
+    if (c == 32 && a.n == 32) return small_launch_act<32, 1>(a, st, grid, lds);
+    return small_launch_act<32, 2>(a, st, grid, lds);
+}

@@ -30,6 +30,7 @@ struct ConvArgs {
     int pool_cs, pool_lead;
     int lds_param_off;       // conv_rows: byte offset of the staged per-channel epilogue parameters in LDS
     int debug;               // timing-ablation switches (results are wrong when non-zero): see mi355_debug_flags
+    const int8_t *ws;        // conv_small: weights-stationary A fragments [m-tile][k-step][lane][16 B] or null
 };
 
 struct AuxArgs {
@@ -75,6 +76,9 @@ struct LayoutArgs {
 
 int conv_igemm_launch(ConvArgs &a, hipStream_t st);
 int conv_rows_launch(ConvArgs &a, hipStream_t st, int bm, int bn);
+int conv_small_pool_launch(ConvArgs &a, hipStream_t st);
+bool conv_small_eligible(int n, int c, int ksize);
+int mi355_debug_flags_get();
 int conv_first_launch(AuxArgs &a, hipStream_t st);
 int conv_first_pool_launch(AuxArgs &a, hipStream_t st);
 int conv_ref_f32_launch(AuxArgs &a, hipStream_t st);

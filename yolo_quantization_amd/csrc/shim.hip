@@ -237,6 +237,10 @@ static int blob_layout(int n, int c, int ksize, ConvBlobHeader *h)
     h->off_shift = off; off = align16(off + (size_t)h->mpad * 4);
     h->off_mprime = off; off = align16(off + (size_t)h->mpad * 8);
     h->off_cwb = off; off = align16(off + (size_t)h->mpad * 4);
+    if (conv_small_eligible(n, c, ksize)) {
+        h->off_ws = off;
+        off = align16(off + (size_t)(n / 32) * (c == 16 ? 5 : 9) * 1024);
+    }
     h->total = off;
     return MI355_OK;
 }
@@ -296,6 +300,21 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
                 wp[oc * 9 + t] = v;
             }
         return MI355_OK;
+    }
+    if (h.off_ws) {  // weights-stationary plane of conv_small.hip: lane (row lj, k-half kh) of K-step s
+        int8_t *ws = (int8_t *)(base + h.off_ws);
+        const int kst = (c == 16) ? 5 : 9;
+        for (int mt = 0; mt < n / 32; ++mt)
+            for (int s = 0; s < kst; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int oc = 32 * mt + (lane & 31), khalf = lane >> 5;
+                    const int tap = (c == 16) ? 2 * s + khalf : s;  // c 16: the k-half is the tap parity (tap 9: zeros)
+                    int8_t *dst = ws + ((size_t)(mt * kst + s) * 64 + lane) * 16;
+                    for (int e = 0; e < 16; ++e) {
+                        const int ci = (c == 16) ? e : 16 * khalf + e;
+                        dst[e] = tap > 8 ? 0 : (int8_t)(wq[(size_t)oc * K + (ci * 3 + tap / 3) * 3 + tap % 3] ^ 0x80);
+                    }
+                }
     }
     int8_t *wp = (int8_t *)(base + h.off_wp);
     const int bpc = h.cb / 16;
@@ -390,7 +409,10 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     a.mprime = (const double *)(base + h.off_mprime);
     a.cwb = (const int32_t *)(base + h.off_cwb);
     a.hdr = (const ConvBlobHeader *)base;  // device copy: the kernel reads the data-dependent pow2 flag from it
-    int rc = conv_igemm_launch(a, st);
+    a.ws = h.off_ws ? (const int8_t *)(base + h.off_ws) : nullptr;
+    int rc = MI355_EINVAL;
+    if (ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) rc = conv_small_pool_launch(a, st);  // few-channel layers
+    if (rc == MI355_EINVAL) rc = conv_igemm_launch(a, st);
     if (rc == MI355_EINVAL) return einval("conv_forward: no tile configuration fits this shape");
     if (rc != MI355_OK) return hip_fail(hipGetLastError(), "conv_igemm launch");
     return rc;
