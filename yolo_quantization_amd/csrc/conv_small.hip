@@ -6,9 +6,11 @@
 //   * weights stationary in registers: a wave keeps the A fragments of ALL K-steps (5 for c = 16: two taps per
 //     V_MFMA_I32_32X32X32_I8, the k-half is the tap parity; 9 for c = 32: one tap per MFMA, the k-half is the 16-channel
 //     piece) and loops over tiles persistently -- there is no A traffic and no K loop.
-//   * a tile is 128 consecutive POOLED pixels (flattened over b, y, x: no ragged edge tiles); its input is the run of
-//     whole PHWC rows that covers the 2x2 windows plus one halo row each side, DMAed (global_load_lds) into a double
-//     buffered LDS row image while the previous tile computes.
+//   * a tile is 128 POOLED pixels: on narrow maps a run of consecutive ones (flattened over b, y, x: no ragged edge
+//     tiles; its input is the run of whole PHWC rows covering the 2x2 windows), on wide maps (pooled width >= 64, where
+//     such a run would drag in two mostly unused rows) an 8 x 16 patch.  Either way the input is a dense image of
+//     nrows x ncell cells incl. one halo cell all round, DMAed (global_load_lds) into a double buffered LDS plane per
+//     16-channel piece while the previous tile computes.
 //   * lane l of a wave owns pooled pixel 32*wave + l; the four 32-column MFMA sub-tiles of the wave are the four window
 //     positions, so the 2x2 window of every (pixel, channel) sits in ONE lane: the pool is three v_max_i32, no
 //     cross-lane traffic and no pre-pool tensor.
@@ -75,11 +77,12 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     constexpr int N = 32 * NM;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ncell = a.W + 2;        // cells of an LDS row: x = -1 .. W
-    const int pieceb = ncell * 16;    // bytes of one 16-byte piece plane of a row
-    const int rowb = a.rowb;          // bytes between LDS rows (= PIECES * pieceb)
-    const int bbytes = a.rows_cap * rowb;
-    int *ldsS = reinterpret_cast<int *>(smem + 2 * bbytes);               // [rows_cap][ncell] per-cell channel sums
+    const int ncell = a.sm_ncell;     // cells of an LDS image row (flat tiles: W + 2, x = -1 .. W; patches: 34)
+    const int rowb = ncell * 16;      // bytes between image rows inside a piece plane
+    const int pieceb = a.sm_pieceb;   // bytes of one 16-channel piece plane (rows_cap * ncell cells)
+    const int bbytes = PIECES * pieceb;
+    const bool patch = a.tiles_x > 0;
+    int *ldsS = reinterpret_cast<int *>(smem + 2 * bbytes);               // [rows_cap * ncell] per-cell channel sums
     double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier
     int *ldsDZ = reinterpret_cast<int *>(ldsMP + N);                      // [N] 128 - zp_w
     int *ldsCB = ldsDZ + N;                                               // [N] cw + bias
@@ -93,7 +96,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     const int W1 = a.W + 1;
     const int OH = a.H >> 1, OW = a.W >> 1, ohw = OH * OW;
     const int total_p = a.B * ohw;
-    const int ntiles = (total_p + SM_PPB - 1) / SM_PPB;
+    const int tpi = a.tiles_x * a.tiles_y;  // patches per image
+    const int ntiles = patch ? a.B * tpi : (total_p + SM_PPB - 1) / SM_PPB;
     const bool pow2 = a.hdr->pow2 == 1;
 
     // ---- per-channel parameters and the wrap-safe ranges
@@ -126,36 +130,44 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
         toff[s] = (t / 3) * rowb + (t % 3) * 16;
     }
 
-    // rows of a tile: first / last global pre-pool row (pad rows of the PHWC layout included) of its pooled pixels
-    auto tile_rows = [&](int tile, int &gr_first, int &nrows) {
-        const int p0 = tile * SM_PPB;
-        const int p1 = min(p0 + SM_PPB, total_p) - 1;
-        const int b0 = p0 / ohw, r0 = (p0 - b0 * ohw) / OW;
-        const int b1 = p1 / ohw, r1 = (p1 - b1 * ohw) / OW;
-        gr_first = b0 * (a.H + 1) + 2 * r0 + 1;
-        const int gr_last = b1 * (a.H + 1) + 2 * r1 + 2;
-        nrows = gr_last - gr_first + 3;  // + one halo row above and below
+    // image of a tile: global row (over all image blocks of the PHWC tensor, pad rows included) of its first pre-pool
+    // row, x of image cell 0, rows
+    auto tile_geom = [&](int tile, int &gr_first, int &col0, int &nrows) {
+        if (patch) {
+            const int b = tile / tpi, t = tile - b * tpi;
+            const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+            gr_first = b * (a.H + 1) + 16 * ty + 1;
+            col0 = 32 * tx - 1;
+            nrows = 18;
+        } else {
+            const int p0 = tile * SM_PPB;
+            const int p1 = min(p0 + SM_PPB, total_p) - 1;
+            const int b0 = p0 / ohw, r0 = (p0 - b0 * ohw) / OW;
+            const int b1 = p1 / ohw, r1 = (p1 - b1 * ohw) / OW;
+            gr_first = b0 * (a.H + 1) + 2 * r0 + 1;
+            const int gr_last = b1 * (a.H + 1) + 2 * r1 + 2;
+            col0 = -1;
+            nrows = gr_last - gr_first + 3;  // + one halo row above and below
+        }
     };
-    // DMA of a tile's rows: wave w loads LDS rows w, w+4, ..; a row piece is ceil(ncell / 64) instructions of 64 cells,
-    // the last one shifted back to end on the row's last cell (ncell >= 64, checked by the launcher)
-    const int nch = (ncell + 63) >> 6;
+    // DMA of a tile's image: instruction k fills cells [64k, 64k + 64) of every piece plane; wave w issues k = w, w+4, ..
     auto issue_tile = [&](int tile, int parity) {
-        int gr_first, nrows;
-        tile_rows(tile, gr_first, nrows);
+        int gr_first, col0, nrows;
+        tile_geom(tile, gr_first, col0, nrows);
         const unsigned buf = lds0 + parity * bbytes;
-        for (int r = wave; r < nrows; r += 4) {
-            const long rowcell = (long)a.in_lead + (long)(gr_first - 1 + r) * W1 - 1;  // global cell of LDS cell 0
-            for (int k = 0; k < nch; ++k) {
-                const int c0 = min(k * 64, ncell - 64);
-                long f = rowcell + c0 + lane;
-                f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
-                const unsigned voff = (unsigned)(f * a.in_cs);
+        const int ncells = nrows * ncell;
+        for (int k = wave; k * 64 < ncells; k += 4) {
+            const int start = min(k * 64, a.rows_cap * ncell - 64);  // the last instruction ends on the plane's last cell
+            const int slot = start + lane;
+            const int r = slot / ncell, c = slot - r * ncell;
+            long f = (long)a.in_lead + (long)(gr_first - 1 + r) * W1 + col0 + c;
+            f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
+            const unsigned voff = (unsigned)(f * a.in_cs);
 #pragma unroll
-                for (int p = 0; p < PIECES; ++p) {
-                    const unsigned dst = buf + r * rowb + p * pieceb + c0 * 16;
-                    const unsigned v = voff + p * 16;
-                    DMA_S(dst, a.x, v);
-                }
+            for (int p = 0; p < PIECES; ++p) {
+                const unsigned dst = buf + p * pieceb + start * 16;
+                const unsigned v = voff + p * 16;
+                DMA_S(dst, a.x, v);
             }
         }
     };
@@ -164,40 +176,54 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     if (tile < ntiles) issue_tile(tile, 0);
     int parity = 0;
     for (; tile < ntiles; tile += gridDim.x, parity ^= 1) {
-        int gr_first, nrows;
-        tile_rows(tile, gr_first, nrows);
+        int gr_first, col0, nrows;
+        tile_geom(tile, gr_first, col0, nrows);
         const char *X = smem + parity * bbytes;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // the tile's rows have landed (and the parameters, first time round)
-
-        // ---- per-cell channel sums S (the receptive-field sum of x' is the 3x3 box sum of S)
-        for (int r = wave; r < nrows; r += 4)
-            for (int c = lane; c < ncell; c += 64) {
-                int t = 0;
-#pragma unroll
-                for (int p = 0; p < PIECES; ++p) {
-                    const v4i v = *reinterpret_cast<const v4i *>(X + r * rowb + p * pieceb + c * 16);
-                    t = __builtin_amdgcn_sdot4(v[0], 0x01010101, t, false);
-                    t = __builtin_amdgcn_sdot4(v[1], 0x01010101, t, false);
-                    t = __builtin_amdgcn_sdot4(v[2], 0x01010101, t, false);
-                    t = __builtin_amdgcn_sdot4(v[3], 0x01010101, t, false);
-                }
-                ldsS[r * ncell + c] = t;
-            }
-        __syncthreads();  // S complete; every wave is past the previous tile: its buffer may be overwritten
+        __syncthreads();  // the tile's image has landed (and the parameters, first time round); every wave is past the
+                          // previous tile, so its buffer may be overwritten
         if (tile + gridDim.x < ntiles) issue_tile(tile + gridDim.x, parity ^ 1);
 
-        // ---- this lane's pooled pixel and its 2x2 window in the row image
-        const int pp = tile * SM_PPB + wave * 32 + lj;
-        const bool valid = pp < total_p;
-        const int ppc = valid ? pp : total_p - 1;
-        const int b = ppc / ohw, prem = ppc - b * ohw;
-        const int prow = prem / OW, pcol = prem - prow * OW;
-        const int lrow = b * (a.H + 1) + 2 * prow + 1 - gr_first;  // LDS row of the window's top row's top tap
+        // ---- per-cell channel sums S (the receptive-field sum of x' is the 3x3 box sum of S)
+        for (int id = tid; id < nrows * ncell; id += 256) {
+            int t = 0;
+#pragma unroll
+            for (int p = 0; p < PIECES; ++p) {
+                const v4i v = *reinterpret_cast<const v4i *>(X + p * pieceb + id * 16);
+                t = __builtin_amdgcn_sdot4(v[0], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(v[1], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(v[2], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(v[3], 0x01010101, t, false);
+            }
+            ldsS[id] = t;
+        }
+        __syncthreads();
+
+        // ---- this lane's pooled pixel and its 2x2 window in the image
+        int b, prow, pcol;
+        bool valid;
+        if (patch) {
+            b = tile / tpi;
+            const int t = tile - b * tpi;
+            const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+            prow = 8 * ty + 2 * wave + (lj >> 4);
+            pcol = 16 * tx + (lj & 15);
+            valid = prow < OH && pcol < OW;
+        } else {
+            const int pp = tile * SM_PPB + wave * 32 + lj;
+            valid = pp < total_p;
+            const int ppc = valid ? pp : total_p - 1;
+            b = ppc / ohw;
+            const int prem = ppc - b * ohw;
+            prow = prem / OW;
+            pcol = prem - prow * OW;
+        }
+        const int lrow = b * (a.H + 1) + 2 * prow + 1 - gr_first;  // image row of the window's top row's top tap
+        const int lcol = 2 * pcol - 1 - col0;                        // image cell of the window's left column's left tap
         int base[4], sx[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int rr = lrow + (j >> 1), cc = 2 * pcol + (j & 1);
+            const int rr = lrow + (j >> 1), cc = lcol + (j & 1);
             base[j] = rr * rowb + cc * 16 + ((C == 32) ? kh * pieceb : 0);
             int t = 0;
 #pragma unroll
@@ -314,16 +340,28 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
 {
     const int c = a.cb * a.nchunks;
     if (!conv_small_eligible(a.n, c, a.ksize) || !a.ypool || a.y || a.acc_out || a.y_f32 || !a.ws) return MI355_EINVAL;
-    if ((a.H & 1) || (a.W & 1) || a.W + 2 < 64 || a.in_cs != c) return MI355_EINVAL;
+    if ((a.H & 1) || (a.W & 1) || a.in_cs != c) return MI355_EINVAL;
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     const int OH = a.H / 2, OW = a.W / 2;
     const long total_p = (long)a.B * OH * OW;
-    const int ntiles = (int)((total_p + SM_PPB - 1) / SM_PPB);
-    // rows of a 128-pooled-pixel run: pooled rows it can touch, two image rows each, one pad row per image boundary
-    // crossed, one halo row above and below
-    a.rows_cap = 2 * ((SM_PPB - 2 + OW) / OW + 1) + (SM_PPB - 2 + OH * OW) / (OH * OW) + 2;
-    a.rowb = (a.W + 2) * c;
-    size_t lds = 2 * (size_t)a.rows_cap * a.rowb + (size_t)a.rows_cap * (a.W + 2) * 4;
+    int ntiles;
+    if (OW >= 64) {  // wide map: 8 x 16 pooled patches (a flat run of 128 would load two mostly unused rows)
+        a.tiles_x = (OW + 15) / 16;
+        a.tiles_y = (OH + 7) / 8;
+        a.sm_ncell = 34;
+        a.rows_cap = 18;
+        ntiles = a.B * a.tiles_x * a.tiles_y;
+    } else {
+        // rows of a 128-pooled-pixel run: pooled rows it can touch, two image rows each, one pad row per image boundary
+        // crossed, one halo row above and below
+        a.tiles_x = a.tiles_y = 0;
+        a.sm_ncell = a.W + 2;
+        a.rows_cap = 2 * ((SM_PPB - 2 + OW) / OW + 1) + (SM_PPB - 2 + OH * OW) / (OH * OW) + 2;
+        ntiles = (int)((total_p + SM_PPB - 1) / SM_PPB);
+    }
+    a.sm_pieceb = a.rows_cap * a.sm_ncell * 16;
+    if (a.rows_cap * a.sm_ncell < 64) return MI355_EINVAL;
+    size_t lds = 2 * (size_t)(c / 16) * a.sm_pieceb + (size_t)a.rows_cap * a.sm_ncell * 4;
     lds = (lds + 15) & ~(size_t)15;
     a.lds_param_off = (int)lds;
     lds += (size_t)a.n * 24;

@@ -31,6 +31,7 @@ struct ConvArgs {
     int lds_param_off;       // conv_rows: byte offset of the staged per-channel epilogue parameters in LDS
     int debug;               // timing-ablation switches (results are wrong when non-zero): see mi355_debug_flags
     const int8_t *ws;        // conv_small: weights-stationary A fragments [m-tile][k-step][lane][16 B] or null
+    int sm_ncell, sm_pieceb; // conv_small: cells per LDS image row; bytes of one 16-channel piece plane
 };
 
 struct AuxArgs {
