@@ -106,8 +106,18 @@ __global__ __launch_bounds__(256) void conv_ref_f32_kernel(const AuxArgs a)
 template <int ACT, bool SAT>
 __global__ __launch_bounds__(256) void conv_first_pool_u8_kernel(const AuxArgs a)
 {
-    extern __shared__ uint32_t wl[];  // [n][9] weights (c0,c1,c2,0) per tap
+    extern __shared__ uint32_t wl[];  // [n][9] weights (c0,c1,c2,0) per tap, then [n] lo, [n] hi wrap-safe ranges
+    int32_t *slo = reinterpret_cast<int32_t *>(wl + a.n * 9), *shi = slo + a.n;
     for (int i = threadIdx.x; i < a.n * 9; i += blockDim.x) wl[i] = a.wfirst[i];
+    // Max-pool commutes with the requantisation while no byte of the window wraps (see conv_small.hip): [lo, hi] is
+    // the per-channel range of accumulators (bias included) that cannot wrap; pre-pool stores keep the plain path.
+    const bool commute = !a.y && a.hdr->pow2 == 1;
+    if (threadIdx.x < a.n) {
+        int32_t lo = -2147483647 - 1, hi = 2147483647;
+        if (!SAT) small_safe_range<ACT>(a.mprime[threadIdx.x], a.zp_act, lo, hi);
+        slo[threadIdx.x] = lo;
+        shi[threadIdx.x] = hi;
+    }
     __syncthreads();
     const int OH = a.H >> 1, OW = a.W >> 1;
     const int total = a.B * OH * OW;
@@ -134,7 +144,9 @@ __global__ __launch_bounds__(256) void conv_first_pool_u8_kernel(const AuxArgs a
     const size_t pcell = a.pool_lead + ((size_t)b * (OH + 1) + (oy + 1)) * (OW + 1) + ox;
     for (int oc0 = 0; oc0 < a.n; oc0 += 4) {  // n % 4 == 0 (checked by the launcher)
         int32_t accb[4][4];
+        int32_t amax[4][1];
         double mp[4];
+        bool bad = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int oc = oc0 + r;
@@ -149,30 +161,41 @@ __global__ __launch_bounds__(256) void conv_first_pool_u8_kernel(const AuxArgs a
                     s1 = __builtin_amdgcn_udot4(wl[oc * 9 + k], xin[(p >> 1) + k / 3][(p & 1) + k % 3], s1, false);
                 accb[r][p] = (int32_t)s1 - zpw * sumx[p] + bias;
             }
-        }
-        int32_t v[4][4];
-        if (a.hdr->pow2 == 1) {
-            requant_values<ACT, SAT, 4>(accb, mp, a.zp_act, v);
-        } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    v[r][p] = (int32_t)requant_u8(accb[r][p], 0, a.mval[oc0 + r], a.sval[oc0 + r], a.zp_act, ACT,
-                                                  SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+            const int32_t mx = max(max(accb[r][0], accb[r][1]), max(accb[r][2], accb[r][3]));
+            const int32_t mn = min(min(accb[r][0], accb[r][1]), min(accb[r][2], accb[r][3]));
+            bad |= (mx > shi[oc]) | (mn < slo[oc]);
+            amax[r][0] = mx;
         }
         int32_t m[4];
+        if (commute && __builtin_amdgcn_ballot_w64(bad) == 0) {  // no window of this wave wraps: requantise the maxima only
+            int32_t v1[4][1];
+            requant_values<ACT, SAT, 1>(amax, mp, a.zp_act, v1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)  // uint8 wrap first, then the unsigned max of the window
-            m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
-        *reinterpret_cast<uint32_t *>(a.ypool + pcell * a.pool_cs + oc0) = pack4_biased(m[0], m[1], m[2], m[3]);
-        if (a.y) {
+            for (int r = 0; r < 4; ++r) m[r] = v1[r][0];
+        } else {
+            int32_t v[4][4];
+            if (a.hdr->pow2 == 1) {
+                requant_values<ACT, SAT, 4>(accb, mp, a.zp_act, v);
+            } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const size_t ocell = a.out_lead + ((size_t)b * (a.H + 1) + (2 * oy + (p >> 1) + 1)) * W1 + 2 * ox + (p & 1);
-                *reinterpret_cast<uint32_t *>(a.y + ocell * a.out_cs + oc0) = pack4_biased(v[0][p], v[1][p], v[2][p], v[3][p]);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        v[r][p] = (int32_t)requant_u8(accb[r][p], 0, a.mval[oc0 + r], a.sval[oc0 + r], a.zp_act, ACT,
+                                                      SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)  // uint8 wrap first, then the unsigned max of the window
+                m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
+            if (a.y) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const size_t ocell = a.out_lead + ((size_t)b * (a.H + 1) + (2 * oy + (p >> 1) + 1)) * W1 + 2 * ox + (p & 1);
+                    *reinterpret_cast<uint32_t *>(a.y + ocell * a.out_cs + oc0) = pack4_biased(v[0][p], v[1][p], v[2][p], v[3][p]);
+                }
             }
         }
+        *reinterpret_cast<uint32_t *>(a.ypool + pcell * a.pool_cs + oc0) = pack4_biased(m[0], m[1], m[2], m[3]);
     }
 }
 
@@ -182,7 +205,7 @@ static int conv_first_pool_launch_act(AuxArgs &a, hipStream_t st)
     const int bs = 256;
     const int total = a.B * (a.H / 2) * (a.W / 2);
     const int grid = (total + bs - 1) / bs;
-    const size_t lds = a.n * 9 * sizeof(uint32_t);
+    const size_t lds = a.n * 11 * sizeof(uint32_t);
     if (a.store_mode == MI355_STORE_SATURATE)
         hipLaunchKernelGGL((conv_first_pool_u8_kernel<ACT, true>), dim3(grid), dim3(bs), lds, st, a);
     else

@@ -31,44 +31,6 @@
 
 constexpr int SM_PPB = 128;  // pooled pixels per workgroup tile (4 waves x 32 lanes)
 
-// activation + zero point of a requantised value, unwrapped (the byte is this & 0xFF or its clamp)
-template <int ACT>
-__device__ __forceinline__ long small_v_of(int32_t accb, double mp, int zp)
-{
-    const int32_t q = requant_q_exact(accb, mp);
-    if (ACT == MI355_ACT_LEAKY) {
-        if (q >= 0) return (long)zp + q;
-        const uint32_t x = (0u - (uint32_t)q) + 5u;
-        return (long)zp - (long)(x / 10u);
-    }
-    if (ACT == MI355_ACT_RELU6) return (long)zp + (q > 0 ? q : 0);
-    return (long)zp + q;
-}
-
-// [lo, hi]: accumulators (incl. bias and zero-point terms) whose stored byte does not wrap.  Any sub-range of the true
-// one is safe (it only sends more waves down the exact path), so the analytic guess is moved inwards until it verifies.
-template <int ACT>
-__device__ void small_safe_range(double mp, int zp, int32_t &lo, int32_t &hi)
-{
-    // upper end: zp + q <= 255  <=>  q <= 255 - zp, q = trunc(a * mp)
-    double gh = ((double)(256 - zp)) / mp;
-    long h = gh >= 2147483000.0 ? 2147483647L : (long)gh;
-    for (int it = 0; it < 64 && h > -2147483647L && small_v_of<ACT>((int32_t)h, mp, zp) > 255; ++it) h -= (it < 8 ? 1 : 4096);
-    if (small_v_of<ACT>((int32_t)h, mp, zp) > 255) h = -2147483647L - 1;  // give up: nothing is safe
-    hi = (int32_t)h;
-    long l;
-    if (ACT == MI355_ACT_RELU6) {
-        l = -2147483647L - 1;  // zp + max(q, 0) >= zp >= 0
-    } else {
-        const double qlo = (ACT == MI355_ACT_LEAKY) ? -(10.0 * zp + 5.0) : -(double)(zp + 1);
-        const double gl = qlo / mp;
-        l = gl <= -2147483000.0 ? -2147483647L - 1 : (long)gl;
-        for (int it = 0; it < 64 && l < 2147483647L && small_v_of<ACT>((int32_t)l, mp, zp) < 0; ++it) l += (it < 8 ? 1 : 4096);
-        if (small_v_of<ACT>((int32_t)l, mp, zp) < 0) l = 2147483647L;
-    }
-    lo = (int32_t)l;
-}
-
 template <int C, int NM, int ACT, bool SAT>
 __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs a)
 {
