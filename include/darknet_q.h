@@ -82,6 +82,8 @@ struct layer {
 
     /* device side */
     mi355_tensor out_t;            /* PHWC uint8 activations */
+    int out_view;                  /* out_t.data is a channel window of a later route layer's buffer (not owned) */
+    int route_elided;              /* route: every input already writes into out_t (see plan_views) -- no copy at run time */
     void *blob_gpu;                /* packed weights + per-channel params (mi355_conv_pack) */
     size_t blob_bytes;
     void *blob_host;

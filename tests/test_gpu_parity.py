@@ -276,18 +276,20 @@ def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain):
 
 def test_fused_maxpool_net_equals_unfused(cfg_dir, tmp_path):
     """Whole yolov3-tiny, batch 3: the throughput configuration (conv+maxpool fused where possible, pre-pool tensors
-    not stored) yields byte-identical tensors on every layer that is stored in both configurations."""
+    not stored, route inputs written straight into the route buffers) yields byte-identical tensors on every layer
+    that is stored, compared with the plain configuration (every layer in its own buffer, nothing fused: the parity
+    dump mode) and with fusion alone switched off."""
     cfg = os.path.join(cfg_dir, "yolov3-tiny_quant.cfg")
     wts = str(tmp_path / "w.weights")
     synth.synth_weights(cfg, wts, seed=1234)
     xs = synth.synth_image_u8(3, 416, 416, seed=21, batch=3)
     outs = {}
-    for fuse in (False, True):
-        net = binding.Net(cfg, wts, batch=3, fuse_maxpool=fuse)
+    for key, fuse, dump in (("plain", False, True), ("unfused", False, False), ("fast", True, False)):
+        net = binding.Net(cfg, wts, batch=3, fuse_maxpool=fuse, dump_int32=dump)
         net.prepare_fixed(1.0 / 255.0, 0)
         net.push_input(xs)
         net.forward(); net.sync()
-        outs[fuse] = [net.pull(i) for i in range(net.n)]
+        outs[key] = [net.pull(i) for i in range(net.n)]
         info = net.info
         fused_flags = [net.is_fused(i) for i in range(net.n)]
         net.close()
@@ -297,11 +299,15 @@ def test_fused_maxpool_net_equals_unfused(cfg_dir, tmp_path):
         skipped = (inf["type"] == binding.T_CONV and nxt and nxt["type"] == binding.T_MAXPOOL and inf["size"] == 3
                    and nxt["size"] == 2 and nxt["stride"] == 2 and inf["c"] % 64 != 0)
         assert skipped == fused_flags[i]
+        for k in outs["plain"][i]:
+            if k in outs["unfused"][i] and k != "int32":  # accumulators are only dumped in the plain configuration
+                assert np.array_equal(outs["unfused"][i][k], outs["plain"][i][k]), (i, k, "unfused vs plain")
         if skipped:
             fused_convs += 1
             continue  # its own tensor is not stored in the fused configuration
-        for k in outs[True][i]:
-            assert np.array_equal(outs[True][i][k], outs[False][i][k]), (i, k)
+        for k in outs["fast"][i]:
+            if k != "int32":
+                assert np.array_equal(outs["fast"][i][k], outs["plain"][i][k]), (i, k, "fast vs plain")
     assert fused_convs == 3
 
 

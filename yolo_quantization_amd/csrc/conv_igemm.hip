@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         }
     }
     __syncthreads();
-    const int dwords = min(BM, a.out_cs - m0) >> 2;  // dwords of this M tile inside the output cell
+    const int dwords = min(BM, a.out_w - m0) >> 2;  // dwords of this M tile inside the output cell
     if (a.y) {
         // dword-granular copy-out: consecutive lanes -> consecutive dwords of a pixel's channel run (coalesced,
         // conflict-free LDS reads)
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         // four (biased) uint8 values, written straight into the pooled PHWC tensor.
         if (a.ypool) {
             const int OH = a.H >> 1, OW = a.W >> 1;
-            const int pdw = min(BM, a.pool_cs - m0) >> 2;
+            const int pdw = min(BM, a.pool_w - m0) >> 2;
             const int total = (TH / 2) * 8 * pdw;
             for (int p = tid; p < total; p += NT) {
                 const int pp = p / pdw, d = p - pp * pdw;

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     __syncthreads();
     TS(4);
     if (a.y && !DBG(128)) {
-        const int dwords = min(BM, a.out_cs - m0) >> 2;
+        const int dwords = min(BM, a.out_w - m0) >> 2;
         if (dwords == BM / 4) {  // common case: constant divisor
 #pragma unroll 4
             for (int p = tid; p < BN * (BM / 4); p += NT) {

@@ -12,6 +12,7 @@ struct ConvArgs {
     float *y_f32;
     int in_cs, in_lead, in_cells;
     int out_cs, out_lead;
+    int out_w, pool_w;       // bytes of an output / pooled cell this layer may write (16-aligned channel count)
     int B, H, W, n;
     int ksize, cb, nchunks, upc, spc, ksteps;
     int total_n, ntiles_n, mtiles;

@@ -398,6 +398,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     a.y = y ? (uint8_t *)y->data : nullptr; a.acc_out = acc_out; a.y_f32 = y_f32;
     a.in_cs = x->cs; a.in_lead = x->lead; a.in_cells = in_cells;
     a.out_cs = y ? y->cs : 0; a.out_lead = y ? y->lead : 0;
+    a.out_w = y ? ((y->C + 15) & ~15) : 0;  // bytes of a cell this layer owns (y may be a channel window of a wider tensor)
     a.B = x->B; a.H = x->H; a.W = x->W; a.n = d->n;
     a.ksize = d->ksize; a.cb = h.cb; a.nchunks = h.nchunks; a.upc = h.upc; a.spc = h.spc; a.ksteps = h.ksteps;
     a.total_n = total_n;
@@ -405,6 +406,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     a.mpad = h.mpad;
     a.ypool = ypool ? (uint8_t *)ypool->data : nullptr; a.pool_cs = ypool ? ypool->cs : 0;
     a.pool_lead = ypool ? ypool->lead : 0;
+    a.pool_w = ypool ? ((ypool->C + 15) & ~15) : 0;
     a.shift = (const int32_t *)(base + h.off_shift);
     a.mprime = (const double *)(base + h.off_mprime);
     a.cwb = (const int32_t *)(base + h.off_cwb);
@@ -439,7 +441,7 @@ int mi355_maxpool_forward(const mi355_tensor *x, const mi355_tensor *y, int size
     const int oh = (x->H + pad - size) / stride + 1, ow = (x->W + pad - size) / stride + 1;  // ref :31-32
     if (oh != y->H || ow != y->W) return einval("maxpool: output dims");
     PoolArgs a{(const uint8_t *)x->data, (uint8_t *)y->data, x->B, x->H, x->W, oh, ow, x->cs, y->cs, x->lead, y->lead,
-               x->cs / 16, size, stride, -pad / 2};
+               (x->C + 15) / 16, size, stride, -pad / 2};
     return maxpool_launch(a, (hipStream_t)stream);
 }
 
@@ -449,7 +451,7 @@ int mi355_upsample_forward(const mi355_tensor *x, const mi355_tensor *y, int str
     if (x->cs % 16 || y->cs % 16 || x->C != y->C || x->B != y->B || y->H != x->H * stride || y->W != x->W * stride)
         return einval("upsample: shape");
     CopyArgs a{(const uint8_t *)x->data, (uint8_t *)y->data, x->B, x->H, x->W, y->H, y->W, x->cs, y->cs, x->lead,
-               y->lead, x->cs / 16, stride, 0};
+               y->lead, (x->C + 15) / 16, stride, 0};
     return copy_cells_launch(a, (hipStream_t)stream);
 }
 

@@ -69,6 +69,7 @@ static void forward_upsample_layer_quant_gpu(layer l, network net)
 static void forward_route_layer_quant_gpu(layer l, network net)
 {
     const mi355_tensor *xs[16];
+    if (l.route_elided) return; /* the producers wrote straight into this layer's buffer */
     if (l.n > 16) error("route: more than 16 inputs");
     for (int i = 0; i < l.n; ++i) xs[i] = &net.layers[l.input_layers[i]].out_t;
     check_mi355(mi355_route_forward(xs, l.n, &l.out_t, net.stream), "mi355_route_forward");
@@ -222,7 +223,8 @@ layer make_yolo_layer(int batch, int w, int h, int n, int total, int *mask, int 
 
 void free_layer_device(layer *l)
 {
-    if (l->out_t.data) mi355_free(l->out_t.data);
+    if (l->out_t.data && !l->out_view) mi355_free(l->out_t.data);
+    l->out_view = 0; l->route_elided = 0;
     if (l->blob_gpu) mi355_free(l->blob_gpu);
     if (l->weights_uint8_gpu) mi355_free(l->weights_uint8_gpu);
     if (l->weight_zero_point_gpu) mi355_free(l->weight_zero_point_gpu);

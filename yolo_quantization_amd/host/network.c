@@ -171,6 +171,64 @@ static void upload_conv(network *net, int i, int with_raw)
     l->prepared = 1;
 }
 
+/* Concat elimination.  forward_route_layer_quant (ref: src/route_layer.c:107-130) copies its inputs' bytes side by side,
+ * unscaled.  When every input of a route can write its channels straight into the route's buffer -- its out_t becomes a
+ * window (data + channel offset, the route's cell stride) of that buffer -- the copy disappears; a one-input route
+ * simply shares its input's tensor.  A producer qualifies when nothing reads ITS pad cells with a different zero point
+ * (the window's pads are the route's: a 3x3 conv consuming the producer directly needs them to be its own input zero
+ * point), its channel count is a multiple of 16, and it stores its tensor at all (no conv+pool fusion). */
+static int view_producer_ok(network *net, int j, int r)
+{
+    layer *p = &net->layers[j];
+    if (j >= r || p->out_view || p->out_c % 16) return 0;
+    if (p->type != CONVOLUTIONAL && p->type != UPSAMPLE && p->type != MAXPOOL) return 0;
+    if (p->type == CONVOLUTIONAL && (p->fuse_next_pool && net->fuse_maxpool)) return 0;
+    if (j > 0 && net->layers[j - 1].fuse_next_pool && net->fuse_maxpool && p->type == MAXPOOL) return 0; /* written by the fused conv */
+    if (j + 1 < net->n) {
+        layer *c = &net->layers[j + 1];
+        if (c->type == CONVOLUTIONAL && c->size != 1 &&
+            p->activ_data_uint8_zero_point[0] != net->layers[r].activ_data_uint8_zero_point[0]) return 0;
+    }
+    return 1;
+}
+
+static void plan_views(network *net)
+{
+    if (net->dump_int32) return; /* parity dumps keep every tensor in its own buffer */
+    for (int r = 0; r < net->n; ++r) { /* concatenating routes first: their inputs must not be shared tensors yet */
+        layer *l = &net->layers[r];
+        if (l->type != ROUTE || l->n < 2) continue;
+        int ok = 1;
+        for (int k = 0; k < l->n; ++k) {
+            ok &= view_producer_ok(net, l->input_layers[k], r);
+            for (int k2 = 0; k2 < k; ++k2) ok &= l->input_layers[k2] != l->input_layers[k];
+        }
+        if (!ok) continue;
+        int off = 0;
+        for (int k = 0; k < l->n; ++k) {
+            layer *p = &net->layers[l->input_layers[k]];
+            mi355_free(p->out_t.data);
+            p->out_t = l->out_t;
+            p->out_t.data = (char *)l->out_t.data + off;
+            p->out_t.C = p->out_c;
+            p->out_view = 1;
+            off += p->out_c;
+        }
+        l->route_elided = 1;
+    }
+    for (int r = 0; r < net->n; ++r) {
+        layer *l = &net->layers[r];
+        if (l->type != ROUTE || l->n != 1) continue;
+        layer *p = &net->layers[l->input_layers[0]];
+        if (l->input_layers[0] >= r || p->type == YOLO || !p->out_t.data) continue;
+        if (p->type == CONVOLUTIONAL && p->fuse_next_pool && net->fuse_maxpool) continue;
+        mi355_free(l->out_t.data);
+        l->out_t = p->out_t;
+        l->out_view = 1;
+        l->route_elided = 1;
+    }
+}
+
 static void alloc_network_device(network *net)
 {
     check_mi355(mi355_init(net->gpu_index), "mi355_init");
@@ -182,6 +240,7 @@ static void alloc_network_device(network *net)
     check_mi355(mi355_alloc(&net->input_t.data, bytes), "alloc input tensor");
     check_mi355(mi355_tensor_fill(&net->input_t, net->layers[0].input_data_uint8_zero_point[0], net->stream), "fill input");
     for (int i = 0; i < net->n; ++i) alloc_layer_device(net, i);
+    plan_views(net);
     if (net->graph) { mi355_graph_destroy(net->graph); net->graph = NULL; }
 }
 
