@@ -201,7 +201,7 @@ def test_layout_roundtrip_and_pads():
 
 
 @pytest.mark.parametrize("c,n,H,W,act", [(3, 16, 20, 36, "leaky"), (16, 32, 24, 40, "leaky"), (32, 64, 16, 16, "relu6"),
-                                         (48, 32, 10, 34, "linear")])
+                                         (48, 32, 10, 34, "linear"), (3, 32, 34, 70, "relu6"), (3, 16, 18, 30, "linear")])
 @pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
 def test_conv_fused_maxpool_equals_conv_then_pool(c, n, H, W, act, store):
     """mi355_conv_pool_forward == conv + requant + 2x2/2 maxpool of the oracle (pre-pool tensor too), including
@@ -272,6 +272,30 @@ def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain):
     finally:
         binding.shim().mi355_debug_flags(0)
     assert np.array_equal(yp2.to_nchw(), want_pool)
+
+
+@pytest.mark.parametrize("gain", ["no-wrap", "much-wrap"])
+def test_first_layer_mfma_pool_extreme_weight_zero_points(gain):
+    """First-layer MFMA kernel: weight zero points 0 and 255 (128 - zp_w = 128 does not fit the int8 operand of the
+    correction MFMA and is split in two), every batch image, ragged 8x16 pooled patches."""
+    import ctypes as C
+    rng = np.random.default_rng(5 + len(gain))
+    B, c, n, H, W = 3, 3, 16, 38, 46
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    lo, hi = (2.0 ** -12, 2.0 ** -11) if gain == "no-wrap" else (2.0 ** -8, 2.0 ** -5)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3, lo, hi)
+    zp_w[0], zp_w[1], zp_w[2], zp_w[3] = 0, 255, 1, 128
+    if gain == "no-wrap":
+        bias = (bias // 64).astype(np.int32)
+    xt = binding.DevTensor.from_nchw(x, 3)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv))
+    for store in (binding.STORE_WRAP, binding.STORE_SATURATE):
+        yp = binding.DevTensor(B, H // 2, W // 2, n, 23)
+        d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT["leaky"], store, binding.ACC_EXACT, 3, 23, 1.0)
+        binding.check(binding.shim().mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, None, yp.ref(), None), "conv_pool")
+        acc, u8 = _oracle_layer(x, wq, zp_w, 3, 3, bias, mv, sv, 23, oracle.LEAKY, store, oracle.ACC_EXACT)
+        want = np.stack([oracle.maxpool_u8(u8.reshape(B, n, H, W)[b], 2, 2, 1) for b in range(B)])
+        assert np.array_equal(yp.to_nchw(), want), store
 
 
 def test_fused_maxpool_net_equals_unfused(cfg_dir, tmp_path):

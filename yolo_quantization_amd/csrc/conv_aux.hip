@@ -238,3 +238,207 @@ int conv_ref_f32_launch(AuxArgs &a, hipStream_t st)
     hipLaunchKernelGGL(conv_ref_f32_kernel, dim3((unsigned)grid), dim3(bs), 0, st, a);
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// First layer (3 input channels, 4-byte cells) fused with its 2x2 / stride-2 maxpool on the matrix pipe.
+//
+// One V_MFMA_I32_16X16X64_I8 covers a whole 3x3x3 receptive field: k-group g = lane >> 4 (16 bytes) is image row
+// dy = g of the window -- the four cells x-1 .. x+2, i.e. 16 CONTIGUOUS bytes of the row image; the fourth cell and
+// every cell's pad byte meet zero weights, k-group 3 is all zero weights.  Column lane & 15 of the B operand is a
+// pooled pixel, the four MFMAs of a set are the four positions of its 2x2 window, so the window of every
+// (pixel, channel) ends up in one lane (see conv_small.hip for the pooling / requantisation argument: the maximum
+// accumulator is requantised once unless a byte of the window could wrap).  The signed-operand correction
+// (128 - zp_w) * sum(x') is a second MFMA with the constant dz in every real k slot -- two when dz = 128 does not fit
+// an int8 -- instead of per-pixel sums on the VALU.  Weights, corrections and per-channel constants live in registers;
+// a workgroup walks 8 x 16 pooled patches persistently, staging the next 18 x 34 cell image (biased to signed bytes)
+// through registers into a double-buffered LDS plane.  Result bytes are identical to conv_first_pool_u8_kernel's.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ACT, bool SAT, int NM>
+__global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxArgs a)
+{
+    __shared__ uint32_t img[2][18 * 34];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int pc = lane & 15, g = lane >> 4;
+    const int W1 = a.W + 1;
+    const int OH = a.H >> 1, OW = a.W >> 1;
+    const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + 7) >> 3, tpi = tiles_x * tiles_y;
+    const int ntiles = a.B * tpi;
+    const bool pow2 = a.hdr->pow2 == 1;
+
+    // ---- per-lane constants: A fragments (row = channel 16*mt + pc, k-group g), channel parameters of the lane's four
+    //      accumulator rows 16*mt + 4*g + r
+    v4i wa[NM], wd1[NM], wd2[NM], cb[NM], lo[NM], hi[NM];
+    int chq[NM];
+    double mp[NM][4];
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt) {
+        const int ch = 16 * mt + pc;
+        const int dz = a.dzp[ch];
+        const int d1 = dz > 127 ? 127 : dz, d2 = dz - d1;  // dz in [-127, 128]
+        const uint32_t m1 = (uint32_t)(d1 & 0xFF) * 0x00010101u, m2 = (uint32_t)(d2 & 0xFF) * 0x00010101u;
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const bool real = g < 3 && dx < 3;
+            wa[mt][dx] = real ? (int)(a.wfirst[ch * 9 + 3 * g + dx] ^ 0x00808080u) : 0;  // w' = w - 128 on the three channels
+            wd1[mt][dx] = real ? (int)m1 : 0;
+            wd2[mt][dx] = real ? (int)m2 : 0;
+        }
+        chq[mt] = 16 * mt + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c2 = chq[mt] + r;
+            const double m = a.mprime[c2];
+            mp[mt][r] = m;
+            cb[mt][r] = a.cwb[c2];
+            int32_t l = -2147483647 - 1, h = 2147483647;
+            if (!SAT) small_safe_range<ACT>(m, a.zp_act, l, h);
+            lo[mt][r] = l;
+            hi[mt][r] = h;
+        }
+    }
+    bool need_d2 = false;
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt) need_d2 |= __builtin_amdgcn_ballot_w64(wd2[mt][0] != 0) != 0;
+
+    // ---- staging: thread t owns image dwords t, t + 256, t + 512 (< 612): their cell offsets from the tile origin
+    int soff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int slot = min(tid + 256 * k, 18 * 34 - 1);
+        const int r = slot / 34, c = slot - r * 34;
+        soff[k] = r * W1 + c;
+    }
+    const uint32_t *xc = reinterpret_cast<const uint32_t *>(a.x);
+    auto tile_origin = [&](int tile, int &b, int &ty, int &tx) {
+        b = tile / tpi;
+        const int t = tile - b * tpi;
+        ty = t / tiles_x;
+        tx = t - ty * tiles_x;
+    };
+    auto fetch = [&](int tile, uint32_t(&v)[3]) {
+        int b, ty, tx;
+        tile_origin(tile, b, ty, tx);
+        const long org = (long)a.in_lead + (long)(b * (a.H + 1) + 16 * ty) * W1 + 32 * tx - 1;  // image cell (0, 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            long f = org + soff[k];
+            f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
+            v[k] = xc[f];
+        }
+    };
+    auto stash = [&](int buf, const uint32_t(&v)[3]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (tid + 256 * k < 18 * 34) img[buf][tid + 256 * k] = v[k] ^ 0x80808080u;  // x' = x - 128 (pad byte: weight 0)
+    };
+
+    int tile = blockIdx.x;
+    uint32_t nxt[3];
+    if (tile < ntiles) {
+        fetch(tile, nxt);
+        stash(0, nxt);
+    }
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        __syncthreads();  // this tile's image is complete; every wave is past the previous tile
+        const bool more = tile + gridDim.x < ntiles;
+        if (more) fetch(tile + gridDim.x, nxt);
+        int b, ty, tx;
+        tile_origin(tile, b, ty, tx);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int pr = 2 * wave + s;  // pooled row inside the patch
+            const int prow = 8 * ty + pr, pcol = 16 * tx + pc;
+            const bool valid = prow < OH && pcol < OW;
+            // two image rows x five cells feed the four window positions of this lane's k-group
+            const uint32_t *p0 = img[buf] + (2 * pr + (g < 3 ? g : 2)) * 34 + 2 * pc;
+            uint32_t rw[2][5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                rw[0][i] = p0[i];
+                rw[1][i] = p0[34 + i];
+            }
+            const size_t pcell = (size_t)a.pool_lead + ((size_t)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol;
+            uint8_t *outp = a.ypool + pcell * a.pool_cs;
+#pragma unroll
+            for (int mt = 0; mt < NM; ++mt) {
+                v4i acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jy = j >> 1, jx = j & 1;
+                    const v4i bf = {(int)rw[jy][jx], (int)rw[jy][jx + 1], (int)rw[jy][jx + 2], (int)rw[jy][jx + 3]};
+                    v4i t = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[mt], bf, cb[mt], 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd1[mt], bf, t, 0, 0, 0);
+                    if (need_d2) t = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt], bf, t, 0, 0, 0);
+                    acc[j] = t;
+                }
+                int32_t accb[4][4], amax[4][1];
+                bool bad = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accb[r][j] = acc[j][r];
+                    const int32_t mx = max(max(accb[r][0], accb[r][1]), max(accb[r][2], accb[r][3]));
+                    const int32_t mn = min(min(accb[r][0], accb[r][1]), min(accb[r][2], accb[r][3]));
+                    bad |= (mx > hi[mt][r]) | (mn < lo[mt][r]);
+                    amax[r][0] = mx;
+                }
+                int32_t m[4];
+                if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {
+                    int32_t v1[4][1];
+                    requant_values<ACT, SAT, 1>(amax, mp[mt], a.zp_act, v1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m[r] = v1[r][0];
+                } else if (pow2) {
+                    int32_t v[4][4];
+                    requant_values<ACT, SAT, 4>(accb, mp[mt], a.zp_act, v);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int32_t t = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            t = max(t, (int32_t)requant_u8(accb[r][j], 0, a.mval[chq[mt] + r], a.sval[chq[mt] + r], a.zp_act,
+                                                           ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
+                        m[r] = t;
+                    }
+                }
+                if (valid) *reinterpret_cast<uint32_t *>(outp + chq[mt]) = pack4_biased(m[0], m[1], m[2], m[3]);
+            }
+        }
+        if (more) stash(buf ^ 1, nxt);
+    }
+}
+
+template <int ACT, int NM>
+static int first_mfma_launch_sat(AuxArgs &a, hipStream_t st, int grid)
+{
+    if (a.store_mode == MI355_STORE_SATURATE)
+        hipLaunchKernelGGL((conv_first_mfma_pool_kernel<ACT, true, NM>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_first_mfma_pool_kernel<ACT, false, NM>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
+// returns MI355_EINVAL when the shape is outside the MFMA kernel's domain (the caller uses the VALU kernel)
+int conv_first_mfma_pool_launch(AuxArgs &a, hipStream_t st)
+{
+    if ((a.n != 16 && a.n != 32) || a.y || a.acc_out || a.y_f32 || (a.H & 1) || (a.W & 1) || !a.cwb || a.in_cs != 4)
+        return MI355_EINVAL;
+    const int OH = a.H / 2, OW = a.W / 2;
+    const long ntiles = (long)a.B * ((OW + 15) / 16) * ((OH + 7) / 8);
+    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // persistent: four workgroups per CU
+    if (a.n == 16) {
+        if (a.act == MI355_ACT_LEAKY) return first_mfma_launch_sat<MI355_ACT_LEAKY, 1>(a, st, grid);
+        if (a.act == MI355_ACT_RELU6) return first_mfma_launch_sat<MI355_ACT_RELU6, 1>(a, st, grid);
+        return first_mfma_launch_sat<MI355_ACT_LINEAR, 1>(a, st, grid);
+    }
+    if (a.act == MI355_ACT_LEAKY) return first_mfma_launch_sat<MI355_ACT_LEAKY, 2>(a, st, grid);
+    if (a.act == MI355_ACT_RELU6) return first_mfma_launch_sat<MI355_ACT_RELU6, 2>(a, st, grid);
+    return first_mfma_launch_sat<MI355_ACT_LINEAR, 2>(a, st, grid);
+}

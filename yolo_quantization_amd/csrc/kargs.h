@@ -55,6 +55,7 @@ struct AuxArgs {
     uint8_t *ypool;          // fused 2x2/2 maxpool output or null
     int pool_cs, pool_lead;
     const ConvBlobHeader *hdr;  // device copy of the blob header (data-dependent pow2 flag)
+    const int32_t *cwb;         // cw + bias (first-layer MFMA kernel)
 };
 
 struct PoolArgs {
@@ -83,6 +84,7 @@ bool conv_small_eligible(int n, int c, int ksize);
 int mi355_debug_flags_get();
 int conv_first_launch(AuxArgs &a, hipStream_t st);
 int conv_first_pool_launch(AuxArgs &a, hipStream_t st);
+int conv_first_mfma_pool_launch(AuxArgs &a, hipStream_t st);
 int conv_ref_f32_launch(AuxArgs &a, hipStream_t st);
 int maxpool_launch(const PoolArgs &a, hipStream_t st);
 int copy_cells_launch(const CopyArgs &a, hipStream_t st);

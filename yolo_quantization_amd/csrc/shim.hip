@@ -377,6 +377,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
         a.zp_in = d->zp_in; a.zp_act = d->zp_act; a.act = d->activation; a.store_mode = d->store_mode;
         a.s_act = d->s_act; a.total_n = total_n;
         a.mprime = (const double *)(base + h.off_mprime); a.hdr = (const ConvBlobHeader *)base;
+        a.cwb = (const int32_t *)(base + h.off_cwb);
         a.ypool = ypool ? (uint8_t *)ypool->data : nullptr; a.pool_cs = ypool ? ypool->cs : 0;
         a.pool_lead = ypool ? ypool->lead : 0;
         if (d->accum_mode == MI355_ACC_REF_F32) {
@@ -385,7 +386,11 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
             return conv_ref_f32_launch(a, st);
         }
         if (x->cs != 4) return einval("conv_forward: first layer expects a cs==4 image tensor");
-        if (ypool) return conv_first_pool_launch(a, st) == MI355_OK ? MI355_OK : einval("conv_pool_forward: shape not fusable");
+        if (ypool) {
+            int rc = (mi355_debug_flags_get() & 1024) ? MI355_EINVAL : conv_first_mfma_pool_launch(a, st);
+            if (rc == MI355_EINVAL) rc = conv_first_pool_launch(a, st);
+            return rc == MI355_OK ? MI355_OK : einval("conv_pool_forward: shape not fusable");
+        }
         return conv_first_launch(a, st);
     }
     if (x->cs % 16) return einval("conv_forward: x.cs must be a multiple of 16");
