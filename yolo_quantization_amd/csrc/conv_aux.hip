@@ -311,16 +311,26 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         soff[k] = r * W1 + c;
     }
     const uint32_t *xc = reinterpret_cast<const uint32_t *>(a.x);
-    auto tile_origin = [&](int tile, int &b, int &ty, int &tx) {
-        b = tile / tpi;
-        const int t = tile - b * tpi;
-        ty = t / tiles_x;
-        tx = t - ty * tiles_x;
+    // tile walk without per-tile divisions: (b, ty, tx) advances by the decomposition of gridDim.x with carries
+    struct Pos { int b, ty, tx; };
+    auto pos_of = [&](int t) {
+        Pos p;
+        p.b = t / tpi;
+        const int r = t - p.b * tpi;
+        p.ty = r / tiles_x;
+        p.tx = r - p.ty * tiles_x;
+        return p;
     };
-    auto fetch = [&](int tile, uint32_t(&v)[3]) {
-        int b, ty, tx;
-        tile_origin(tile, b, ty, tx);
-        const long org = (long)a.in_lead + (long)(b * (a.H + 1) + 16 * ty) * W1 + 32 * tx - 1;  // image cell (0, 0)
+    const Pos step = pos_of(gridDim.x);
+    auto advance = [&](Pos &p) {
+        p.tx += step.tx;
+        p.ty += step.ty;
+        p.b += step.b;
+        if (p.tx >= tiles_x) { p.tx -= tiles_x; ++p.ty; }
+        if (p.ty >= tiles_y) { p.ty -= tiles_y; ++p.b; }
+    };
+    auto fetch = [&](const Pos &p, uint32_t(&v)[3]) {
+        const long org = (long)a.in_lead + (long)(p.b * (a.H + 1) + 16 * p.ty) * W1 + 32 * p.tx - 1;  // image cell (0, 0)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             long f = org + soff[k];
@@ -335,18 +345,19 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     };
 
     int tile = blockIdx.x;
+    Pos cur = pos_of(tile), nxp = cur;
     uint32_t nxt[3];
     if (tile < ntiles) {
-        fetch(tile, nxt);
+        fetch(cur, nxt);
         stash(0, nxt);
     }
     int buf = 0;
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1, cur = nxp) {
         __syncthreads();  // this tile's image is complete; every wave is past the previous tile
         const bool more = tile + gridDim.x < ntiles;
-        if (more) fetch(tile + gridDim.x, nxt);
-        int b, ty, tx;
-        tile_origin(tile, b, ty, tx);
+        advance(nxp);
+        if (more) fetch(nxp, nxt);
+        const int b = cur.b, ty = cur.ty, tx = cur.tx;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int pr = 2 * wave + s;  // pooled row inside the patch

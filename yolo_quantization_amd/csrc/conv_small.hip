@@ -30,6 +30,7 @@
                  : "memory")
 
 constexpr int SM_PPB = 128;  // pooled pixels per workgroup tile (4 waves x 32 lanes)
+constexpr int SM_KMAX = 6;    // DMA instructions per wave and piece per tile image (image <= 4 * 6 * 64 cells)
 
 template <int C, int NM, int ACT, bool SAT>
 __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs a)
@@ -92,14 +93,60 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
         toff[s] = (t / 3) * rowb + (t % 3) * 16;
     }
 
+    // DMA of a tile's image: instruction k fills cells [64k, 64k + 64) of every piece plane (the last one is shifted
+    // back to end on the plane's last cell); wave w issues k = w, w+4, ..  The lane's cell offset from the tile origin
+    // does not depend on the tile: computed once per slot.
+    int doff[SM_KMAX], dstart[SM_KMAX];
+#pragma unroll
+    for (int i = 0; i < SM_KMAX; ++i) {
+        const int k = wave + 4 * i;
+        dstart[i] = min(k * 64, a.rows_cap * ncell - 64);
+        const int slot = dstart[i] + lane;
+        const int r = slot / ncell, c = slot - r * ncell;
+        doff[i] = r * W1 + c;
+    }
+    auto issue_tile = [&](int gr_first, int col0, int nrows, int parity) {
+        const unsigned buf = lds0 + parity * bbytes;
+        const int ncells = nrows * ncell;
+        const long org = (long)a.in_lead + (long)(gr_first - 1) * W1 + col0;
+#pragma unroll
+        for (int i = 0; i < SM_KMAX; ++i)
+            if ((wave + 4 * i) * 64 < ncells) {
+                long f = org + doff[i];
+                f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
+                const unsigned voff = (unsigned)(f * a.in_cs);
+#pragma unroll
+                for (int p = 0; p < PIECES; ++p) {
+                    const unsigned dst = buf + p * pieceb + dstart[i] * 16;
+                    const unsigned v = voff + p * 16;
+                    DMA_S(dst, a.x, v);
+                }
+            }
+    };
+    // patch walk without per-tile divisions: (b, ty, tx) advances by the decomposition of gridDim.x with carries
+    struct Pos { int b, ty, tx; };
+    auto pos_of = [&](int t) {
+        Pos p{0, 0, 0};
+        if (patch) {
+            p.b = t / tpi;
+            const int r = t - p.b * tpi;
+            p.ty = r / a.tiles_x;
+            p.tx = r - p.ty * a.tiles_x;
+        }
+        return p;
+    };
+    const Pos pstep = pos_of(gridDim.x);
+    auto advance = [&](Pos &p) {
+        p.tx += pstep.tx; p.ty += pstep.ty; p.b += pstep.b;
+        if (p.tx >= a.tiles_x) { p.tx -= a.tiles_x; ++p.ty; }
+        if (p.ty >= a.tiles_y) { p.ty -= a.tiles_y; ++p.b; }
+    };
     // image of a tile: global row (over all image blocks of the PHWC tensor, pad rows included) of its first pre-pool
     // row, x of image cell 0, rows
-    auto tile_geom = [&](int tile, int &gr_first, int &col0, int &nrows) {
+    auto tile_geom = [&](int tile, const Pos &p, int &gr_first, int &col0, int &nrows) {
         if (patch) {
-            const int b = tile / tpi, t = tile - b * tpi;
-            const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-            gr_first = b * (a.H + 1) + 16 * ty + 1;
-            col0 = 32 * tx - 1;
+            gr_first = p.b * (a.H + 1) + 16 * p.ty + 1;
+            col0 = 32 * p.tx - 1;
             nrows = 18;
         } else {
             const int p0 = tile * SM_PPB;
@@ -112,39 +159,27 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
             nrows = gr_last - gr_first + 3;  // + one halo row above and below
         }
     };
-    // DMA of a tile's image: instruction k fills cells [64k, 64k + 64) of every piece plane; wave w issues k = w, w+4, ..
-    auto issue_tile = [&](int tile, int parity) {
-        int gr_first, col0, nrows;
-        tile_geom(tile, gr_first, col0, nrows);
-        const unsigned buf = lds0 + parity * bbytes;
-        const int ncells = nrows * ncell;
-        for (int k = wave; k * 64 < ncells; k += 4) {
-            const int start = min(k * 64, a.rows_cap * ncell - 64);  // the last instruction ends on the plane's last cell
-            const int slot = start + lane;
-            const int r = slot / ncell, c = slot - r * ncell;
-            long f = (long)a.in_lead + (long)(gr_first - 1 + r) * W1 + col0 + c;
-            f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
-            const unsigned voff = (unsigned)(f * a.in_cs);
-#pragma unroll
-            for (int p = 0; p < PIECES; ++p) {
-                const unsigned dst = buf + p * pieceb + start * 16;
-                const unsigned v = voff + p * 16;
-                DMA_S(dst, a.x, v);
-            }
-        }
-    };
 
     int tile = blockIdx.x;
-    if (tile < ntiles) issue_tile(tile, 0);
+    Pos cur = pos_of(tile), nxp = cur;
+    int gr_first = 0, col0 = 0, nrows = 0;
+    if (tile < ntiles) {
+        tile_geom(tile, cur, gr_first, col0, nrows);
+        issue_tile(gr_first, col0, nrows, 0);
+    }
     int parity = 0;
-    for (; tile < ntiles; tile += gridDim.x, parity ^= 1) {
-        int gr_first, col0, nrows;
-        tile_geom(tile, gr_first, col0, nrows);
+    for (; tile < ntiles; tile += gridDim.x, parity ^= 1, cur = nxp) {
+        tile_geom(tile, cur, gr_first, col0, nrows);
         const char *X = smem + parity * bbytes;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the tile's image has landed (and the parameters, first time round); every wave is past the
                           // previous tile, so its buffer may be overwritten
-        if (tile + gridDim.x < ntiles) issue_tile(tile + gridDim.x, parity ^ 1);
+        advance(nxp);
+        if (tile + gridDim.x < ntiles) {
+            int g2, c2, n2;
+            tile_geom(tile + gridDim.x, nxp, g2, c2, n2);
+            issue_tile(g2, c2, n2, parity ^ 1);
+        }
 
         // ---- per-cell channel sums S (the receptive-field sum of x' is the 3x3 box sum of S)
         for (int id = tid; id < nrows * ncell; id += 256) {
@@ -165,11 +200,9 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
         int b, prow, pcol;
         bool valid;
         if (patch) {
-            b = tile / tpi;
-            const int t = tile - b * tpi;
-            const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-            prow = 8 * ty + 2 * wave + (lj >> 4);
-            pcol = 16 * tx + (lj & 15);
+            b = cur.b;
+            prow = 8 * cur.ty + 2 * wave + (lj >> 4);
+            pcol = 16 * cur.tx + (lj & 15);
             valid = prow < OH && pcol < OW;
         } else {
             const int pp = tile * SM_PPB + wave * 32 + lj;
@@ -322,7 +355,7 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
         ntiles = (int)((total_p + SM_PPB - 1) / SM_PPB);
     }
     a.sm_pieceb = a.rows_cap * a.sm_ncell * 16;
-    if (a.rows_cap * a.sm_ncell < 64) return MI355_EINVAL;
+    if (a.rows_cap * a.sm_ncell < 64 || a.rows_cap * a.sm_ncell > 4 * SM_KMAX * 64) return MI355_EINVAL;
     size_t lds = 2 * (size_t)(c / 16) * a.sm_pieceb + (size_t)a.rows_cap * a.sm_ncell * 4;
     lds = (lds + 15) & ~(size_t)15;
     a.lds_param_off = (int)lds;
