@@ -190,6 +190,13 @@ __device__ void small_safe_range(double mp, int zp, int32_t &lo, int32_t &hi)
     lo = (int32_t)l;
 }
 
+// yolo head activation of entry e = channel % (classes + 5): logistic on x, y, objectness and the class scores, identity on
+// w, h (ref: src/yolo_layer.c:132-146, src/activations.h:39; double precision exp as the reference's logistic_activate)
+__device__ __forceinline__ float yolo_entry_act(float v, int e)
+{
+    return (e == 2 || e == 3) ? v : (float)(1. / (1. + exp(-(double)v)));
+}
+
 // low bytes of four ints -> one dword, biased (^0x80): 3 v_perm + 1 v_xor
 __device__ __forceinline__ uint32_t pack4_biased(int32_t v0, int32_t v1, int32_t v2, int32_t v3)
 {

@@ -462,7 +462,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
                             if (nvalid[ns] && (a.acc_out || a.y_f32)) {
                                 const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
                                 if (a.acc_out) a.acc_out[ridx] = accv;
-                                if (a.y_f32) a.y_f32[ridx] = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
+                                if (a.y_f32) {
+                                    const float f = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
+                                    a.y_f32[ridx] = f;
+                                    if (a.yolo_out) a.yolo_out[ridx] = yolo_entry_act(f, oc % a.yolo_per);
+                                }
                             }
                         }
                         packed[ns] |= (u8 ^ 0x80u) << (8 * r);

@@ -75,9 +75,13 @@ extern "C" int mi355_debug_read_wp(long long *host)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),           \
                                      (__attribute__((address_space(3))) void *)(ldst), 16, 0, 0)
 
-// A ring depth: 3 for the plain 1x1 loop, 6 for the software-pipelined 3x3 loop (fragments of step g+1 are read
-// while the MFMAs of step g run, so A(g), A(g+1) are being read while A(g+2) .. A(g+5) are in flight)
-template <int KS> constexpr int ra_stages() { return KS == 3 ? 6 : 3; }
+// A ring depth: 6 for the software-pipelined 3x3 loop (fragments of step g+1 are read while the MFMAs of step g run, so
+// A(g), A(g+1) are being read while A(g+2) .. A(g+5) are in flight); 4 (3 for the widest tiles: LDS) for the plain 1x1
+// loop, which then has its DMA two or three K-steps ahead instead of one -- its K-steps took 0.7 us each, the DMA latency
+template <int KS, int BN> constexpr int ra_stages() { return KS == 3 ? 6 : (BN <= 128 ? 4 : 3); }
+// B buffers: two per-chunk row images for 3x3 (a chunk lasts nine K-steps); for 1x1 every K-step is a new chunk and the
+// row image rides the same ring as the weights
+template <int KS, int BN> constexpr int rb_stages() { return KS == 3 ? 2 : ra_stages<KS, BN>(); }
 // B DMA slots per wave per channel-chunk load: a compile-time constant per configuration (one VGPR of source offset
 // each, issued unconditionally -- slots past a tile's last LDS row repeat its last one), so that every vmcnt wait of
 // the K loop is an immediate.  Sized for the rows a BN-pixel tile spans when the map is at least 3/4 as wide as the
@@ -112,24 +116,26 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     constexpr int PIECEB = RS * 16;     // bytes between 16-byte pieces of a row
     constexpr int CPR = RS / 16;        // 1 KiB DMA chunks per row
     constexpr int OSTR = BM + 4;
-    constexpr int RA_STAGES = ra_stages<KS>();
+    constexpr int RA_STAGES = ra_stages<KS, BN>();
+    constexpr int RB_STAGES = rb_stages<KS, BN>();
     constexpr int NBS = rows_nb_slots(BN, RS, NW, KS);  // B DMA slots per wave per chunk
     constexpr int SPS = (NBS + 3) / 4;                  // ... issued per K-step over a chunk's first four steps (3x3 loop)
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ldsA = smem;                                   // [RA_STAGES][BM*64]
-    char *ldsB = smem + RA_STAGES * BM * 64;             // [2][rows_cap*rowb]
+    char *ldsB = smem + RA_STAGES * BM * 64;             // [RB_STAGES][rows_cap*rowb]
     // bytes between LDS rows: RS*64 of data + a skew of (W mod 16) cells, so that the pixel after a row's last one
     // lands in the next 16-byte bank slot -- a wave's 32 consecutive pixels then never collide across a row wrap
     // (tools/ubench/lds_conflict.hip: 2.1x slower ds_read_b128 for W = 13 without it)
     const int rowb = a.rowb;
     const int bbytes = a.rows_cap * rowb;
-    int *ldsS = reinterpret_cast<int *>(ldsB + 2 * bbytes);  // [rows_cap*RS] receptive-field partial sums per cell
+    int *ldsS = reinterpret_cast<int *>(ldsB + RB_STAGES * bbytes);  // [rows_cap*RS] receptive-field partial sums per cell
     // per-channel epilogue parameters of this M tile, staged once (the epilogue would otherwise issue 5 dependent
     // global loads per output channel per lane): doubles first (8-byte aligned), then the three int planes
     double *ldsPM = reinterpret_cast<double *>(smem + a.lds_param_off);  // [BM] M_value, [BM] shift_value
     int *ldsPI = reinterpret_cast<int *>(ldsPM + 3 * BM);                  // [BM] cw, dzp, bias, cw+bias
+    float *ldsYL = reinterpret_cast<float *>(ldsPI + 4 * BM);              // [256] fused yolo head: logistic of every byte's dequantised value
     // ldsPM: [BM] M_value, [BM] shift_value, [BM] M_value*shift_value
 
     const int tid = threadIdx.x;
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     }
     auto issueB_slots = [&](int chunk, auto lo_c, auto hi_c) {  // slots [LO, HI) of channel chunk `chunk`
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-        const unsigned boff = (chunk & 1) * bbytes;
+        const unsigned boff = (chunk % RB_STAGES) * bbytes;
         int phys = chunk + rot;  // rotated walk, see above
         if (phys >= a.nchunks) phys -= a.nchunks;
         const int8_t *base = a.x + (size_t)phys * 64;
@@ -269,6 +275,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
 
     // zero the S plane, stage the epilogue parameters (both visible after the first barrier of the K loop)
     for (int i = tid; i < a.rows_cap * RS; i += NT) ldsS[i] = 0;
+    if (a.yolo_out)  // a head's float outputs take 256 values: one table instead of a double-precision exp per element
+        for (int i = tid; i < 256; i += NT) ldsYL[i] = yolo_entry_act((float)(i - a.zp_act) * a.s_act, 0);
     for (int i = tid; i < BM; i += NT) {
         const int oc = mtile * BM + i;  // parameter arrays are padded to mpad
         ldsPM[i] = a.mval[oc];
@@ -280,6 +288,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         ldsPM[2 * BM + i] = a.mprime[oc];
     }
 
+    int sxr[NS];  // 1x1 only: the receptive field is the pixel itself -- its channel sum accumulates from the B fragments
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) sxr[ns] = 0;
     auto compute = [&](const char *A, const char *Bt, int tapoff) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -289,6 +300,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
                 const v4i bf = *reinterpret_cast<const v4i *>(Bt + bbase[ns] + tapoff + h * 2 * PIECEB);
+                int t = sxr[ns];
+                t = __builtin_amdgcn_sdot4(bf[0], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(bf[1], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(bf[2], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(bf[3], 0x01010101, t, false);
+                sxr[ns] = t;
 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms)
                     acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
@@ -485,23 +502,34 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     } else {
         TS(1);
         TS(2);
-        issueB(0);
-        issueA_next(0);
-        if (a.ksteps > 1) issueA_next(BM * 64);
-        for (int g0 = 0; g0 < a.ksteps; g0 += 3) {
+        // 1x1: every K-step is one 64-channel chunk; stage g % R1 of both rings holds step g.  A step's DMA group is its
+        // B slots followed by its A slabs (G instructions per wave), issued R1 - 1 steps ahead.
+        constexpr int R1 = RA_STAGES;
+        constexpr int G = NBS + APT;
+        static_assert(RB_STAGES == R1 && (R1 == 3 || R1 == 4), "1x1 loop: common ring depth");
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+        for (int s = 0; s < R1 - 1; ++s)
+            if (s < a.ksteps) {
+                issueB(s);
+                issueA_next(s * (BM * 64));
+            }
+        for (int g0 = 0; g0 < a.ksteps; g0 += R1) {
+#pragma unroll
+            for (int u = 0; u < R1; ++u) {
                 const int g = g0 + u;
                 if (g < a.ksteps) {
-                    // queue: A(g) B(g) A(g+1)  (B(g) was issued in step g-1 before A(g+1))
-                    if (g + 1 < a.ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APT) : "memory");
+                    // group g has to have landed; the groups issued after it (at most R1 - 2) may stay in flight
+                    const int young = min(R1 - 2, a.ksteps - 1 - g);
+                    if (young == R1 - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R1 - 2) * G) : "memory");
+                    else if (young == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    if (g + 1 < a.ksteps) issueB(g + 1);
-                    if (g + 2 < a.ksteps) issueA_next(((u + 2) % 3) * (BM * 64));
-                    const char *Bt = ldsB + (g & 1) * bbytes;
+                    __builtin_amdgcn_s_barrier();  // ... for every wave, and every wave is past step g - 1: its stage is free
+                    if (g + R1 - 1 < a.ksteps) {
+                        issueB(g + R1 - 1);
+                        issueA_next(((u + R1 - 1) % R1) * (BM * 64));
+                    }
+                    const char *Bt = ldsB + u * bbytes;
                     compute(ldsA + u * (BM * 64), Bt, 0);
-                    cell_sums(Bt);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -519,11 +547,15 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
         int t = 0;
-        const int c0 = prow[ns] * RS + pcol[ns];
+        if (KS == 1) {
+            t = sxr[ns] + __shfl_xor(sxr[ns], 32);  // the two 16-byte k-halves of every K-step
+        } else {
+            const int c0 = prow[ns] * RS + pcol[ns];
 #pragma unroll
-        for (int dy = 0; dy < KS; ++dy)
+            for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < KS; ++dx) t += ldsS[c0 + dy * RS + dx];
+                for (int dx = 0; dx < KS; ++dx) t += ldsS[c0 + dy * RS + dx];
+        }
         sx[ns] = t;
     }
     __syncthreads();  // before the LDS is reused as the [BN][BM+4] uint8 output tile
@@ -616,7 +648,14 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
                             if (nvalid[ns] && (a.acc_out || a.y_f32)) {
                                 const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
                                 if (a.acc_out) a.acc_out[ridx] = accv;
-                                if (a.y_f32) a.y_f32[ridx] = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
+                                if (a.y_f32) {
+                                    const float f = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
+                                    a.y_f32[ridx] = f;
+                                    if (a.yolo_out) {
+                                        const int e = oc % a.yolo_per;
+                                        a.yolo_out[ridx] = (e == 2 || e == 3) ? f : ldsYL[u8];
+                                    }
+                                }
                             }
                         }
                         packed[ns] |= (u8 ^ 0x80u) << (8 * r);
@@ -669,12 +708,12 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     if ((ndma + NW - 1) / NW > rows_nb_slots(BN, RS, NW, KS)) return MI355_EINVAL;  // map too narrow for this tile
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     a.rowb = RS * 64 + 16 * (a.W & 15);
-    size_t lds = (size_t)ra_stages<KS>() * BM * 64 + 2 * (size_t)a.rows_cap * a.rowb + (size_t)a.rows_cap * RS * 4;
+    size_t lds = (size_t)ra_stages<KS, BN>() * BM * 64 + (size_t)rb_stages<KS, BN>() * a.rows_cap * a.rowb + (size_t)a.rows_cap * RS * 4;
     const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
     if (lds_epi > lds) lds = lds_epi;
     lds = (lds + 15) & ~(size_t)15;
     a.lds_param_off = (int)lds;  // beyond both the K-loop buffers and the epilogue tile
-    lds += (size_t)BM * 40;
+    lds += (size_t)BM * 40 + 1024;
     if (lds > 160 * 1024) return MI355_EINVAL;
     auto kern = conv_rows_i8_kernel<BM, BN, WMW, WNW, RS, KS>;
     static size_t lds_attr = 0;  // per kernel instantiation: raise the dynamic-LDS limit once, not per launch

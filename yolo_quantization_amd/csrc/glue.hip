@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void yolo_logistic_kernel(const float *in, flo
     if (idx >= total) return;
     const int e = (int)((idx / hw) % per);
     const float v = in[idx];
-    out[idx] = (e == 2 || e == 3) ? v : (float)(1. / (1. + exp(-(double)v)));
+    out[idx] = yolo_entry_act(v, e);
 }
 
 

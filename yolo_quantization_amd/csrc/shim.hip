@@ -343,7 +343,7 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
 // ------------------------------------------------------------------------------------------------ convolution
 static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const uint8_t *w_u8,
                              const uint8_t *zp_w, const mi355_tensor *y, const mi355_tensor *ypool, int32_t *acc_out,
-                             float *y_f32, void *stream)
+                             float *y_f32, void *stream, float *yolo_out = nullptr, int yolo_classes = 0)
 {
     if (!d || !x || !x->data || !blob) return einval("conv_forward: null");
     if (d->stride != 1) return einval("conv_forward: stride must be 1 (3x3 s1 / 1x1 of yolov3-tiny)");
@@ -417,6 +417,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     a.cwb = (const int32_t *)(base + h.off_cwb);
     a.hdr = (const ConvBlobHeader *)base;  // device copy: the kernel reads the data-dependent pow2 flag from it
     a.ws = h.off_ws ? (const int8_t *)(base + h.off_ws) : nullptr;
+    a.yolo_out = yolo_out; a.yolo_per = yolo_classes + 5;
     int rc = MI355_EINVAL;
     if (ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) rc = conv_small_pool_launch(a, st);  // few-channel layers
     if (rc == MI355_EINVAL) rc = conv_igemm_launch(a, st);
@@ -429,6 +430,14 @@ int mi355_conv_forward(const mi355_conv_desc *d, const mi355_tensor *x, const vo
                        const uint8_t *zp_w, const mi355_tensor *y, int32_t *acc_out, float *y_f32, void *stream)
 {
     return conv_forward_impl(d, x, blob, w_u8, zp_w, y, nullptr, acc_out, y_f32, stream);
+}
+
+int mi355_conv_yolo_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const mi355_tensor *y,
+                            float *y_f32, float *yolo_out, int classes, void *stream)
+{
+    if (!d || !y_f32 || !yolo_out || classes < 0 || d->n % (classes + 5)) return einval("conv_yolo_forward: need y_f32, yolo_out and n % (classes + 5) == 0");
+    if (d->accum_mode != MI355_ACC_EXACT || d->c % 16) return einval("conv_yolo_forward: exact mode, c % 16 == 0 only");
+    return conv_forward_impl(d, x, blob, nullptr, nullptr, y, nullptr, nullptr, y_f32, stream, yolo_out, classes);
 }
 
 int mi355_conv_pool_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const mi355_tensor *y,

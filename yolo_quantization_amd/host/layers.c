@@ -47,6 +47,11 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
                     "mi355_conv_pool_forward");
         return;
     }
+    if (net.fused_yolo_out) { /* quant_stop head + the yolo layer after it (ref: src/yolo_layer.c:132-146) in one kernel */
+        check_mi355(mi355_conv_yolo_forward(&d, net.cur_t, l.blob_gpu, &l.out_t, l.output_gpu, net.fused_yolo_out,
+                                            net.fused_yolo_classes, net.stream), "mi355_conv_yolo_forward");
+        return;
+    }
     check_mi355(mi355_conv_forward(&d, net.cur_t, l.blob_gpu, l.weights_uint8_gpu, l.weight_zero_point_gpu, &l.out_t,
                                    net.dump_int32 ? l.output_int32_gpu : NULL,
                                    l.quant_stop_flag ? l.output_gpu : NULL, net.stream),

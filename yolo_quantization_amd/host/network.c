@@ -273,7 +273,13 @@ void quantization_prep_host(network *net, float in_scale, uint8_t in_zp)
  * even map, the conv is 3x3 and nothing else (a route) reads the conv's own output */
 static void plan_fusion(network *net)
 {
-    for (int i = 0; i < net->n; ++i) net->layers[i].fuse_next_pool = 0;
+    for (int i = 0; i < net->n; ++i) net->layers[i].fuse_next_pool = net->layers[i].fuse_next_yolo = 0;
+    for (int i = 0; i + 1 < net->n; ++i) { /* quant_stop head conv + yolo: one kernel writes both float tensors */
+        layer *c = &net->layers[i], *y = &net->layers[i + 1];
+        if (c->type == CONVOLUTIONAL && c->quant_stop_flag && y->type == YOLO && c->c % 16 == 0 &&
+            c->n == y->n * (y->classes + 5))
+            c->fuse_next_yolo = 1;
+    }
     for (int i = 0; i + 1 < net->n; ++i) {
         layer *c = &net->layers[i], *p = &net->layers[i + 1];
         if (c->type != CONVOLUTIONAL || p->type != MAXPOOL) continue;
@@ -387,9 +393,19 @@ static void run_layers(network *netp)
         net.index = i;
         layer l = net.layers[i];
         const int fuse = l.fuse_next_pool && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
+        const int fuse_yolo = l.fuse_next_yolo && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
         net.fused_pool_t = fuse ? &netp->layers[i + 1].out_t : NULL;
+        net.fused_yolo_out = fuse_yolo ? netp->layers[i + 1].output_gpu : NULL;
+        net.fused_yolo_classes = fuse_yolo ? netp->layers[i + 1].classes : 0;
         l.forward_gpu(l, net);
         if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
+        if (fuse_yolo) { /* the yolo layer's activations were written by the conv kernel: skip it */
+            net.cur_t = &netp->layers[i].out_t;
+            ++i;
+            net.cur_f32_gpu = netp->layers[i].output_gpu;
+            if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
+            continue;
+        }
         if (fuse) { /* the maxpool layer already ran inside the conv kernel: hand its tensor on and skip it */
             ++i;
             net.cur_t = &netp->layers[i].out_t;
