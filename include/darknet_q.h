@@ -93,6 +93,7 @@ struct layer {
     float *output_gpu;             /* reference layout float (quant_stop convs, yolo) */
     uint8_t *output_uint8_nchw_gpu; /* scratch for pull_layer_output */
     int fuse_next_pool; /* this conv and the 2x2/2 maxpool after it run as one kernel (set by the prep) */
+    int fuse_next_upsample; /* this conv stores its pixels straight into the upsample layer's tensor after it */
     int fuse_next_yolo; /* this quant_stop head conv also writes the activations of the yolo layer after it */
     int prepared;
 };
@@ -121,6 +122,8 @@ struct network {
     int dump_int32; /* keep int32 accumulators of every conv (parity runs) */
     int fuse_maxpool; /* 1 (default): conv + following 2x2/2 maxpool fused, the pre-pool tensor is not stored.
                          0: every layer writes its own tensor like the reference (per-layer parity dumps) */
+    const mi355_tensor *fused_up_t;   /* run-time: upsampled tensor the conv being run has to fill, or NULL */
+    int fused_up_stride;
     float *fused_yolo_out;            /* run-time: yolo output buffer the conv being run has to fill, or NULL */
     int fused_yolo_classes;
     const mi355_tensor *fused_pool_t; /* executor -> conv forward_gpu: pooled output tensor of the fused pair */

@@ -139,6 +139,12 @@ int mi355_conv_pool_forward(const mi355_conv_desc *desc, const mi355_tensor *x, 
 int mi355_conv_yolo_forward(const mi355_conv_desc *desc, const mi355_tensor *x, const void *blob, const mi355_tensor *y,
                             float *y_f32, float *yolo_out, int classes, void *stream);
 
+/* A convolution fused with the nearest-neighbour upsample layer that follows it (ref: forward_upsample_layer_quant,
+ * src/upsample_layer.c:96-113): y_up is the (stride*H) x (stride*W) tensor, every output pixel is stored stride x stride
+ * times; the conv's own tensor is not stored.  Layers with c % 64 == 0, exact mode.  Identical to conv_forward + upsample_forward. */
+int mi355_conv_upsample_forward(const mi355_conv_desc *desc, const mi355_tensor *x, const void *blob, const mi355_tensor *y_up,
+                                int stride, void *stream);
+
 /* Tile configuration override for benchmarking (0 = auto). */
 int mi355_conv_set_tile(int bm, int bn);
 /* Development switches.  Bits 0..8 are timing ablations of the K loop (no DMA / no s_barrier / no MFMA / ...), compiled

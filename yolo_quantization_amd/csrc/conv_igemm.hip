@@ -659,6 +659,7 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
         if (rc != MI355_EINVAL) return rc;
         a.ntiles_n = 0;
     }
+    if (a.up != 1) return MI355_EINVAL;  // the fused upsample store exists in conv_rows.hip only
     // N-tile mode: PATCH when a 16-wide patch wastes little (W >= 24) -- its halo is (TH+2)x18 cells instead of two
     // full image rows; FLAT for the small maps where a patch would be mostly padding.
     bool patch = a.ksize == 3 && a.W >= 24 && a.H >= 8;

@@ -574,7 +574,14 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         const int y = rem0 / a.W, xx = rem0 - y * a.W;
         pb_[ns] = b;
         rem[ns] = rem0;
-        if (wm == 0 && kh == 0) celltab[nl] = nvalid[ns] ? a.out_lead + (b * (a.H + 1) + (y + 1)) * W1 + xx : -1;
+        if (wm == 0 && kh == 0) {
+            // output cell; with a fused nearest-neighbour upsample (ref: src/upsample_layer.c:96-113) the top-left cell of the
+            // pixel's up x up block in the (up*H) x (up*W) tensor
+            const int up = a.up;
+            celltab[nl] = !nvalid[ns] ? -1
+                          : up == 1   ? a.out_lead + (b * (a.H + 1) + (y + 1)) * W1 + xx
+                                      : a.out_lead + (b * (up * a.H + 1) + (up * y + 1)) * (up * a.W + 1) + up * xx;
+        }
     }
     // Fast path: whole M tile inside n, no parity dumps, power-of-two shifts (always true for the reference's prep):
     // activation and store mode become compile-time constants and the per-output code is branch free.
@@ -670,7 +677,19 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     TS(4);
     if (a.y && !DBG(128)) {
         const int dwords = min(BM, a.out_w - m0) >> 2;
-        if (dwords == BM / 4) {  // common case: constant divisor
+        if (a.up > 1) {  // every pixel is stored up x up times
+            const int total = BN * dwords, rowc = a.up * a.W + 1;
+            for (int p = tid; p < total; p += NT) {
+                const int pix = p / dwords, d = p - pix * dwords;
+                const int cell = celltab[pix];
+                if (cell >= 0) {
+                    const uint32_t v = *reinterpret_cast<const uint32_t *>(otile + pix * OSTR + d * 4);
+                    for (int uy = 0; uy < a.up; ++uy)
+                        for (int ux = 0; ux < a.up; ++ux)
+                            *reinterpret_cast<uint32_t *>(a.y + (size_t)(cell + uy * rowc + ux) * a.out_cs + m0 + d * 4) = v;
+                }
+            }
+        } else if (dwords == BM / 4) {  // common case: constant divisor
 #pragma unroll 4
             for (int p = tid; p < BN * (BM / 4); p += NT) {
                 const int pix = p / (BM / 4), d = p % (BM / 4);

@@ -343,13 +343,13 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
 // ------------------------------------------------------------------------------------------------ convolution
 static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const uint8_t *w_u8,
                              const uint8_t *zp_w, const mi355_tensor *y, const mi355_tensor *ypool, int32_t *acc_out,
-                             float *y_f32, void *stream, float *yolo_out = nullptr, int yolo_classes = 0)
+                             float *y_f32, void *stream, float *yolo_out = nullptr, int yolo_classes = 0, int up = 1)
 {
     if (!d || !x || !x->data || !blob) return einval("conv_forward: null");
     if (d->stride != 1) return einval("conv_forward: stride must be 1 (3x3 s1 / 1x1 of yolov3-tiny)");
     if (!((d->ksize == 3 && d->pad == 1) || (d->ksize == 1 && d->pad == 0))) return einval("conv_forward: ksize/pad");
     if (x->C != d->c) return einval("conv_forward: x.C != desc.c");
-    if (y && (y->C != d->n || y->B != x->B || y->H != x->H || y->W != x->W || !y->data))
+    if (y && (y->C != d->n || y->B != x->B || y->H != x->H * up || y->W != x->W * up || !y->data))
         return einval("conv_forward: y shape");
     if (ypool) {
         if ((x->H & 1) || (x->W & 1) || ypool->C != d->n || ypool->B != x->B || ypool->H != x->H / 2 ||
@@ -418,6 +418,8 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     a.hdr = (const ConvBlobHeader *)base;  // device copy: the kernel reads the data-dependent pow2 flag from it
     a.ws = h.off_ws ? (const int8_t *)(base + h.off_ws) : nullptr;
     a.yolo_out = yolo_out; a.yolo_per = yolo_classes + 5;
+    a.up = up;
+    if (up != 1 && (h.cb != 64 || ypool)) return einval("conv_upsample_forward: 64-channel-chunk layers only");
     int rc = MI355_EINVAL;
     if (ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) rc = conv_small_pool_launch(a, st);  // few-channel layers
     if (rc == MI355_EINVAL) rc = conv_igemm_launch(a, st);
@@ -438,6 +440,14 @@ int mi355_conv_yolo_forward(const mi355_conv_desc *d, const mi355_tensor *x, con
     if (!d || !y_f32 || !yolo_out || classes < 0 || d->n % (classes + 5)) return einval("conv_yolo_forward: need y_f32, yolo_out and n % (classes + 5) == 0");
     if (d->accum_mode != MI355_ACC_EXACT || d->c % 16) return einval("conv_yolo_forward: exact mode, c % 16 == 0 only");
     return conv_forward_impl(d, x, blob, nullptr, nullptr, y, nullptr, nullptr, y_f32, stream, yolo_out, classes);
+}
+
+int mi355_conv_upsample_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const mi355_tensor *y_up,
+                                int stride, void *stream)
+{
+    if (!d || !y_up || stride < 1 || stride > 4) return einval("conv_upsample_forward: y_up, 1 <= stride <= 4");
+    if (d->accum_mode != MI355_ACC_EXACT || d->c % 64) return einval("conv_upsample_forward: exact mode, c % 64 == 0 only");
+    return conv_forward_impl(d, x, blob, nullptr, nullptr, y_up, nullptr, nullptr, nullptr, stream, nullptr, 0, stride);
 }
 
 int mi355_conv_pool_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const mi355_tensor *y,

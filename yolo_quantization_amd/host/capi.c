@@ -62,10 +62,11 @@ int dnq_layer_prep(network *net, int i, int32_t *biases_int32, double *M_value, 
     return 0;
 }
 
-/* 1 when layer i (a conv) runs fused with the maxpool after it in the current configuration: its own uint8 tensor is
- * then not stored (only the pooled one is) */
+/* 1 when layer i (a conv) runs fused with the maxpool / upsample after it in the current configuration: its own uint8
+ * tensor is then not stored (only the pooled / upsampled one is) */
 int dnq_layer_is_fused(network *net, int i)
 {
     if (i < 0 || i >= net->n) return 0;
-    return net->layers[i].fuse_next_pool && net->fuse_maxpool && !net->dump_int32 && net->accum_mode == MI355_ACC_EXACT;
+    return (net->layers[i].fuse_next_pool || net->layers[i].fuse_next_upsample) && net->fuse_maxpool && !net->dump_int32 &&
+           net->accum_mode == MI355_ACC_EXACT;
 }

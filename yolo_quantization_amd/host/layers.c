@@ -47,6 +47,11 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
                     "mi355_conv_pool_forward");
         return;
     }
+    if (net.fused_up_t) { /* this conv + the nearest-neighbour upsample after it; the conv's own tensor is not stored */
+        check_mi355(mi355_conv_upsample_forward(&d, net.cur_t, l.blob_gpu, net.fused_up_t, net.fused_up_stride, net.stream),
+                    "mi355_conv_upsample_forward");
+        return;
+    }
     if (net.fused_yolo_out) { /* quant_stop head + the yolo layer after it (ref: src/yolo_layer.c:132-146) in one kernel */
         check_mi355(mi355_conv_yolo_forward(&d, net.cur_t, l.blob_gpu, &l.out_t, l.output_gpu, net.fused_yolo_out,
                                             net.fused_yolo_classes, net.stream), "mi355_conv_yolo_forward");

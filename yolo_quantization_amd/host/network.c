@@ -274,6 +274,16 @@ void quantization_prep_host(network *net, float in_scale, uint8_t in_zp)
 static void plan_fusion(network *net)
 {
     for (int i = 0; i < net->n; ++i) net->layers[i].fuse_next_pool = net->layers[i].fuse_next_yolo = 0;
+    for (int i = 0; i < net->n; ++i) net->layers[i].fuse_next_upsample = 0;
+    for (int i = 0; i + 1 < net->n; ++i) { /* conv + nearest upsample: the conv stores every pixel stride x stride times */
+        layer *c = &net->layers[i], *u = &net->layers[i + 1];
+        if (c->type != CONVOLUTIONAL || u->type != UPSAMPLE || c->quant_stop_flag || c->c % 64 || u->stride > 4) continue;
+        int used = 0;
+        for (int j = 0; j < net->n; ++j)
+            if (net->layers[j].type == ROUTE)
+                for (int k = 0; k < net->layers[j].n; ++k) used |= net->layers[j].input_layers[k] == i;
+        if (!used) c->fuse_next_upsample = 1;
+    }
     for (int i = 0; i + 1 < net->n; ++i) { /* quant_stop head conv + yolo: one kernel writes both float tensors */
         layer *c = &net->layers[i], *y = &net->layers[i + 1];
         if (c->type == CONVOLUTIONAL && c->quant_stop_flag && y->type == YOLO && c->c % 16 == 0 &&
@@ -393,12 +403,22 @@ static void run_layers(network *netp)
         net.index = i;
         layer l = net.layers[i];
         const int fuse = l.fuse_next_pool && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
-        const int fuse_yolo = l.fuse_next_yolo && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
+        const int fuse_yolo = l.fuse_next_yolo && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
         net.fused_pool_t = fuse ? &netp->layers[i + 1].out_t : NULL;
         net.fused_yolo_out = fuse_yolo ? netp->layers[i + 1].output_gpu : NULL;
         net.fused_yolo_classes = fuse_yolo ? netp->layers[i + 1].classes : 0;
+        const int fuse_up = l.fuse_next_upsample && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
+        net.fused_up_t = fuse_up ? &netp->layers[i + 1].out_t : NULL;
+        net.fused_up_stride = fuse_up ? netp->layers[i + 1].stride : 1;
         l.forward_gpu(l, net);
         if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
+        if (fuse_up) { /* the upsample layer's tensor was written by the conv kernel: hand it on and skip the layer */
+            ++i;
+            net.cur_t = &netp->layers[i].out_t;
+            net.cur_f32_gpu = NULL;
+            if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
+            continue;
+        }
         if (fuse_yolo) { /* the yolo layer's activations were written by the conv kernel: skip it */
             net.cur_t = &netp->layers[i].out_t;
             ++i;
