@@ -256,6 +256,22 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     };
     auto issueB = [&](int chunk) { issueB_slots(chunk, std::integral_constant<int, 0>{}, std::integral_constant<int, NBS>{}); };
 
+    // K-loop prologue DMA, issued as early as its addresses exist: the first weight slabs and the first row image fly
+    // while the accumulators and the epilogue parameters are fetched (3x3: B(0), A(0..4); 1x1: groups 0 .. R-2)
+    TS(1);
+    if constexpr (KS == 3) {
+        issueB(0);
+#pragma unroll
+        for (int st = 0; st < RA_STAGES - 1; ++st) issueA_next(st * (BM * 64));
+    } else {
+#pragma unroll
+        for (int st = 0; st < RA_STAGES - 1; ++st)
+            if (st < a.ksteps) {
+                issueB(st);
+                issueA_next(st * (BM * 64));
+            }
+    }
+
     // accumulators start at the per-channel constant cw + bias (blob plane cwb), so the epilogue does not add it:
     // register grp*4+r of a 32x32 tile holds channel row 8*grp + 4*kh + r (parameter planes are padded to mpad)
     v16i acc[MS][NS];
@@ -404,11 +420,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         using std::integral_constant;
         using std::true_type;
         using std::false_type;
-        // prologue: B(0), A(0..4) (ksteps >= 9); A(0), A(1) (and B(0), older) landed; both k-halves of step 0 on their way
-        TS(1);
-        issueB(0);
-#pragma unroll
-        for (int st = 0; st < R - 1; ++st) issueA_next(st * (BM * 64));
+        // prologue DMA (issued above): B(0), A(0..4) (ksteps >= 9); here A(0), A(1) (and B(0), older) have to have landed;
+        // then both k-halves of step 0 are put on their way
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * APT) : "memory");
         __builtin_amdgcn_s_barrier();
         TS(2);
@@ -500,19 +513,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         WP_FLUSH();
 #undef LDS_READ128
     } else {
-        TS(1);
         TS(2);
         // 1x1: every K-step is one 64-channel chunk; stage g % R1 of both rings holds step g.  A step's DMA group is its
         // B slots followed by its A slabs (G instructions per wave), issued R1 - 1 steps ahead.
         constexpr int R1 = RA_STAGES;
         constexpr int G = NBS + APT;
         static_assert(RB_STAGES == R1 && (R1 == 3 || R1 == 4), "1x1 loop: common ring depth");
-#pragma unroll
-        for (int s = 0; s < R1 - 1; ++s)
-            if (s < a.ksteps) {
-                issueB(s);
-                issueA_next(s * (BM * 64));
-            }
         for (int g0 = 0; g0 < a.ksteps; g0 += R1) {
 #pragma unroll
             for (int u = 0; u < R1; ++u) {
