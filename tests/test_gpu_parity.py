@@ -298,6 +298,52 @@ def test_first_layer_mfma_pool_extreme_weight_zero_points(gain):
         assert np.array_equal(yp.to_nchw(), want), store
 
 
+def test_conv_upsample_and_conv_yolo_entry_points():
+    """The two fused C-ABI entry points against their unfused definitions: mi355_conv_upsample_forward == conv_forward +
+    upsample_forward (also into a channel window of a wider tensor, as the host's concat elimination uses it), and
+    mi355_conv_yolo_forward == conv_forward(y_f32) + yolo_forward, bit for bit."""
+    import ctypes as C
+    S = binding.shim()
+    rng = np.random.default_rng(77)
+    # ---- conv 1x1 256 -> 128 on 13x13, stored 2x upsampled into channels [0, 128) of a 384-channel tensor
+    B, c, n, H, W = 3, 256, 128, 13, 13
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 1)
+    xt = binding.DevTensor.from_nchw(x, 23)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 1, bias, mv, sv))
+    d = binding.ConvDesc(n, c, 1, 1, 0, binding.ACT["leaky"], binding.STORE_WRAP, binding.ACC_EXACT, 23, 23, 1.0)
+    _, u8 = _oracle_layer(x, wq, zp_w, 1, 23, bias, mv, sv, 23, oracle.LEAKY, oracle.STORE_WRAP, oracle.ACC_EXACT)
+    want = np.stack([oracle.upsample_u8(u8.reshape(B, n, H, W)[b], 2) for b in range(B)])
+    wide = binding.DevTensor(B, 2 * H, 2 * W, 384, 23)
+    win = binding.Tensor(wide.t.data, B, 2 * H, 2 * W, n, wide.t.cs, wide.t.lead, wide.t.tail)  # channels 0..127 of `wide`
+    binding.check(S.mi355_conv_upsample_forward(C.byref(d), xt.ref(), blob.ptr, C.byref(win), 2, None), "conv_upsample")
+    binding.check(S.mi355_stream_sync(None), "sync")
+    got = wide.to_nchw()
+    assert np.array_equal(got[:, :n], want)
+    assert (got[:, n:] == 23).all(), "the other channels of the wide tensor keep their fill"
+    # ---- head: conv 1x1 512 -> 30 (3 anchors x (5 classes + 5)) + yolo
+    c, n, classes = 512, 30, 5
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 1, 2.0 ** -13, 2.0 ** -11)
+    xt = binding.DevTensor.from_nchw(x, 23)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 1, bias, mv, sv))
+    d = binding.ConvDesc(n, c, 1, 1, 0, binding.ACT["linear"], binding.STORE_WRAP, binding.ACC_EXACT, 23, 128, 0.0625)
+    cnt = B * n * H * W
+    y = binding.DevTensor(B, H, W, n, 128)
+    f_fused, yo_fused = binding.DevBuf(cnt * 4), binding.DevBuf(cnt * 4)
+    binding.check(S.mi355_conv_yolo_forward(C.byref(d), xt.ref(), blob.ptr, y.ref(), f_fused.ptr, yo_fused.ptr, classes, None), "conv_yolo")
+    y2 = binding.DevTensor(B, H, W, n, 128)
+    f_ref, yo_ref = binding.DevBuf(cnt * 4), binding.DevBuf(cnt * 4)
+    binding.check(S.mi355_conv_forward(C.byref(d), xt.ref(), blob.ptr, None, None, y2.ref(), None, f_ref.ptr, None), "conv")
+    binding.check(S.mi355_yolo_forward(f_ref.ptr, yo_ref.ptr, B, 3, classes, H, W, None), "yolo")
+    binding.check(S.mi355_stream_sync(None), "sync")
+    assert np.array_equal(y.to_nchw(), y2.to_nchw())
+    assert np.array_equal(f_fused.to_numpy(np.float32, cnt), f_ref.to_numpy(np.float32, cnt))
+    assert np.array_equal(yo_fused.to_numpy(np.float32, cnt), yo_ref.to_numpy(np.float32, cnt))
+    _, u8 = _oracle_layer(x, wq, zp_w, 1, 23, bias, mv, sv, 128, oracle.LINEAR, oracle.STORE_WRAP, oracle.ACC_EXACT)
+    assert np.array_equal(f_ref.to_numpy(np.float32, cnt), oracle.dequant(u8, 128, np.float32(0.0625)).ravel())
+
+
 def test_fused_maxpool_net_equals_unfused(cfg_dir, tmp_path):
     """Whole yolov3-tiny, batch 3: the throughput configuration (conv+maxpool fused where possible, pre-pool tensors
     not stored, route inputs written straight into the route buffers) yields byte-identical tensors on every layer

@@ -77,6 +77,8 @@ def shim():
         L.mi355_conv_set_tile.argtypes = [ci, ci]
         L.mi355_conv_pool_forward.argtypes = [C.POINTER(ConvDesc), C.POINTER(Tensor), vp, C.POINTER(Tensor), C.POINTER(Tensor), vp]
         L.mi355_debug_flags.argtypes = [ci]
+        L.mi355_conv_yolo_forward.argtypes = [C.POINTER(ConvDesc), C.POINTER(Tensor), vp, C.POINTER(Tensor), vp, vp, ci, vp]
+        L.mi355_conv_upsample_forward.argtypes = [C.POINTER(ConvDesc), C.POINTER(Tensor), vp, C.POINTER(Tensor), ci, vp]
         L.mi355_maxpool_forward.argtypes = [C.POINTER(Tensor), C.POINTER(Tensor), ci, ci, ci, vp]
         L.mi355_upsample_forward.argtypes = [C.POINTER(Tensor), C.POINTER(Tensor), ci, vp]
         L.mi355_route_forward.argtypes = [C.POINTER(C.POINTER(Tensor)), ci, C.POINTER(Tensor), vp]
