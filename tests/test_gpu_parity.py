@@ -245,6 +245,7 @@ def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain):
     x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
     lo, hi = {"no-wrap": (2.0 ** -17, 2.0 ** -16), "some-wrap": (2.0 ** -14, 2.0 ** -12), "much-wrap": (2.0 ** -11, 2.0 ** -7)}[gain]
     wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3, lo, hi)
+    zp_w[0], zp_w[1], zp_w[2] = 0, 255, 1   # 128 - zp_w = 128 does not fit the int8 operand of the correction MFMA (c = 16)
     if gain != "much-wrap":
         bias = (bias // 16).astype(np.int32)
     zp_in, zp_act = 9, (23 if act != "linear" else 128)

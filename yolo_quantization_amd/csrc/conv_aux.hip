@@ -443,7 +443,7 @@ int conv_first_mfma_pool_launch(AuxArgs &a, hipStream_t st)
         return MI355_EINVAL;
     const int OH = a.H / 2, OW = a.W / 2;
     const long ntiles = (long)a.B * ((OW + 15) / 16) * ((OH + 7) / 8);
-    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // persistent: four workgroups per CU
+    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // persistent: four workgroups per CU (five measured slower)
     if (a.n == 16) {
         if (a.act == MI355_ACT_LEAKY) return first_mfma_launch_sat<MI355_ACT_LEAKY, 1>(a, st, grid);
         if (a.act == MI355_ACT_RELU6) return first_mfma_launch_sat<MI355_ACT_RELU6, 1>(a, st, grid);

@@ -76,9 +76,10 @@ extern "C" int mi355_debug_read_wp(long long *host)
                                      (__attribute__((address_space(3))) void *)(ldst), 16, 0, 0)
 
 // A ring depth: 6 for the software-pipelined 3x3 loop (fragments of step g+1 are read while the MFMAs of step g run, so
-// A(g), A(g+1) are being read while A(g+2) .. A(g+5) are in flight); 4 (3 for the widest tiles: LDS) for the plain 1x1
+// A(g), A(g+1) are being read while A(g+2) .. A(g+5) are in flight) -- 4 in the 128-column configurations, whose LDS
+// then lets two workgroups share a CU (one's epilogue under the other's K loop); 4 (3 for the widest tiles: LDS) for the plain 1x1
 // loop, which then has its DMA two or three K-steps ahead instead of one -- its K-steps took 0.7 us each, the DMA latency
-template <int KS, int BN> constexpr int ra_stages() { return KS == 3 ? 6 : (BN <= 128 ? 4 : 3); }
+template <int KS, int BN> constexpr int ra_stages() { return KS == 3 ? (BN <= 128 ? 4 : 6) : (BN <= 128 ? 4 : 3); }
 // B buffers: two per-chunk row images for 3x3 (a chunk lasts nine K-steps); for 1x1 every K-step is a new chunk and the
 // row image rides the same ring as the weights
 template <int KS, int BN> constexpr int rb_stages() { return KS == 3 ? 2 : ra_stages<KS, BN>(); }
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         //      its barrier: the in-loop stall profile (tools/conv_microbench.py --waveprof) showed the previous
         //      two-set / four-stage loop waiting 8% of its time on vmcnt and ~15% on lgkmcnt.
         constexpr int R = RA_STAGES;
-        static_assert(R == 6, "the table rotation below assumes 9 mod R == 3");
+        static_assert(R == 6 || R == 4, "ring depths the stage bookkeeping below is written for");
+        constexpr int ROT = 9 % R;  // ring phase advance of one channel chunk (nine K-steps)
         v4i fa[3][MS], fb[3][NS];
         // Fragment reads are issued as inline asm so that hipcc does not account for them: its own bookkeeping puts an
         // s_waitcnt lgkmcnt(0) in front of the first MFMA after ANY ds_read.  We count instead: LDS returns in order,
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         using std::false_type;
         // prologue DMA (issued above): B(0), A(0..4) (ksteps >= 9); here A(0), A(1) (and B(0), older) have to have landed;
         // then both k-halves of step 0 are put on their way
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * APT) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * APT) : "memory");
         __builtin_amdgcn_s_barrier();
         TS(2);
 #pragma unroll
@@ -459,18 +461,19 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
                 // for chunk 0 the prologue issued the same DMAs in the same order)
                 constexpr auto n_b = [](int st) { return (LAST || st < 0 || st >= 4) ? 0 : ((st + 1) * SPS < NBS ? (st + 1) * SPS : NBS) - (st * SPS < NBS ? st * SPS : NBS); };
                 constexpr auto n_a = [](int st) { return (st < 0 || !LAST || st + R - 1 < 9) ? APT : 0; };
-                constexpr int YOUNG = n_a(t - 3) + n_b(t - 3) + n_a(t - 2) + n_b(t - 2) + n_a(t - 1) + n_b(t - 1);
+                constexpr int YOUNG = n_a(t - 1) + n_b(t - 1) + (R > 4 ? n_a(t - 2) + n_b(t - 2) + n_a(t - 3) + n_b(t - 3) : 0);
                 constexpr int BLO = t * SPS < NBS ? t * SPS : NBS, BHI = (t + 1) * SPS < NBS ? (t + 1) * SPS : NBS;
                 if (t == 8 && !LAST) {
                     const int bdelta = odd ? -bbytes : bbytes;
+                    unsigned rot[R][MS];
 #pragma unroll
-                    for (int st = 0; st < 3; ++st)
+                    for (int st = 0; st < R; ++st)
 #pragma unroll
-                        for (int ms = 0; ms < MS; ++ms) {
-                            const unsigned sw = aaddr[st][ms];
-                            aaddr[st][ms] = aaddr[st + 3][ms];
-                            aaddr[st + 3][ms] = sw;
-                        }
+                        for (int ms = 0; ms < MS; ++ms) rot[st][ms] = aaddr[(st + ROT) % R][ms];
+#pragma unroll
+                    for (int st = 0; st < R; ++st)
+#pragma unroll
+                        for (int ms = 0; ms < MS; ++ms) aaddr[st][ms] = rot[st][ms];
 #pragma unroll
                     for (int yy = 0; yy < 3; ++yy)
 #pragma unroll
@@ -487,9 +490,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
                      integral_constant<int, 0>{}, integral_constant<bool, RD>{}, true_type{}, [&] {
                          if (!LAST && t < 4 && !DBG(1))
                              issueB_slots(chunk + 1, integral_constant<int, BLO>{}, integral_constant<int, BHI>{});
-                         if (ISSUE_A && !DBG(1)) {  // slab g+5 -> ring stage (3 * odd + t + 5) % 6
-                             constexpr unsigned E = ((t + R - 1) % R) * (BM * 64), O = ((t + R - 1 + 3) % R) * (BM * 64);
-                             issueA_next(odd ? O : E);
+                         if (ISSUE_A && !DBG(1)) {  // slab g+R-1 -> ring stage (9 * chunk + t + R - 1) % R
+                             if constexpr (R == 6) {  // (9 * chunk) % 6 = 3 * odd
+                                 constexpr unsigned E = ((t + R - 1) % R) * (BM * 64), O = ((t + R - 1 + 3) % R) * (BM * 64);
+                                 issueA_next(odd ? O : E);
+                             } else {                 // (9 * chunk) % 4 = chunk % 4
+                                 issueA_next((unsigned)((chunk + t + R - 1) & 3) * (BM * 64));
+                             }
                          }
                      });
                 WP_MARK(3);  // first k-half

@@ -38,6 +38,12 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     constexpr int KST = (C == 16) ? 5 : 9;
     constexpr int PIECES = C / 16;
     constexpr int N = 32 * NM;
+    // C == 16: the signed-operand correction (128 - zp_w) * sum(x') comes from the matrix pipe -- a second pass over
+    // the same B fragments with the constant dz in every real k slot (a third, almost always skipped, for dz = 128,
+    // which does not fit an int8) -- instead of per-cell sums, a 3x3 box sum per pixel and a multiply-add per
+    // accumulator on the VALU, which is the bottleneck of this kernel.  With 32 input channels the extra MFMAs (72 per
+    // wave and tile) would cost more than they save.
+    constexpr bool DZM = (C == 16);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ncell = a.sm_ncell;     // cells of an LDS image row (flat tiles: W + 2, x = -1 .. W; patches: 34)
@@ -82,6 +88,16 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
 #pragma unroll
         for (int s = 0; s < KST; ++s)
             wf[mt][s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(mt * KST + s) * 64 + lane) * 16);
+    int wd1[NM], wd2[NM];  // DZM: dz of this lane's A row, replicated over the four bytes of a dword (split 127 + 1 for 128)
+    bool need_d2 = false;
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt) {
+        const int dz = a.dzp[32 * mt + lj];
+        const int d1 = dz > 127 ? 127 : dz, d2 = dz - d1;
+        wd1[mt] = (int)((uint32_t)(d1 & 0xFF) * 0x01010101u);
+        wd2[mt] = (int)((uint32_t)(d2 & 0xFF) * 0x01010101u);
+        need_d2 |= __builtin_amdgcn_ballot_w64(d2 != 0) != 0;
+    }
 
     // tap byte offsets inside the row image.  C == 16: lane-dependent (k-half = tap parity; tap 9 does not exist, its
     // weights are zero and the lane re-reads tap 8).  C == 32: uniform per step, the k-half selects the piece plane.
@@ -182,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
         }
 
         // ---- per-cell channel sums S (the receptive-field sum of x' is the 3x3 box sum of S)
-        for (int id = tid; id < nrows * ncell; id += 256) {
+        if (!DZM) for (int id = tid; id < nrows * ncell; id += 256) {
             int t = 0;
 #pragma unroll
             for (int p = 0; p < PIECES; ++p) {
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
             }
             ldsS[id] = t;
         }
-        __syncthreads();
+        if (!DZM) __syncthreads();
 
         // ---- this lane's pooled pixel and its 2x2 window in the image
         int b, prow, pcol;
@@ -221,10 +237,12 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
             const int rr = lrow + (j >> 1), cc = lcol + (j & 1);
             base[j] = rr * rowb + cc * 16 + ((C == 32) ? kh * pieceb : 0);
             int t = 0;
+            if (!DZM) {
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) t += ldsS[(rr + dy) * ncell + cc + dx];
+                    for (int dx = 0; dx < 3; ++dx) t += ldsS[(rr + dy) * ncell + cc + dx];
+            }
             sx[j] = t;
         }
         const size_t pcell = (size_t)a.pool_lead + ((size_t)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol;
@@ -249,6 +267,16 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
                 for (int j = 0; j < 4; ++j) {
                     const v4i bf = *reinterpret_cast<const v4i *>(X + base[j] + toff[s]);
                     acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[mt][s], bf, acc[j], 0, 0, 0);
+                    if (DZM) {
+                        // tap 2s + kh: the k-half of the nonexistent tap 9 carries a zero constant
+                        const int z1 = (s == KST - 1 && kh) ? 0 : wd1[mt], z2 = (s == KST - 1 && kh) ? 0 : wd2[mt];
+                        const v4i d1 = {z1, z1, z1, z1};
+                        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(d1, bf, acc[j], 0, 0, 0);
+                        if (need_d2) {
+                            const v4i d2 = {z2, z2, z2, z2};
+                            acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(d2, bf, acc[j], 0, 0, 0);
+                        }
+                    }
                 }
             // ---- epilogue: window max, one requantisation per (pixel, channel), biased packed store
 #pragma unroll
@@ -267,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
                 for (int r = 0; r < 4; ++r) {
                     mp[r] = ldsMP[ch0 + r];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) accb[r][j] = acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
+                    for (int j = 0; j < 4; ++j) accb[r][j] = DZM ? acc[j][grp * 4 + r] : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
                     const int32_t mx = max(max(accb[r][0], accb[r][1]), max(accb[r][2], accb[r][3]));
                     const int32_t mn = min(min(accb[r][0], accb[r][1]), min(accb[r][2], accb[r][3]));
                     bad |= (mx > hiv[r]) | (mn < lov[r]);
@@ -361,7 +389,9 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
     a.lds_param_off = (int)lds;
     lds += (size_t)a.n * 24;
     if (lds > 160 * 1024) return MI355_EINVAL;
-    const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
+    // persistent workgroups per CU: LDS permitting; the c = 16, n = 32 variant needs few enough registers for three
+    int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
+    if (c == 16 && a.n == 32 && 3 * lds <= 160 * 1024) per_cu = 3;
     const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
     if (c == 16 && a.n == 32) return small_launch_act<16, 1>(a, st, grid, lds);
     if (c == 16 && a.n == 64) return small_launch_act<16, 2>(a, st, grid, lds);
