@@ -1,22 +1,27 @@
 // conv_rows.hip -- the MFMA implicit-GEMM INT8 convolution for layers whose input channels come in 64-byte chunks
 // (every 3x3 s1 / 1x1 layer of yolov3-tiny from the 4th conv on, and BASELINE config[1]).  Same mathematics as
 // conv_igemm.hip (read its header for the signed-operand decomposition); what differs is the inner loop, which is
-// built so that a K-step is almost nothing but 8 ds_read_b128 + 8 V_MFMA_I32_32X32X32_I8:
+// built so that a K-step is almost nothing but ds_read_b128 + V_MFMA_I32_32X32X32_I8:
 //
 //   * LDS image of the B operand = whole image ROWS of the PHWC tensor, RS cells per row (RS = 16/32/64 >= W+2,
-//     a template constant), stored per row as [16-byte piece][RS cells][16 B].  A 3x3 tap (dy,dx) is then the
-//     compile-time byte offset dy*RS*64 + dx*16 from the lane's own pixel: every B fragment address is
-//     `lane base + immediate`, no per-step address arithmetic.  Consecutive lanes read consecutive 16-byte slots
-//     (conflict-free ds_read_b128 lane groups).
-//   * the receptive-field sums  sum_k x'  (needed because V_MFMA_*_I8 is signed x signed, see conv_igemm.hip) are NOT
-//     accumulated from the fragments any more (that cost 16 v_dot4 per K-step per wave): once per channel chunk every
-//     thread reduces one LDS cell (4 ds_read_b128 + 16 v_dot4) into an LDS int32 plane S[cell]; the epilogue forms the
-//     3x3 box sum of S.  9x less VALU work than per-tap accumulation.
-//   * A operand: 3-stage DMA ring (global_load_lds_dwordx4), B operand: double-buffered per channel chunk, DMA two
-//     K-steps ahead, one s_barrier per K-step, counted vmcnt waits -- as in conv_igemm.hip.
+//     a template constant), stored per row as [16-byte piece][RS cells][16 B], rows skewed by W mod 16 cells so that a
+//     wave's 32 consecutive pixels never collide in a bank across a row wrap.  A 3x3 tap (dy,dx) is a per-row table
+//     entry plus the immediate dx*16: no per-step address arithmetic.
+//   * the receptive-field sums  sum_k x'  (needed because V_MFMA_*_I8 is signed x signed) are reduced once per channel
+//     chunk from the landed row image into an LDS int32 plane S[cell]; the epilogue forms the 3x3 box sum of S
+//     (1x1: straight from the B fragments in registers).
+//   * A operand: 6-stage DMA ring five K-steps ahead (4 stages in the 128-column configurations, the 1x1 loop 3-4 for
+//     A and B alike); B operand: double-buffered per channel chunk, its DMA slots spread over a chunk's first four
+//     K-steps.  LDS-DMA (global_load_lds_dwordx4) is written by hand with scalar bases; one s_barrier per K-step.
+//   * 3x3 K loop: nine K-steps per chunk fully unrolled in a steady-state and a last-chunk variant, every vmcnt /
+//     lgkmcnt wait an immediate; three fragment register sets, a set is read one K-step before its MFMAs and the
+//     reads are threaded between the MFMAs of the previous sets.
+//   * N tiles split the pixel range evenly (host-side tile planner in conv_igemm_launch), 32-column sub-tiles are dealt
+//     round-robin to the N waves, workgroups walk the channel chunks in rotated order.
+//   * epilogue: accumulators start at cw + bias, one FP64 multiply per output (folded multiplier), branch-free leaky,
+//     LDS-transposed stores; optional fused nearest-neighbour upsample store and fused yolo head activations.
 //
-// Measured motivation (profiles/r01_*): with per-step address arithmetic and per-tap v_dot4 the kernel issued ~67
-// VALU + 44 SALU instructions per 8 MFMAs and SQ_VALU_MFMA_COEXEC_CYCLES showed they do not overlap the matrix pipe.
+// Measured motivation and the microbenchmarks behind each of these choices: DESIGN.md section 3.1, profiles/r01_*.
 #include "kargs.h"
 #include <type_traits>
 
