@@ -80,8 +80,9 @@ def test_conv_mfma_bit_exact(case, store):
         assert (sat != u8).any(), "case should exercise out-of-range (wrap != saturate) elements"
     # the throughput path: no dumps requested -> the kernels take their specialised (branch-free) epilogue
     fast = binding.conv_forward(xt, wq, zp_w, k, bias, mv, sv, zp_in, zp_act, 0.05, binding.ACT[act], store,
-                                binding.ACC_EXACT, want_acc=False)
+                                binding.ACC_EXACT, want_acc=False, want_f32=True)
     assert np.array_equal(fast["u8"].reshape(B, n, H * W), u8), "uint8 activations, fast epilogue"
+    assert np.array_equal(fast["f32"], f32), "quant_stop float tail, fast epilogue"
 
 
 @pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])

@@ -601,9 +601,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
                                       : a.out_lead + (b * (up * a.H + 1) + (up * y + 1)) * (up * a.W + 1) + up * xx;
         }
     }
-    // Fast path: whole M tile inside n, no parity dumps, power-of-two shifts (always true for the reference's prep):
-    // activation and store mode become compile-time constants and the per-output code is branch free.
-    const bool fast = !a.acc_out && !a.y_f32 && (m0 + BM <= a.n) && a.hdr->pow2 == 1;
+    // Fast path: no int32 parity dump, power-of-two shifts (always true for the reference's prep): activation and store
+    // mode become compile-time constants and the per-output code is branch free.  Channels past n (the parameter planes
+    // are zero-padded to mpad) produce bytes nobody reads; the float tail of a quant_stop head skips them.
+    const bool fast = !a.acc_out && a.hdr->pow2 == 1;
     auto epi_fast = [&](auto act_c, auto sat_c) {
         constexpr int ACT = decltype(act_c)::value;
         constexpr bool SAT = decltype(sat_c)::value != 0;
@@ -623,10 +624,29 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
                     for (int ns = 0; ns < NS; ++ns)  // |dz| <= 128, |sx| < 2^23 (K <= 64K): 24-bit multiply, full rate
                         accb[r][ns] = acc[ms][ns][grp * 4 + r] + __mul24(dzv[r], sx[ns]);
                 }
-                uint32_t packed[NS];
-                requant_group<ACT, SAT, NS>(accb, mp, a.zp_act, packed);
+                int32_t v[4][NS];
+                requant_values<ACT, SAT, NS>(accb, mp, a.zp_act, v);
 #pragma unroll
-                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
+                for (int ns = 0; ns < NS; ++ns)
+                    *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = pack4_biased(v[0][ns], v[1][ns], v[2][ns], v[3][ns]);
+                if (a.y_f32) {  // quant_stop tail (ref :752-760) and, fused, the yolo layer's activations
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int oc = m0 + ocl + r;
+                        if (oc < a.n) {
+                            const int e = a.yolo_out ? oc % a.yolo_per : 0;
+#pragma unroll
+                            for (int ns = 0; ns < NS; ++ns)
+                                if (nvalid[ns]) {
+                                    const int u8 = v[r][ns] & 0xFF;
+                                    const float f = (float)(u8 - a.zp_act) * a.s_act;
+                                    const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
+                                    a.y_f32[ridx] = f;
+                                    if (a.yolo_out) a.yolo_out[ridx] = (e == 2 || e == 3) ? f : ldsYL[u8];
+                                }
+                        }
+                    }
+                }
             }
         }
     };
