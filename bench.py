@@ -34,6 +34,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8, help="bounded CPU-baseline sample (images through the reference)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
+    ap.add_argument("--cpu-omp", action="store_true", help="also time the reference's OpenMP build on all host cores (extra JSON key)")
     return ap.parse_args()
 
 
@@ -62,18 +63,19 @@ def pmc_traffic_per_launch():
     return tot / n
 
 
-def cpu_baseline(cfg, wts, nimg):
-    """The reference itself (oracle/_ref/libdarknet_ref.so, Makefile-default build, 1 thread) timed on this box's host
-    cores on a bounded sample; falls back to the CPU restatement ('port') if the prebuilt reference is absent."""
+def cpu_baseline(cfg, wts, nimg, omp=False):
+    """The reference itself (oracle/_ref/libdarknet_ref.so, Makefile-default build, 1 thread; omp=True: its MULTI_CORE=1
+    OpenMP flavour on every host core) timed on this box's host cores on a bounded sample; falls back to the CPU
+    restatement ('port') if the prebuilt reference is absent."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     from yolo_quantization_amd import synth
     x = synth.synth_image_u8(3, 416, 416, seed=7)
     try:
         import refdrv
-        if not refdrv.available():
+        if not refdrv.available(omp):
             raise FileNotFoundError("oracle/_ref not built")
-        net = refdrv.RefNet(cfg, wts)
+        net = refdrv.RefNet(cfg, wts, omp=omp)
         net.prepare(synth.image_u8_to_float(x))
         t0 = time.time()
         for _ in range(nimg):
@@ -91,7 +93,7 @@ def cpu_baseline(cfg, wts, nimg):
             onet.forward(x, accum=oracle.ACC_REF_F32)
         dt = time.time() - t0
         kind = "port"
-    return {"value": nimg / dt, "unit": "images/s", "cores": 1, "kind": kind,
+    return {"value": nimg / dt, "unit": "images/s", "cores": (os.cpu_count() if omp and kind == "reference" else 1), "kind": kind,
             "sample": f"{nimg} x yolov3-tiny 416x416 image, whole net, batch 1, {os.cpu_count()} host cores present"}
 
 
@@ -214,9 +216,11 @@ def main():
             for r in layers:
                 print("[layer]", json.dumps(r), file=sys.stderr)
 
-    cpu = None
+    cpu = cpu_omp = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cfg, wts, args.cpu_images)
+        if args.cpu_omp:
+            cpu_omp = cpu_baseline(args.cfg, wts, args.cpu_images * 4, omp=True)
 
     if rank == 0:
         out = {"metric": "images/sec yolov3-tiny INT8 416x416", "value": round(value, 1), "unit": "images/s",
@@ -229,6 +233,8 @@ def main():
                           "launch": "hipGraph replay" if args.graph else f"eager; per-layer HIP events on every {prof_stride}th step of the timed region",
                           "weight_broadcast_ms": round(bcast_ms, 3)},
                "roofline": roof, "cpu_baseline": cpu}
+        if cpu_omp:
+            out["cpu_baseline_allcores"] = cpu_omp
         if layers:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             json.dump({"ms_per_step": ms_per_step, "layers": layers},
