@@ -106,7 +106,7 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *weights_uint8, const
                     const int32_t *biases_int32, const double *M_value, const double *shift_value, void *blob);
 
 typedef struct mi355_conv_desc {
-    int n, c, ksize, stride, pad; /* filters, input channels, 1|3, 1, ksize/2 */
+    int n, c, ksize, stride, pad; /* filters, input channels, 1|3, 1|2, ksize/2 (stride 2: plain exact-mode convs, c % 16 == 0) */
     int activation;               /* MI355_ACT_* */
     int store_mode;               /* MI355_STORE_* */
     int accum_mode;               /* MI355_ACC_* */

@@ -35,11 +35,11 @@ def _rand_layer(rng, n, c, k, m_lo=2.0 ** -11, m_hi=2.0 ** -7):
     return wq, zp_w, bias, M0 * 2.0 ** -31, 2.0 ** -shift.astype(np.float64)
 
 
-def _oracle_layer(x, wq, zp_w, k, zp_in, bias, mv, sv, zp_act, act, store, accum):
+def _oracle_layer(x, wq, zp_w, k, zp_in, bias, mv, sv, zp_act, act, store, accum, stride=1):
     B = x.shape[0]
     accs, u8s = [], []
     for b in range(B):
-        a = oracle.conv_acc(x[b], wq, zp_w, k, 1, k // 2, zp_in, accum)
+        a = oracle.conv_acc(x[b], wq, zp_w, k, stride, k // 2, zp_in, accum)
         accs.append(a)
         u8s.append(oracle.requant(a, bias, mv, sv, zp_act, act, store))
     return np.stack(accs), np.stack(u8s)
@@ -98,6 +98,30 @@ def test_conv_fast_epilogue_huge_requantised_values(c, n, k, H, W, store):
     acc, u8 = _oracle_layer(x, wq, zp_w, k, 17, bias, mv, sv, 23, oracle.LEAKY, store, oracle.ACC_EXACT)
     assert np.abs(acc).max() * mv.max() * sv.max() > 45000
     assert np.array_equal(got["u8"].reshape(2, n, H * W), u8)
+
+
+@pytest.mark.parametrize("B,c,n,H,W,k", [(2, 32, 64, 40, 38, 3), (1, 64, 128, 76, 76, 3), (2, 128, 256, 19, 21, 3),
+                                          (1, 16, 32, 31, 50, 3), (1, 256, 512, 38, 38, 3), (3, 48, 40, 9, 11, 3)])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+def test_conv_stride2(B, c, n, H, W, k, store):
+    """Stride-2 convolutions (the downsampling layers of full YOLOv3, BASELINE config[4]; ref: the same
+    forward_convolutional_layer_quant_inputi_outputi, im2col with stride 2): accumulators, bytes and the float tail
+    against the oracle, odd and even maps, dump path and fast epilogue."""
+    rng = np.random.default_rng(B + c + n + H + W)
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, k)
+    xt = binding.DevTensor.from_nchw(x, 11)
+    got = binding.conv_forward(xt, wq, zp_w, k, bias, mv, sv, 11, 23, 0.05, binding.ACT["leaky"], store, binding.ACC_EXACT,
+                               want_acc=True, want_f32=True, stride=2)
+    acc, u8 = _oracle_layer(x, wq, zp_w, k, 11, bias, mv, sv, 23, oracle.LEAKY, store, oracle.ACC_EXACT, stride=2)
+    OH, OW = (H + 2 * (k // 2) - k) // 2 + 1, (W + 2 * (k // 2) - k) // 2 + 1
+    assert acc.shape == (B, n, OH * OW)
+    assert np.array_equal(got["int32"], acc), "int32 pre-requant accumulators"
+    assert np.array_equal(got["u8"].reshape(B, n, OH * OW), u8), "uint8 activations"
+    assert np.array_equal(got["f32"], oracle.dequant(u8, 23, np.float32(0.05)))
+    fast = binding.conv_forward(xt, wq, zp_w, k, bias, mv, sv, 11, 23, 0.05, binding.ACT["leaky"], store, binding.ACC_EXACT,
+                                want_acc=False, stride=2)
+    assert np.array_equal(fast["u8"].reshape(B, n, OH * OW), u8), "uint8 activations, fast epilogue"
 
 
 @pytest.mark.parametrize("bm,bn,nt", [(128, 256, 0), (128, 128, 0), (64, 256, 0), (64, 128, 0), (32, 256, 0), (32, 128, 0),

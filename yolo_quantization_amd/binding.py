@@ -182,26 +182,28 @@ def conv_pack(wq, zp_w, c, ksize, biases_int32, M_value, shift_value):
 
 
 def conv_forward(x: DevTensor, wq, zp_w, ksize, biases_int32, M_value, shift_value, zp_in, zp_act, s_act,
-                 activation, store=STORE_WRAP, accum=ACC_EXACT, want_acc=True, want_f32=False):
+                 activation, store=STORE_WRAP, accum=ACC_EXACT, want_acc=True, want_f32=False, stride=1):
     """One quantized conv layer through the C-ABI. Returns dict(u8 NCHW, int32 [B,n,HW], f32)."""
     n = wq.shape[0]
     c = x.t.C
     blob = DevBuf.from_numpy(conv_pack(wq, zp_w, c, ksize, biases_int32, M_value, shift_value))
     wraw = DevBuf.from_numpy(np.ascontiguousarray(wq, np.uint8))
     zraw = DevBuf.from_numpy(np.ascontiguousarray(zp_w, np.uint8))
-    y = DevTensor(x.t.B, x.t.H, x.t.W, n, zp_act)
-    cnt = x.t.B * n * x.t.H * x.t.W
+    pad = ksize // 2
+    OH, OW = (x.t.H + 2 * pad - ksize) // stride + 1, (x.t.W + 2 * pad - ksize) // stride + 1
+    y = DevTensor(x.t.B, OH, OW, n, zp_act)
+    cnt = x.t.B * n * OH * OW
     acc = DevBuf(cnt * 4) if want_acc else None
     f32 = DevBuf(cnt * 4) if want_f32 else None
-    d = ConvDesc(n, c, ksize, 1, ksize // 2, activation, store, accum, zp_in, zp_act, float(s_act))
+    d = ConvDesc(n, c, ksize, stride, pad, activation, store, accum, zp_in, zp_act, float(s_act))
     check(shim().mi355_conv_forward(C.byref(d), x.ref(), blob.ptr, wraw.ptr, zraw.ptr, y.ref(),
                                     acc.ptr if acc else None, f32.ptr if f32 else None, None), "conv_forward")
     check(shim().mi355_stream_sync(None), "sync")
     out = {"u8": y.to_nchw(), "tensor": y}
     if acc:
-        out["int32"] = acc.to_numpy(np.int32, cnt).reshape(x.t.B, n, x.t.H * x.t.W)
+        out["int32"] = acc.to_numpy(np.int32, cnt).reshape(x.t.B, n, OH * OW)
     if f32:
-        out["f32"] = f32.to_numpy(np.float32, cnt).reshape(x.t.B, n, x.t.H * x.t.W)
+        out["f32"] = f32.to_numpy(np.float32, cnt).reshape(x.t.B, n, OH * OW)
     return out
 
 

@@ -62,7 +62,8 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 }
 
 constexpr int A_STAGES = 3;
-constexpr int BPT_MAX = 8;  // B DMA instructions per wave per chunk load (upper bound)
+constexpr int BPT_MAX = 12;  // B DMA instructions per wave per chunk load (upper bound; stride-2 patches need 9)
+#define APT_OF(BM, NW) (((BM) / 16 + (NW) - 1) / (NW))
 
 // KMODE: 0 = generic K loop (any cb, any ksize); 3 = cb==64 && ksize==3 (taps unrolled, address tables);
 //        1 = cb==64 && ksize==1
@@ -100,7 +101,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
     const int mtile = logical / a.ntiles_n;
     const int ntile = logical - mtile * a.ntiles_n;
 
-    const int W1 = a.W + 1, hw = a.H * a.W;
+    const int W1 = a.W + 1;                    // input row pitch in cells
+    const int OW1 = a.OW + 1, hw = a.OH * a.OW;  // output geometry (== input for stride 1)
+    const int cs = a.stride;                   // PATCH mode only: 1 or 2
     const int cb = a.cb, bpc = cb >> 4;
     const int bpc_sh = (bpc == 4) ? 2 : (bpc == 2 ? 1 : 0);
     const int cpc_sh = 6 - bpc_sh, cpc = 1 << cpc_sh;     // cells per 1 KiB LDS chunk
@@ -116,9 +119,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         pb = ntile / tpi;
         const int t = ntile - pb * tpi;
         const int ty = t / a.tiles_x;
-        py0 = ty * TH;
+        py0 = ty * TH;                       // patch origin in OUTPUT pixels
         px0 = (t - ty * a.tiles_x) * TW;
-        rs = TW + 2;
+        rs = (TW - 1) * cs + 3;              // input cells per LDS row: the patch's columns at stride cs + one halo cell each side
     } else {
         n0 = ntile * BN;
         const int nlast = min(n0 + BN, a.total_n) - 1;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
     for (int ns = 0; ns < NS; ++ns) {
         const int nl = wn * TN + ns * 32 + lj;
         if constexpr (PATCH) {
-            bcell[ns] = ((nl >> 4) + 1) * rs + (nl & 15) + 1;
+            bcell[ns] = (cs * (nl >> 4) + 1) * rs + cs * (nl & 15) + 1;  // centre tap of output pixel (nl/16, nl%16)
         } else {
             const int n = min(n0 + nl, a.total_n - 1);
             bcell[ns] = cell_of_pixel(n, a.H, a.W, a.in_lead) - fstart;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         long f;
         if constexpr (PATCH) {
             const int rr = lc / rs, cc = lc - rr * rs;
-            f = (long)a.in_lead + ((long)pb * (a.H + 1) + (py0 + rr)) * W1 + (px0 - 1 + cc);
+            f = (long)a.in_lead + ((long)pb * (a.H + 1) + (cs * py0 + rr)) * W1 + (cs * px0 - 1 + cc);
         } else {
             f = (long)fstart + lc;
         }
@@ -376,18 +379,18 @@ __global__ __launch_bounds__(64 * WMW * WNW, (WMW * WNW == 8) ? 4 : 2) void conv
         int b, y, xx;
         if constexpr (PATCH) {
             b = pb; y = py0 + (nl >> 4); xx = px0 + (nl & 15);
-            nvalid[ns] = y < a.H && xx < a.W;
+            nvalid[ns] = y < a.OH && xx < a.OW;
         } else {
             const int n = n0 + nl;
             nvalid[ns] = n < a.total_n;
             const int nn = nvalid[ns] ? n : 0;
             b = nn / hw;
             const int rem0 = nn - b * hw;
-            y = rem0 / a.W; xx = rem0 - y * a.W;
+            y = rem0 / a.OW; xx = rem0 - y * a.OW;
         }
         pb_[ns] = b;
-        rem[ns] = y * a.W + xx;
-        if (wm == 0 && kh == 0) celltab[nl] = nvalid[ns] ? a.out_lead + (b * (a.H + 1) + (y + 1)) * W1 + xx : -1;
+        rem[ns] = y * a.OW + xx;
+        if (wm == 0 && kh == 0) celltab[nl] = nvalid[ns] ? a.out_lead + (b * (a.OH + 1) + (y + 1)) * OW1 + xx : -1;
     }
     // Fast path: whole M tile inside n, no parity dumps, power-of-two shifts (always true for the reference's prep):
     // compile-time activation / store mode, folded single-multiply requantise (csrc/common.h requant_group).
@@ -560,11 +563,12 @@ static int launch_cfg(ConvArgs &a, hipStream_t st)
     int ncell;
     if (PATCH) {
         constexpr int TH = BN / 16, TW = 16;
-        a.tiles_x = (a.W + TW - 1) / TW;
-        a.tiles_y = (a.H + TH - 1) / TH;
+        a.tiles_x = (a.OW + TW - 1) / TW;
+        a.tiles_y = (a.OH + TH - 1) / TH;
         a.ntiles_n = a.B * a.tiles_x * a.tiles_y;
-        ncell = (TH + 2) * (TW + 2);
+        ncell = ((TH - 1) * a.stride + 3) * ((TW - 1) * a.stride + 3);  // input patch incl. the 3x3 halo
     } else {
+        if (a.stride != 1) return MI355_EINVAL;
         a.ntiles_n = (a.total_n + BN - 1) / BN;
         const int halo = (a.ksize == 3) ? (a.W + 2) : 0;
         // pixels + row pads + image-boundary pad rows, + halo both sides
@@ -573,7 +577,7 @@ static int launch_cfg(ConvArgs &a, hipStream_t st)
     }
     a.bchunks = (ncell + cpc - 1) / cpc;
     a.bpt = (a.bchunks + NW - 1) / NW;
-    if (a.bpt > BPT_MAX || 2 + a.bpt > 18) return MI355_EINVAL;
+    if (a.bpt > BPT_MAX || APT_OF(BM, NW) + a.bpt > 20) return MI355_EINVAL;
     size_t lds = (size_t)A_STAGES * BM * 64 + 2 * ((size_t)a.bchunks << 10);
     const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
     if (lds_epi > lds) lds = lds_epi;
@@ -620,7 +624,7 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
     int bm = g_force_bm, bn = g_force_bn;
     if (!bm) bm = a.n >= 128 ? 128 : (a.n > 32 ? 64 : 32);
     a.debug = g_debug;
-    if (a.cb == 64 && !g_force_generic && !g_no_rows && g_force_patch < 0 && !a.ypool) {
+    if (a.cb == 64 && !g_force_generic && !g_no_rows && g_force_patch < 0 && !a.ypool && a.stride == 1) {
         // row-image kernel (conv_rows.hip).  Tile plan: N tiles split the pixel range evenly; pick the tile capacity
         // (384 / 256 / 128 columns) and the tile count that minimise  rounds x (fixed + K-steps x step time)  where a
         // round is one workgroup per CU for the 8-wave configurations and two for the 4-wave one (measured model,
@@ -668,16 +672,17 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
     if (!bn) {
         bn = 256;
         long tiles;
-        if (patch) tiles = (long)a.B * ((a.W + 15) / 16) * ((a.H + 15) / 16);
+        if (patch) tiles = (long)a.B * ((a.OW + 15) / 16) * ((a.OH + 15) / 16);
         else tiles = (a.total_n + 255) / 256;
         tiles *= (a.n + bm - 1) / bm;
         if (tiles < 200) bn = 128;  // measured: 256-wide tiles win down to ~0.8 workgroups per CU (r01 sweep)
     }
     if (a.ksize == 1) patch = false;
+    if (a.stride != 1) patch = true;  // strided convs exist as 2-D patches only (input patch = stride x the output patch)
     int rc = launch_any(a, st, bm, bn, patch);
     if (rc == MI355_EINVAL && !(g_force_bm || g_force_bn)) {
         // staging budget exceeded (very wide rows in FLAT mode): fall back to the other mode / narrower tile
-        rc = launch_any(a, st, bm, 128, a.ypool ? true : (a.ksize == 3 ? !patch : false));
+        rc = launch_any(a, st, bm, 128, (a.ypool || a.stride != 1) ? true : (a.ksize == 3 ? !patch : false));
     }
     return rc;
 }

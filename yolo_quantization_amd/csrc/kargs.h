@@ -13,7 +13,8 @@ struct ConvArgs {
     int in_cs, in_lead, in_cells;
     int out_cs, out_lead;
     int out_w, pool_w;       // bytes of an output / pooled cell this layer may write (16-aligned channel count)
-    int B, H, W, n;
+    int B, H, W, n;          // H, W: input map
+    int stride, OH, OW;      // output map = (H + 2*pad - ksize) / stride + 1 (== H, W for the stride-1 kernels)
     int ksize, cb, nchunks, upc, spc, ksteps;
     int total_n, ntiles_n, mtiles;
     int zp_act, act, store_mode;

@@ -346,10 +346,14 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
                              float *y_f32, void *stream, float *yolo_out = nullptr, int yolo_classes = 0, int up = 1)
 {
     if (!d || !x || !x->data || !blob) return einval("conv_forward: null");
-    if (d->stride != 1) return einval("conv_forward: stride must be 1 (3x3 s1 / 1x1 of yolov3-tiny)");
+    if (d->stride != 1 && d->stride != 2) return einval("conv_forward: stride must be 1 or 2");
+    if (d->stride == 2 && (d->ksize != 3 || ypool || up != 1 || yolo_out || d->accum_mode != MI355_ACC_EXACT || d->c % 16))
+        return einval("conv_forward: stride 2 exists for plain exact-mode 3x3 convs with c % 16 == 0 only (the reference's 1x1 path "
+                      "feeds the input to the GEMM unsampled, src/convolutional_layer.c:711-716)");
+    const int OH = (x->H + 2 * d->pad - d->ksize) / d->stride + 1, OW = (x->W + 2 * d->pad - d->ksize) / d->stride + 1;
     if (!((d->ksize == 3 && d->pad == 1) || (d->ksize == 1 && d->pad == 0))) return einval("conv_forward: ksize/pad");
     if (x->C != d->c) return einval("conv_forward: x.C != desc.c");
-    if (y && (y->C != d->n || y->B != x->B || y->H != x->H * up || y->W != x->W * up || !y->data))
+    if (y && (y->C != d->n || y->B != x->B || y->H != OH * up || y->W != OW * up || !y->data))
         return einval("conv_forward: y shape");
     if (ypool) {
         if ((x->H & 1) || (x->W & 1) || ypool->C != d->n || ypool->B != x->B || ypool->H != x->H / 2 ||
@@ -360,7 +364,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     if (blob_layout(d->n, d->c, d->ksize, &h) != MI355_OK) return einval("conv_forward: shape");
     const char *base = (const char *)blob;
     hipStream_t st = (hipStream_t)stream;
-    const int total_n = x->B * x->H * x->W;
+    const int total_n = x->B * OH * OW;
     const int in_cells = (int)tensor_cells(x);
 
     if (d->accum_mode == MI355_ACC_REF_F32 || h.first) {
@@ -405,6 +409,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     a.out_cs = y ? y->cs : 0; a.out_lead = y ? y->lead : 0;
     a.out_w = y ? ((y->C + 15) & ~15) : 0;  // bytes of a cell this layer owns (y may be a channel window of a wider tensor)
     a.B = x->B; a.H = x->H; a.W = x->W; a.n = d->n;
+    a.stride = d->stride; a.OH = OH; a.OW = OW;
     a.ksize = d->ksize; a.cb = h.cb; a.nchunks = h.nchunks; a.upc = h.upc; a.spc = h.spc; a.ksteps = h.ksteps;
     a.total_n = total_n;
     a.zp_act = d->zp_act; a.act = d->activation; a.store_mode = d->store_mode; a.s_act = d->s_act;
