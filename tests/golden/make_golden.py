@@ -6,6 +6,7 @@
 
 Fixtures are data only (inputs + the reference's outputs):
   tiny_unit_seed{1,2}.npz   full per-layer tensors of cfg/tiny_unit.cfg (seed 2 = act_gain 8: wrap-on-store cases)
+  s2_unit_seed{1,2}.npz     the same for cfg/s2_unit.cfg (stride-2 3x3 convolutions)
   funcs.npz                 known-answer vectors for gemm_nn_uint8_int32_te / im2col_cpu_uint8 /
                             quant_multi_smaller_than_one_to_scale_and_shift / quant_weights_with_min_max_channel
   yolov3_tiny_{leaky,relu6}.json   per-layer SHA-256 of output_int32 / output_uint8_final / output (f32) of the
@@ -44,9 +45,9 @@ def run_ref(cfg, wts, img_seed):
     return net, layers, x
 
 
-def tiny_unit(seed, act_gain):
-    cfg = os.path.join(ROOT, "cfg", "tiny_unit.cfg")
-    wts = f"/tmp/golden_tiny_unit_{seed}.weights"
+def tiny_unit(seed, act_gain, name="tiny_unit"):
+    cfg = os.path.join(ROOT, "cfg", f"{name}.cfg")
+    wts = f"/tmp/golden_{name}_{seed}.weights"
     meta = synth.synth_weights(cfg, wts, seed=seed, act_gain=act_gain)
     net, layers, x = run_ref(cfg, wts, img_seed=100 + seed)
     d = {"input_u8": x, "weights_sha256": np.array(meta["sha256"]), "seed": np.array(seed),
@@ -61,9 +62,8 @@ def tiny_unit(seed, act_gain):
             d[f"L{i}_u8"] = net.layer_u8(i)
         if L.quant_stop or L.type == "yolo":
             d[f"L{i}_f32"] = net.layer_f32(i)
-    np.savez_compressed(os.path.join(HERE, f"tiny_unit_seed{seed}.npz"), **d)
-    nwrap = 0
-    print(f"tiny_unit seed {seed}: wrote {len(d)} arrays")
+    np.savez_compressed(os.path.join(HERE, f"{name}_seed{seed}.npz"), **d)
+    print(f"{name} seed {seed}: wrote {len(d)} arrays")
 
 
 def funcs():
@@ -143,6 +143,8 @@ if __name__ == "__main__":
     assert refdrv.available(), "run oracle/build_ref.sh first (needs /root/reference)"
     tiny_unit(1, 1.0)
     tiny_unit(2, 8.0)
+    tiny_unit(1, 1.0, "s2_unit")
+    tiny_unit(2, 8.0, "s2_unit")
     funcs()
     yolov3_tiny("leaky", "yolov3-tiny_quant.cfg")
     yolov3_tiny("relu6", "yolov3-tiny_quant_relu6.cfg")

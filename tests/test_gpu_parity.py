@@ -426,13 +426,15 @@ def _run_host_net(cfg, wts, x_u8_batch, accum, store=binding.STORE_WRAP, graph=F
     return outs, info
 
 
+@pytest.mark.parametrize("name,accum", [("tiny_unit", binding.ACC_EXACT), ("tiny_unit", binding.ACC_REF_F32),
+                                        ("s2_unit", binding.ACC_EXACT)], ids=["tiny-exact", "tiny-ref_f32", "s2-exact"])
 @pytest.mark.parametrize("seed", [1, 2])
-@pytest.mark.parametrize("accum", [binding.ACC_EXACT, binding.ACC_REF_F32], ids=["exact", "ref_f32"])
-def test_tiny_unit_net_vs_reference_golden(golden_dir, cfg_dir, tmp_path, seed, accum):
-    """Full-tensor equality with the tensors the reference itself produced (tests/golden/tiny_unit_seed*.npz),
-    through the plain-C darknet host (cfg parser, weights reader, prep, layer.forward_gpu loop)."""
-    g = np.load(os.path.join(golden_dir, f"tiny_unit_seed{seed}.npz"))
-    cfg = os.path.join(cfg_dir, "tiny_unit.cfg")
+def test_tiny_unit_net_vs_reference_golden(golden_dir, cfg_dir, tmp_path, seed, accum, name):
+    """Full-tensor equality with the tensors the reference itself produced (tests/golden/{tiny,s2}_unit_seed*.npz),
+    through the plain-C darknet host (cfg parser, weights reader, prep, layer.forward_gpu loop).  s2_unit is a chain of
+    stride-2 3x3 convolutions (exact mode only: the fp32-emulation kernel is stride 1)."""
+    g = np.load(os.path.join(golden_dir, f"{name}_seed{seed}.npz"))
+    cfg = os.path.join(cfg_dir, f"{name}.cfg")
     wts = str(tmp_path / "w.weights")
     meta = synth.synth_weights(cfg, wts, seed=seed, act_gain=float(g["act_gain"]))
     assert meta["sha256"] == str(g["weights_sha256"])

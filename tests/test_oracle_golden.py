@@ -55,13 +55,15 @@ def test_quantize_image_known_answer(funcs, name):
     assert np.array_equal(u8, funcs[f"qimg_{name}_u8"])
 
 
+@pytest.mark.parametrize("name", ["tiny_unit", "s2_unit"])
 @pytest.mark.parametrize("seed", [1, 2])
 @pytest.mark.parametrize("accum", [oracle.ACC_REF_F32, oracle.ACC_EXACT])
-def test_tiny_unit_full_tensors(golden_dir, cfg_dir, tmp_path, seed, accum):
-    """Every layer type of the path on a 12x12 net: full-tensor equality with the reference, including the
-    wrap-on-store cases of seed 2 (act_gain 8).  K <= 288 so fp32 accumulation is exact: both modes must match."""
-    g = np.load(os.path.join(golden_dir, f"tiny_unit_seed{seed}.npz"))
-    cfg = os.path.join(cfg_dir, "tiny_unit.cfg")
+def test_tiny_unit_full_tensors(golden_dir, cfg_dir, tmp_path, seed, accum, name):
+    """Every layer type of the path on a 12x12 net (tiny_unit) and a chain of stride-2 3x3 convolutions on 24x24
+    (s2_unit): full-tensor equality with the reference, including the wrap-on-store cases of seed 2 (act_gain 8).
+    K <= 1152 and small sums, so fp32 accumulation is exact: both modes must match."""
+    g = np.load(os.path.join(golden_dir, f"{name}_seed{seed}.npz"))
+    cfg = os.path.join(cfg_dir, f"{name}.cfg")
     wts = str(tmp_path / "w.weights")
     meta = synth.synth_weights(cfg, wts, seed=seed, act_gain=float(g["act_gain"]))
     assert meta["sha256"] == str(g["weights_sha256"]), "synthetic weight generator drifted from the fixture"

@@ -6,6 +6,7 @@ accepts: /root/reference/src/parser.c:170-204 (convolutional), 411-431 (maxpool)
   cfg/yolov3-tiny_quant.cfg        leaky activations (the variant BASELINE.json names)
   cfg/yolov3-tiny_quant_relu6.cfg  relu6 activations (same topology as the one cfg the reference ships)
   cfg/tiny_unit.cfg                12x12 5-layer unit-test net (conv3x3, maxpool 2/2, conv1x1, maxpool 2/1, ...)
+  cfg/s2_unit.cfg                  24x24 chain of stride-2 3x3 convolutions (the downsampling layers of full YOLOv3)
 """
 import os, sys
 
@@ -59,10 +60,26 @@ def tiny_unit(act="leaky"):
     s += yolo("0,1,2")               # 9
     return s
 
+def s2_unit(act="leaky"):
+    # 24x24x3 input, a darknet-53-style downsampling chain: stride-2 3x3 convolutions instead of maxpools (the layer
+    # shapes of full YOLOv3, BASELINE config[4], in miniature), odd map at the end
+    s = net(24, 24, c=3)
+    s += conv(16, 3, act)                 # 0   24x24 (first-layer kernel)
+    s += conv(32, 3, act, stride=2)       # 1   12x12
+    s += conv(16, 1, act)                 # 2
+    s += conv(64, 3, act, stride=2)       # 3   6x6   (16-byte channel chunks)
+    s += conv(128, 3, "relu6", stride=2)  # 4   3x3   (64-byte channel chunks)
+    s += conv(64, 1, act)                 # 5
+    s += conv(128, 3, act, stride=2)      # 6   2x2   (odd input map)
+    s += conv(30, 1, "linear", bn=0, stop=1)  # 7
+    s += yolo("0,1,2")                    # 8
+    return s
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cfg")
     os.makedirs(out, exist_ok=True)
     open(os.path.join(out, "yolov3-tiny_quant.cfg"), "w").write(yolov3_tiny("leaky"))
     open(os.path.join(out, "yolov3-tiny_quant_relu6.cfg"), "w").write(yolov3_tiny("relu6"))
     open(os.path.join(out, "tiny_unit.cfg"), "w").write(tiny_unit())
+    open(os.path.join(out, "s2_unit.cfg"), "w").write(s2_unit())
     print("wrote cfgs to", os.path.normpath(out))
