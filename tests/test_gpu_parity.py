@@ -541,6 +541,37 @@ def test_yolov3_tiny_batch64_properties(cfg_dir, tmp_path):
         assert hs[0] != hs[1]
 
 
+def test_yolov3_chain_608_properties(cfg_dir, tmp_path):
+    """BASELINE config[4] in spirit (full-YOLOv3 convolution shapes at 608x608: 378 MB activation tensors at batch 32
+    would not fit the test time budget of the CPU oracle, so batch 4 and size-independent properties): slots holding the
+    same image give the same bytes on every layer, slot 0 equals the batch-1 run, the 255-channel head's float tensors
+    are finite, and the first three layers (first-layer kernel, stride-2 32->64, 1x1 64->32 at 304x304) equal the oracle."""
+    cfg = os.path.join(cfg_dir, "yolov3_chain_quant.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=99)
+    x = synth.synth_image_u8(3, 608, 608, seed=5)
+    xb = np.repeat(x[None], 4, axis=0)
+    xb[1::2] = synth.synth_image_u8(3, 608, 608, seed=6)
+    outs, info = _run_host_net(cfg, wts, xb, binding.ACC_EXACT, dump_int32=False)
+    one, _ = _run_host_net(cfg, wts, x[None], binding.ACC_EXACT, dump_int32=False)
+    assert sum(1 for inf in info if inf["type"] == binding.T_CONV and inf["stride"] == 2) == 5
+    for i, inf in enumerate(info):
+        if inf["type"] == binding.T_YOLO or inf["fused"]:
+            continue
+        per = inf["outputs"]
+        u = outs[i]["u8"].reshape(4, per)
+        assert np.array_equal(u[0], one[i]["u8"]), f"layer {i}: slot 0 != batch-1 run"
+        assert np.array_equal(u[0], u[2]) and np.array_equal(u[1], u[3]) and not np.array_equal(u[0], u[1]), f"layer {i}"
+    head = len(info) - 2
+    assert np.isfinite(outs[head]["f32"]).all() and np.isfinite(outs[head + 1]["f32"]).all()
+    onet = oracle.OracleNet(cfg, wts)
+    onet.layers = onet.layers[:3]; onet.w = onet.w[:3]
+    onet.prepare(np.float32(1.0 / 255.0), 0)
+    want = onet.forward(x, accum=oracle.ACC_EXACT)
+    for i in range(3):
+        assert np.array_equal(one[i]["u8"], want[i]["u8"].ravel()), f"layer {i} vs oracle"
+
+
 def test_microbench_shape_vs_oracle_and_linearity():
     """BASELINE config[1]: 3x3 s1 conv 256->256, 52x52, batch 32.  Oracle on 2 of the 32 images (full tensors) plus
     properties at full size: duplicated images -> identical outputs; accumulators are linear in the weights:

@@ -6,6 +6,7 @@ accepts: /root/reference/src/parser.c:170-204 (convolutional), 411-431 (maxpool)
   cfg/yolov3-tiny_quant.cfg        leaky activations (the variant BASELINE.json names)
   cfg/yolov3-tiny_quant_relu6.cfg  relu6 activations (same topology as the one cfg the reference ships)
   cfg/tiny_unit.cfg                12x12 5-layer unit-test net (conv3x3, maxpool 2/2, conv1x1, maxpool 2/1, ...)
+  cfg/yolov3_chain_quant.cfg       608x608 chain of full YOLOv3's conv shapes (5 stride-2 stages, 1x1/3x3 pairs, 255-channel head)
   cfg/s2_unit.cfg                  24x24 chain of stride-2 3x3 convolutions (the downsampling layers of full YOLOv3)
 """
 import os, sys
@@ -75,6 +76,19 @@ def s2_unit(act="leaky"):
     s += yolo("0,1,2")                    # 8
     return s
 
+def yolov3_chain(act="leaky", classes=80, w=608, h=608):
+    # the convolution shapes of full YOLOv3's darknet-53 trunk at 608x608 (BASELINE config[4]) as a plain chain: five
+    # stride-2 3x3 downsampling convs, the 1x1 / 3x3 pair of every residual stage once, one detection head.  The
+    # reference has no quantized [shortcut] (src/shortcut_layer.c is float only), so the residual adds are left out.
+    s = net(w, h)
+    s += conv(32, 3, act)
+    for f in (64, 128, 256, 512, 1024):
+        s += conv(f, 3, act, stride=2) + conv(f // 2, 1, act) + conv(f, 3, act)
+    s += conv(3 * (classes + 5), 1, "linear", bn=0, stop=1)
+    s += (f"[yolo]\nmask = 6,7,8\nanchors = 10,13,  16,30,  33,23,  30,61,  62,45,  59,119,  116,90,  156,198,  373,326\n"
+          f"classes={classes}\nnum=9\njitter=.3\nignore_thresh = .7\ntruth_thresh = 1\nrandom=1\n\n")
+    return s
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cfg")
     os.makedirs(out, exist_ok=True)
@@ -82,4 +96,5 @@ if __name__ == "__main__":
     open(os.path.join(out, "yolov3-tiny_quant_relu6.cfg"), "w").write(yolov3_tiny("relu6"))
     open(os.path.join(out, "tiny_unit.cfg"), "w").write(tiny_unit())
     open(os.path.join(out, "s2_unit.cfg"), "w").write(s2_unit())
+    open(os.path.join(out, "yolov3_chain_quant.cfg"), "w").write(yolov3_chain())
     print("wrote cfgs to", os.path.normpath(out))
