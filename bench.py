@@ -123,6 +123,8 @@ def main():
 
     from yolo_quantization_amd import binding, synth
     binding.init(local_rank)
+    if os.environ.get("BENCH_DEBUG_FLAGS"):  # A/B switches between equivalent kernel variants (mi355_debug_flags)
+        binding.shim().mi355_debug_flags(int(os.environ["BENCH_DEBUG_FLAGS"]))
     B = args.batch
     wts = f"/tmp/bench_yolov3_tiny_{os.getpid()}.weights"
 
