@@ -74,6 +74,8 @@ struct layer {
     int classes, total;
     int *mask;
     float *anchors; /* the reference calls this l.biases for yolo layers */
+    float *anchors_gpu, *det_recs_gpu; /* on-device box decode (network_yolo_detections_gpu): anchors, records, counts */
+    int *mask_gpu, *det_counts_gpu, det_cap;
 
     /* host mirrors of the outputs, reference layout (filled by pull_layer_output) */
     float *output;               /* [batch][outputs] float (quant_stop convs, yolo) */
@@ -164,6 +166,12 @@ float *network_predict(network *net, float *input);
 void push_network_input_uint8(network *net, const uint8_t *host_nchw);
 /* device -> host mirrors of layer i in the reference layout */
 void pull_layer_output(network *net, int i);
+/* get_yolo_detections + correct_yolo_boxes (ref: src/yolo_layer.c:246-277,316-345, as called by get_network_boxes,
+ * src/network.c:583-640) of yolo layer i for the whole batch on the device; only the detections are copied back.
+ * recs: [batch][max_recs][6 + classes] floats {rank, x, y, w, h, objectness, prob[classes]} sorted by rank (the order of
+ * the reference's loop), counts: [batch] detections found (records beyond max_recs are dropped). */
+void network_yolo_detections_gpu(network *net, int i, int imw, int imh, float thresh, int relative, float *recs,
+                                 int max_recs, int *counts);
 
 /* per-layer profiling: record HIP events around every layer for the next `max_steps` forward passes (eager
  * launches only), then read the per-layer sums in ms: out[0] = input layout conversion, out[1+i] = layer i. */

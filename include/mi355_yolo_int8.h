@@ -163,6 +163,17 @@ int mi355_route_forward(const mi355_tensor *const *xs, int n, const mi355_tensor
 /* yolo head activations (ref: src/yolo_layer.c:132-146) on the float head tensor [B][n*(classes+5)][H*W] */
 int mi355_yolo_forward(const float *in, float *out, int B, int n, int classes, int H, int W, void *stream);
 
+/* get_yolo_detections + correct_yolo_boxes (ref: src/yolo_layer.c:246-277, 316-345) for a batch, on the device: only
+ * detections cross PCIe.  yolo_out: the yolo layer's output [B][n*(classes+5)][H*W]; anchors [2*num] and mask [n] on the
+ * device.  Every (cell, anchor) whose objectness exceeds thresh yields a record of 6 + classes floats
+ *   {rank = cell * n + anchor, x, y, w, h, objectness, prob[classes] (objectness * class score if > thresh, else 0)}
+ * in recs[b][slot] (slot order is arbitrary: sort by rank for the reference's order); counts[b] = number of detections of
+ * image b (may exceed max_recs, the surplus is dropped).  Box centre, objectness and scores equal the reference's bits;
+ * width / height agree to a few ulp (the reference is built with -Ofast, its exp() is not reproducible). */
+int mi355_yolo_detections(const float *yolo_out, int B, int n, int classes, int H, int W, const float *anchors,
+                          const int *mask, int netw, int neth, int imw, int imh, float thresh, int relative, float *recs,
+                          int max_recs, int *counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

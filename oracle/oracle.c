@@ -293,3 +293,50 @@ void orc_yolo_forward(const float *in, int n, int classes, int h, int w, float *
         for (int i = 4 * hw; i < per * hw; ++i) o[i] = logistic(o[i]);                /* obj + classes */
     }
 }
+
+/* ------------------------------------------------------------------ src/yolo_layer.c:83-91, 246-277, 316-345
+ * get_yolo_detections of one image: for every cell (row-major) and every anchor of the layer's mask, in the reference's
+ * loop order, an objectness above `thresh` yields a record
+ *     rec[0] = cell * n + anchor (the record's rank in the reference's loop, as a float)
+ *     rec[1..4] = box x, y, w, h after correct_yolo_boxes (letterbox of an imw x imh image into netw x neth)
+ *     rec[5] = objectness, rec[6 + j] = objectness * class_j if that product exceeds thresh, else 0.
+ * `out` is the yolo layer's l.output for the image: [n][classes + 5][h * w].  Returns the number of detections; at most
+ * `max_recs` are written.  Float / double promotion follows the reference's C expressions term by term. */
+int orc_yolo_detections(const float *out, int n, int classes, int h, int w, const float *biases, const int *mask, int netw,
+                        int neth, int imw, int imh, float thresh, int relative, float *recs, int max_recs)
+{
+    const int hw = h * w, per = classes + 5, rl = 6 + classes;
+    int new_w, new_h; /* correct_yolo_boxes :250-257 */
+    if (((float)netw / imw) < ((float)neth / imh)) { new_w = netw; new_h = (imh * netw) / imw; }
+    else { new_h = neth; new_w = (imw * neth) / imh; }
+    int count = 0;
+    for (int i = 0; i < hw; ++i) {
+        const int row = i / w, col = i % w;
+        for (int a = 0; a < n; ++a) {
+            const float *p = out + (size_t)a * per * hw + i; /* entry e of this (anchor, cell): p[e * hw] (:125-130) */
+            const float objectness = p[4 * hw];
+            if (objectness <= thresh) continue; /* :326 */
+            if (count < max_recs) {
+                float *r = recs + (size_t)count * rl;
+                float bx = (col + p[0 * hw]) / w;  /* get_yolo_box :86-89 */
+                float by = (row + p[1 * hw]) / h;
+                float bw = exp(p[2 * hw]) * biases[2 * mask[a]] / netw;
+                float bh = exp(p[3 * hw]) * biases[2 * mask[a] + 1] / neth;
+                bx = (bx - (netw - new_w) / 2. / netw) / ((float)new_w / netw); /* :260-263 */
+                by = (by - (neth - new_h) / 2. / neth) / ((float)new_h / neth);
+                bw *= (float)netw / new_w;
+                bh *= (float)neth / new_h;
+                if (!relative) { bx *= imw; bw *= imw; by *= imh; bh *= imh; } /* :264-269 */
+                r[0] = (float)(i * n + a);
+                r[1] = bx; r[2] = by; r[3] = bw; r[4] = bh;
+                r[5] = objectness;
+                for (int j = 0; j < classes; ++j) { /* :333-337 */
+                    const float prob = objectness * p[(5 + j) * hw];
+                    r[6 + j] = (prob > thresh) ? prob : 0;
+                }
+            }
+            ++count;
+        }
+    }
+    return count;
+}

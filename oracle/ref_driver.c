@@ -201,3 +201,43 @@ void refdrv_quantize_image(float *x, int n, uint8_t *out, float *scale, uint8_t 
     unhush();
     free(tmp16);
 }
+
+/* get_yolo_detections of the reference itself (src/yolo_layer.c:316-345) on yolo layer i after a forward: records in
+ * the layout of orc_yolo_detections (oracle.c).  Also hands out the layer's anchors / mask for the restatement. */
+int refdrv_yolo_detections(void *h, int i, int imw, int imh, float thresh, int relative, float *recs, int max_recs)
+{
+    refnet *r = h;
+    layer l = r->net->layers[i];
+    if (l.type != YOLO) return -1;
+    const int cand = l.w * l.h * l.n, rl = 6 + l.classes;
+    detection *dets = calloc(cand, sizeof(detection));
+    for (int k = 0; k < cand; ++k) dets[k].prob = calloc(l.classes, sizeof(float));
+    const int count = get_yolo_detections(l, imw, imh, r->net->w, r->net->h, thresh, 0, relative, dets);
+    /* the rank of a record in the reference's loop: recount the objectness test in the same order */
+    int c = 0;
+    for (int p = 0; p < l.w * l.h && c < count; ++p)
+        for (int n = 0; n < l.n && c < count; ++n) {
+            const float obj = l.output[n * l.w * l.h * (4 + l.classes + 1) + 4 * l.w * l.h + p];
+            if (obj <= thresh) continue;
+            if (c < max_recs) {
+                float *o = recs + (size_t)c * rl;
+                o[0] = (float)(p * l.n + n);
+                o[1] = dets[c].bbox.x; o[2] = dets[c].bbox.y; o[3] = dets[c].bbox.w; o[4] = dets[c].bbox.h;
+                o[5] = dets[c].objectness;
+                for (int j = 0; j < l.classes; ++j) o[6 + j] = dets[c].prob[j];
+            }
+            ++c;
+        }
+    for (int k = 0; k < cand; ++k) free(dets[k].prob);
+    free(dets);
+    return count;
+}
+int refdrv_yolo_params(void *h, int i, float *biases, int *mask, int *total)
+{
+    layer l = ((refnet *)h)->net->layers[i];
+    if (l.type != YOLO) return -1;
+    for (int k = 0; k < 2 * l.total; ++k) biases[k] = l.biases[k];
+    for (int k = 0; k < l.n; ++k) mask[k] = l.mask[k];
+    *total = l.total;
+    return l.n;
+}

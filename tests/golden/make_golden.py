@@ -30,6 +30,9 @@ import refdrv  # noqa: E402
 WEIGHT_SEED, IMAGE_SEED = 1234, 7
 
 
+DET_CALLS = [(640, 480, 1, 0.5), (300, 500, 0, 0.3), (416, 416, 1, 0.6)]  # (image w, h, relative, thresh)
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -62,6 +65,13 @@ def tiny_unit(seed, act_gain, name="tiny_unit"):
             d[f"L{i}_u8"] = net.layer_u8(i)
         if L.quant_stop or L.type == "yolo":
             d[f"L{i}_f32"] = net.layer_f32(i)
+    for i, L in enumerate(layers):  # the reference's get_yolo_detections on every yolo layer, three call shapes
+        if L.type == "yolo":
+            b, m = net.yolo_params(i)
+            d[f"L{i}_anchors"] = b; d[f"L{i}_mask"] = m
+            for k, (imw, imh, rel, th) in enumerate(DET_CALLS):
+                cnt, recs = net.yolo_detections(i, L.c // L.n - 5, imw, imh, th, rel, L.n * L.h * L.w)
+                d[f"L{i}_det{k}_count"] = np.array(cnt); d[f"L{i}_det{k}_recs"] = recs
     np.savez_compressed(os.path.join(HERE, f"{name}_seed{seed}.npz"), **d)
     print(f"{name} seed {seed}: wrote {len(d)} arrays")
 

@@ -43,6 +43,8 @@ def lib():
         L.orc_prep_conv.argtypes = [ci, ci, ci, vp, vp, vp, cf, u8, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_quantize_image.argtypes = [vp, ci, vp, vp, vp]
         L.orc_yolo_forward.argtypes = [vp, ci, ci, ci, ci, vp]
+        L.orc_yolo_detections.restype = ci
+        L.orc_yolo_detections.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, C.c_float, ci, vp, ci]
         _lib = L
     return _lib
 
@@ -119,6 +121,17 @@ def upsample_u8(x, stride):
     x = np.ascontiguousarray(x)
     lib().orc_upsample_u8(_p(x), c, h, w, stride, _p(out))
     return out
+
+
+def yolo_detections(out, n, classes, h, w, biases, mask, netw, neth, imw, imh, thresh, relative, max_recs=None):
+    """out: yolo layer output of one image [n*(classes+5)*h*w] f32 -> (count, records [min(count,max)][6+classes])."""
+    out = np.ascontiguousarray(out, np.float32)
+    biases = np.ascontiguousarray(biases, np.float32); mask = np.ascontiguousarray(mask, np.int32)
+    cap = n * h * w if max_recs is None else max_recs
+    recs = np.zeros((cap, 6 + classes), np.float32)
+    cnt = lib().orc_yolo_detections(_p(out), n, classes, h, w, _p(biases), _p(mask), netw, neth, imw, imh,
+                                    C.c_float(thresh), int(relative), _p(recs), cap)
+    return cnt, recs[:min(cnt, cap)]
 
 
 def quant_multiplier(m):

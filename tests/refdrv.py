@@ -39,6 +39,8 @@ def lib(omp=False):
         L.refdrv_im2col_u8.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_uint8]
         L.refdrv_quant_multiplier.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
         L.refdrv_quantize_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.refdrv_yolo_detections.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int]
+        L.refdrv_yolo_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _libs[omp] = L
     return _libs[omp]
 
@@ -88,6 +90,20 @@ class RefNet:
 
     def layer_f32(self, i):
         return _as(self.L.refdrv_layer_f32(self.h, i), self.info[i]["outputs"], C.c_float).copy()
+
+    def yolo_params(self, i):
+        """(anchors [2*total] f32, mask [n] i32) of yolo layer i."""
+        b = np.zeros(64, np.float32); m = np.zeros(16, np.int32); t = C.c_int()
+        n = self.L.refdrv_yolo_params(self.h, i, b.ctypes.data, m.ctypes.data, C.byref(t))
+        assert n > 0
+        return b[:2 * t.value].copy(), m[:n].copy()
+
+    def yolo_detections(self, i, classes, imw, imh, thresh, relative, cap):
+        """The reference's get_yolo_detections on yolo layer i: (count, records [count][6 + classes])."""
+        recs = np.zeros((cap, 6 + classes), np.float32)
+        cnt = self.L.refdrv_yolo_detections(self.h, i, imw, imh, C.c_float(thresh), int(relative), recs.ctypes.data, cap)
+        assert cnt >= 0
+        return cnt, recs[:min(cnt, cap)]
 
     def prep(self, i):
         n = max(self.info[i]["n"], 1)

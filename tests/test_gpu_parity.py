@@ -541,6 +541,67 @@ def test_yolov3_tiny_batch64_properties(cfg_dir, tmp_path):
         assert hs[0] != hs[1]
 
 
+@pytest.mark.parametrize("name", ["tiny_unit", "s2_unit"])
+def test_yolo_detections_on_device_vs_reference(golden_dir, cfg_dir, tmp_path, name):
+    """get_yolo_detections + correct_yolo_boxes on the device (network_yolo_detections_gpu ->
+    mi355_yolo_detections) against the detections the reference produced on the same net (golden fixture), and with a
+    record budget smaller than the number of detections."""
+    from test_oracle_golden import DET_CALLS, assert_detections_match
+    g = np.load(os.path.join(golden_dir, f"{name}_seed1.npz"))
+    cfg = os.path.join(cfg_dir, f"{name}.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=1, act_gain=float(g["act_gain"]))
+    x = g["input_u8"]
+    net = binding.Net(cfg, wts, batch=3)
+    net.prepare_fixed(1.0 / 255.0, 0)
+    net.push_input(np.repeat(x[None], 3, axis=0))
+    net.forward(); net.sync()
+    ly = [i for i, inf in enumerate(net.info) if inf["type"] == binding.T_YOLO]
+    for i in ly:
+        inf = net.info[i]
+        cand = len(g[f"L{i}_mask"]) * inf["out_h"] * inf["out_w"]
+        classes = inf["outputs"] // cand - 5
+        for k, (imw, imh, rel, th) in enumerate(DET_CALLS):
+            counts, recs = net.detections(i, classes, imw, imh, th, rel, cand)
+            for b in range(3):
+                assert_detections_match(int(counts[b]), recs[b, :counts[b]], int(g[f"L{i}_det{k}_count"]), g[f"L{i}_det{k}_recs"])
+        want = int(g[f"L{i}_det0_count"])
+        if want > 4:  # budget smaller than the detections: the count is still reported, records are a subset
+            counts, recs = net.detections(i, classes, *DET_CALLS[0][:2], DET_CALLS[0][3], DET_CALLS[0][2], 4)
+            assert (counts == want).all()
+            ranks = set(g[f"L{i}_det0_recs"][:, 0].tolist())
+            assert all(r in ranks for r in recs[:, :, 0].ravel().tolist())
+    net.close()
+
+
+def test_yolo_detections_batch64_vs_oracle(cfg_dir, tmp_path):
+    """Both heads of yolov3-tiny @416 at batch 8 (two distinct images): device box decode == oracle on the device's own
+    yolo tensors, per image."""
+    cfg = os.path.join(cfg_dir, "yolov3-tiny_quant.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=1234)
+    xb = np.repeat(synth.synth_image_u8(3, 416, 416, seed=7)[None], 8, axis=0)
+    xb[1::2] = synth.synth_image_u8(3, 416, 416, seed=8)
+    net = binding.Net(cfg, wts, batch=8)
+    net.prepare_fixed(1.0 / 255.0, 0)
+    net.push_input(xb)
+    net.forward(); net.sync()
+    anchors = np.array([10, 14, 23, 27, 37, 58, 81, 82, 135, 169, 344, 319], np.float32)
+    for i, mask in ((16, [3, 4, 5]), (23, [0, 1, 2])):
+        inf = net.info[i]
+        h, w = inf["out_h"], inf["out_w"]
+        out = net.pull(i)["f32"].reshape(8, -1)
+        counts, recs = net.detections(i, 5, 640, 424, 0.5, 1, 3 * h * w)
+        for b in range(8):
+            cnt, want = oracle.yolo_detections(out[b], 3, 5, h, w, anchors, mask, 416, 416, 640, 424, 0.5, 1)
+            assert counts[b] == cnt and cnt > 0
+            got = recs[b, :cnt]
+            exact = [0, 1, 2] + list(range(5, got.shape[1]))
+            assert np.array_equal(got[:, exact], want[:, exact])
+            np.testing.assert_allclose(got[:, 3:5], want[:, 3:5], rtol=3e-7, atol=0)  # exp(): device libm vs glibc
+    net.close()
+
+
 def test_yolov3_chain_608_properties(cfg_dir, tmp_path):
     """BASELINE config[4] in spirit (full-YOLOv3 convolution shapes at 608x608: 378 MB activation tensors at batch 32
     would not fit the test time budget of the CPU oracle, so batch 4 and size-independent properties): slots holding the

@@ -149,3 +149,38 @@ def test_exact_mode_equals_ref_where_fp32_is_exact(golden_dir, cfg_dir, tmp_path
         if K * 255 * 255 < 2 ** 24:
             assert safe.all() and differs[i] == 0
     assert differs[12] > 0, "L12 (K=4608) is expected to show the reference's fp32 rounding"
+
+
+DET_CALLS = [(640, 480, 1, 0.5), (300, 500, 0, 0.3), (416, 416, 1, 0.6)]  # as in tests/golden/make_golden.py
+
+
+def assert_detections_match(count, recs, g_count, g_recs):
+    """Detections against the reference's get_yolo_detections: same count, same records in the same order; cell / anchor
+    rank, box centre, objectness and class scores bit for bit, box width / height to 4 ulp -- the reference binary is
+    built with -Ofast, whose exp() of a float is not a correctly rounded libm call (the centre, a plain add and divide,
+    is reproducible)."""
+    assert count == g_count
+    assert recs.shape == g_recs.shape
+    exact = [0, 1, 2] + list(range(5, recs.shape[1]))
+    assert np.array_equal(recs[:, exact], g_recs[:, exact])
+    np.testing.assert_allclose(recs[:, 3:5], g_recs[:, 3:5], rtol=5e-7, atol=0)
+
+
+@pytest.mark.parametrize("name", ["tiny_unit", "s2_unit"])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_yolo_detections_vs_reference(golden_dir, name, seed):
+    """orc_yolo_detections (get_yolo_detections + correct_yolo_boxes, src/yolo_layer.c:246-277,316-345) on the yolo
+    tensors the reference produced, against the detections the reference produced from them."""
+    g = np.load(os.path.join(golden_dir, f"{name}_seed{seed}.npz"))
+    ly = [int(k[1:].split("_")[0]) for k in g.files if k.endswith("_anchors")]
+    assert ly
+    for i in ly:
+        out = g[f"L{i}_f32"]
+        mask = g[f"L{i}_mask"]; anchors = g[f"L{i}_anchors"]
+        n = len(mask)
+        side = {"tiny_unit": (12, 12, 12), "s2_unit": (2, 2, 24)}[name]  # head h, w, net size
+        classes = out.size // (n * side[0] * side[1]) - 5
+        for k, (imw, imh, rel, th) in enumerate(DET_CALLS):
+            cnt, recs = oracle.yolo_detections(out, n, classes, side[0], side[1], anchors, mask, side[2], side[2], imw, imh, th, rel)
+            assert_detections_match(cnt, recs, int(g[f"L{i}_det{k}_count"]), g[f"L{i}_det{k}_recs"])
+            assert cnt > 0 or name == "s2_unit"

@@ -233,6 +233,7 @@ def host():
         L.pull_layer_output.argtypes = [vp, ci]
         L.network_profile_begin.argtypes = [vp, ci]
         L.network_profile_read.argtypes = [vp, vp]
+        L.network_yolo_detections_gpu.argtypes = [vp, ci, ci, ci, C.c_float, ci, vp, ci, vp]
         L.network_profile_set_stride.argtypes = [vp, ci]
         L.network_packed_size.restype = C.c_size_t
         L.network_packed_size.argtypes = [vp]
@@ -352,6 +353,14 @@ class Net:
                               sh.ctypes.data, q.ctypes.data)
         return dict(biases_int32=b, M_value=mv, shift_value=sv, M0=m0, shift=sh, s_in=q[0], zp_in=int(q[1]),
                     s_act=q[2], zp_act=int(q[3]))
+
+    def detections(self, i, classes, imw, imh, thresh, relative, max_recs):
+        """Box decode of yolo layer i on the device: (counts [B], records [B][max_recs][6 + classes], reference order)."""
+        recs = np.zeros((self.batch, max_recs, 6 + classes), np.float32)
+        counts = np.zeros(self.batch, np.int32)
+        self.H.network_yolo_detections_gpu(self.h, i, imw, imh, C.c_float(thresh), int(relative), recs.ctypes.data, max_recs,
+                                           counts.ctypes.data)
+        return counts, recs
 
     def profile_begin(self, max_steps, stride=1):
         self.H.network_profile_set_stride(self.h, stride)

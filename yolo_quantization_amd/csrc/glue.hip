@@ -139,6 +139,60 @@ __global__ __launch_bounds__(256) void yolo_logistic_kernel(const float *in, flo
 }
 
 
+// get_yolo_detections + correct_yolo_boxes (ref: src/yolo_layer.c:83-91, 246-277, 316-345) for a whole batch: one thread per
+// (image, cell, anchor); an objectness above thresh claims the next record of its image (atomic counter -- records
+// carry their rank cell * n + anchor in the reference's loop, the host sorts by it).  Float / double promotion follows the
+// reference's C expressions.  rec = {rank, x, y, w, h, objectness, prob[classes]}.
+__global__ __launch_bounds__(256) void yolo_detections_kernel(const float *out, int B, int n, int classes, int h, int w,
+                                                              const float *biases, const int *mask, int netw, int neth,
+                                                              int imw, int imh, float thresh, int relative, float *recs,
+                                                              int max_recs, int *counts)
+{
+    const int hw = h * w, per = classes + 5, rl = 6 + classes;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * hw * n) return;
+    const int a = (int)(idx % n);
+    const int i = (int)((idx / n) % hw);
+    const int b = (int)(idx / ((long)n * hw));
+    const float *p = out + ((size_t)b * n + a) * per * hw + i;
+    const float objectness = p[4 * hw];
+    if (objectness <= thresh) return;
+    const int slot = atomicAdd(counts + b, 1);
+    if (slot >= max_recs) return;
+    int new_w, new_h;
+    if (((float)netw / imw) < ((float)neth / imh)) { new_w = netw; new_h = (imh * netw) / imw; }
+    else { new_h = neth; new_w = (imw * neth) / imh; }
+    const int row = i / w, col = i % w;
+    float bx = (col + p[0 * hw]) / w;
+    float by = (row + p[1 * hw]) / h;
+    float bw = (float)(exp((double)p[2 * hw]) * biases[2 * mask[a]] / netw);
+    float bh = (float)(exp((double)p[3 * hw]) * biases[2 * mask[a] + 1] / neth);
+    bx = (float)((bx - (netw - new_w) / 2. / netw) / ((float)new_w / netw));
+    by = (float)((by - (neth - new_h) / 2. / neth) / ((float)new_h / neth));
+    bw *= (float)netw / new_w;
+    bh *= (float)neth / new_h;
+    if (!relative) { bx *= imw; bw *= imw; by *= imh; bh *= imh; }
+    float *r = recs + ((size_t)b * max_recs + slot) * rl;
+    r[0] = (float)(i * n + a);
+    r[1] = bx; r[2] = by; r[3] = bw; r[4] = bh;
+    r[5] = objectness;
+    for (int j = 0; j < classes; ++j) {
+        const float prob = objectness * p[(5 + j) * hw];
+        r[6 + j] = (prob > thresh) ? prob : 0.f;
+    }
+}
+
+int yolo_detections_launch(const float *out, int B, int n, int classes, int h, int w, const float *biases, const int *mask,
+                           int netw, int neth, int imw, int imh, float thresh, int relative, float *recs, int max_recs,
+                           int *counts, hipStream_t st)
+{
+    if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)B, st) != hipSuccess) return MI355_EHIP;
+    const long total = (long)B * h * w * n;
+    hipLaunchKernelGGL(yolo_detections_kernel, dim3(nblk(total)), dim3(256), 0, st, out, B, n, classes, h, w, biases, mask, netw,
+                       neth, imw, imh, thresh, relative, recs, max_recs, counts);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
 int maxpool_launch(const PoolArgs &a, hipStream_t st)
 {
     const long total = (long)a.B * a.OH * a.OW * a.groups;

@@ -81,6 +81,9 @@ struct LayoutArgs {
     int B, H, W, C, cs, lead;
 };
 
+int yolo_detections_launch(const float *out, int B, int n, int classes, int h, int w, const float *biases, const int *mask,
+                           int netw, int neth, int imw, int imh, float thresh, int relative, float *recs, int max_recs,
+                           int *counts, hipStream_t st);
 int conv_igemm_launch(ConvArgs &a, hipStream_t st);
 int conv_rows_launch(ConvArgs &a, hipStream_t st, int bm, int bn);
 int conv_small_pool_launch(ConvArgs &a, hipStream_t st);

@@ -509,4 +509,15 @@ int mi355_yolo_forward(const float *in, float *out, int B, int n, int classes, i
     return yolo_logistic_launch(in, out, B, n, classes, H * W, (hipStream_t)stream);
 }
 
+int mi355_yolo_detections(const float *yolo_out, int B, int n, int classes, int H, int W, const float *anchors,
+                          const int *mask, int netw, int neth, int imw, int imh, float thresh, int relative, float *recs,
+                          int max_recs, int *counts, void *stream)
+{
+    if (!yolo_out || !anchors || !mask || !recs || !counts || B <= 0 || n <= 0 || classes < 0 || max_recs <= 0 || imw <= 0 ||
+        imh <= 0)
+        return einval("yolo_detections: bad argument");
+    return yolo_detections_launch(yolo_out, B, n, classes, H, W, anchors, mask, netw, neth, imw, imh, thresh, relative, recs,
+                                  max_recs, counts, (hipStream_t)stream);
+}
+
 }  // extern "C"

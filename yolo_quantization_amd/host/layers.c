@@ -241,6 +241,11 @@ void free_layer_device(layer *l)
     if (l->output_int32_gpu) mi355_free(l->output_int32_gpu);
     if (l->output_gpu) mi355_free(l->output_gpu);
     if (l->output_uint8_nchw_gpu) mi355_free(l->output_uint8_nchw_gpu);
+    if (l->anchors_gpu) mi355_free(l->anchors_gpu);
+    if (l->mask_gpu) mi355_free(l->mask_gpu);
+    if (l->det_recs_gpu) mi355_free(l->det_recs_gpu);
+    if (l->det_counts_gpu) mi355_free(l->det_counts_gpu);
+    l->anchors_gpu = NULL; l->mask_gpu = NULL; l->det_recs_gpu = NULL; l->det_counts_gpu = NULL; l->det_cap = 0;
     l->out_t.data = NULL; l->blob_gpu = NULL; l->weights_uint8_gpu = NULL; l->weight_zero_point_gpu = NULL;
     l->output_int32_gpu = NULL; l->output_gpu = NULL; l->output_uint8_nchw_gpu = NULL;
 }

@@ -493,6 +493,45 @@ void pull_layer_output(network *net, int i)
     check_mi355(mi355_stream_sync(net->stream), "sync");
 }
 
+static int cmp_rec_rank(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+void network_yolo_detections_gpu(network *net, int i, int imw, int imh, float thresh, int relative, float *recs,
+                                 int max_recs, int *counts)
+{
+    if (i < 0 || i >= net->n || net->layers[i].type != YOLO) error("network_yolo_detections_gpu: not a yolo layer");
+    layer *l = &net->layers[i];
+    const int B = net->batch, rl = 6 + l->classes;
+    if (!l->anchors_gpu) {
+        check_mi355(mi355_alloc((void **)&l->anchors_gpu, sizeof(float) * 2 * (size_t)l->total), "alloc anchors");
+        check_mi355(mi355_h2d(l->anchors_gpu, l->anchors, sizeof(float) * 2 * (size_t)l->total, net->stream), "anchors");
+        check_mi355(mi355_alloc((void **)&l->mask_gpu, sizeof(int) * (size_t)l->n), "alloc mask");
+        check_mi355(mi355_h2d(l->mask_gpu, l->mask, sizeof(int) * (size_t)l->n, net->stream), "mask");
+    }
+    if (l->det_cap < max_recs) {
+        if (l->det_recs_gpu) { mi355_free(l->det_recs_gpu); mi355_free(l->det_counts_gpu); }
+        check_mi355(mi355_alloc((void **)&l->det_recs_gpu, sizeof(float) * (size_t)B * max_recs * rl), "alloc records");
+        check_mi355(mi355_alloc((void **)&l->det_counts_gpu, sizeof(int) * (size_t)B), "alloc counts");
+        l->det_cap = max_recs;
+    }
+    check_mi355(mi355_yolo_detections(l->output_gpu, B, l->n, l->classes, l->h, l->w, l->anchors_gpu, l->mask_gpu, net->w,
+                                      net->h, imw, imh, thresh, relative, l->det_recs_gpu, max_recs, l->det_counts_gpu,
+                                      net->stream), "mi355_yolo_detections");
+    check_mi355(mi355_d2h(counts, l->det_counts_gpu, sizeof(int) * (size_t)B, net->stream), "pull counts");
+    check_mi355(mi355_stream_sync(net->stream), "sync");
+    for (int b = 0; b < B; ++b) { /* only the records that exist cross PCIe; reference order = ascending rank */
+        const int k = counts[b] < max_recs ? counts[b] : max_recs;
+        if (!k) continue;
+        float *dst = recs + (size_t)b * max_recs * rl;
+        check_mi355(mi355_d2h(dst, l->det_recs_gpu + (size_t)b * max_recs * rl, sizeof(float) * (size_t)k * rl, net->stream), "pull records");
+        check_mi355(mi355_stream_sync(net->stream), "sync");
+        qsort(dst, (size_t)k, sizeof(float) * rl, cmp_rec_rank);
+    }
+}
+
 /* ------------------------------------------------------------------------------------ packed-weight exchange */
 typedef struct { uint32_t magic; int32_t nlayers; float in_scale; int32_t in_zp; uint64_t total; } pack_head;
 typedef struct { float s_act, s_in; int32_t zp_act, zp_in; uint64_t blob_bytes; } pack_rec;
