@@ -106,20 +106,27 @@ static void test_detector(const char *cfgfile, const char *weightfile, const cha
     double dt = (what_time_is_it_now() - t0) / iters;
     printf("%s: Predicted in %f seconds. (batch %d, %.1f images/s, accum=%s, parity=%s)\n", filename, dt, batch,
            batch / dt, accum == MI355_ACC_EXACT ? "exact" : "ref-f32", store == MI355_STORE_WRAP ? "wrap" : "saturate");
+    /* ref: get_network_boxes (src/network.c:583-640) -> get_yolo_detections, here decoded on the device; NMS / drawing are
+     * host-side post-processing outside the INT8 path: the boxes above thresh are printed instead */
     for (int i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];
         if (l->type != YOLO) continue;
-        pull_layer_output(net, i);
-        const int hw = l->h * l->w, per = l->classes + 5;
-        int nboxes = 0;
-        for (int a = 0; a < l->n; ++a)
-            for (int p = 0; p < hw; ++p) {
-                const float *o = l->output + (size_t)a * per * hw;
-                float obj = o[4 * hw + p];
-                for (int c = 0; c < l->classes; ++c)
-                    if (obj * o[(5 + c) * hw + p] > thresh) { ++nboxes; break; }
-            }
-        printf("yolo layer %d (%dx%d): %d candidate boxes above %.2f in image 0\n", i, l->w, l->h, nboxes, thresh);
+        const int cap = l->n * l->h * l->w, rl = 6 + l->classes;
+        float *recs = calloc((size_t)batch * cap * rl, sizeof(float));
+        int *counts = calloc((size_t)batch, sizeof(int));
+        /* the image is handed over at network size (no letterbox resize built), so the box correction is the identity */
+        network_yolo_detections_gpu(net, i, net->w, net->h, thresh, 1, recs, cap, counts);
+        printf("yolo layer %d (%dx%d): %d boxes with objectness above %.2f in image 0\n", i, l->w, l->h, counts[0], thresh);
+        for (int k = 0; k < counts[0] && k < 5; ++k) {
+            const float *r = recs + (size_t)k * rl;
+            int best = 0;
+            for (int c = 1; c < l->classes; ++c)
+                if (r[6 + c] > r[6 + best]) best = c;
+            printf("  cell %d anchor %d: class %d %.0f%%  box x %.4f y %.4f w %.4f h %.4f\n", (int)r[0] / l->n, (int)r[0] % l->n,
+                   best, 100.f * r[6 + best], r[1], r[2], r[3], r[4]);
+        }
+        free(recs);
+        free(counts);
     }
     if (dumpdir) for (int i = 0; i < net->n; ++i) dump_layer(dumpdir, net, i);
     free(img);
