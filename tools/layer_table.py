@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer roofline table (markdown) from bench.py --layers output (gpurun_out/bench_layers_n1.json).
-Times are HIP-event intervals on the launch stream of the profiled steps (each carries ~4 us of event overhead);
+Times are HIP-event intervals on the launch stream of the profiled steps, net of the cost of recording an event
+(calibrated by bench.py on the intervals that contain no launch);
 ops / bytes are the algorithmic figures of SURVEY.md section 8 times the batch.
 
 usage: tools/layer_table.py [bench_layers.json] [batch]"""
@@ -25,4 +26,4 @@ for r in d["layers"]:
         print(f"| {r['i']} | {t} | {shape} | {us:.1f} | {r['tops']:.0f} | {100 * r['tops'] / PEAK_TOPS:.1f} | {r['gbs']:.0f} | "
               f"{100 * r['gbs'] / PEAK_GBS:.1f} | {bound} |")
     else:
-        print(f"| {r['i']} | {t} | | {us:.1f} | | | | | {'fused / elided' if us < 6.0 else 'HBM / launch'} |")
+        print(f"| {r['i']} | {t} | | {us:.1f} | | | | | {'fused / elided' if us < 1.5 else 'HBM / launch'} |")
