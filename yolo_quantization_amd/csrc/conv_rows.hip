@@ -27,7 +27,7 @@
 
 // timing-ablation switches (tools/conv_microbench.py --ablate) exist only in builds made with -DMI355_ABLATE;
 // in the product build DBG(x) is the constant 0 and every switch folds away.
-#ifdef MI355_ABLATE
+#if defined(MI355_ABLATE) && !defined(ROWS_TU_KS1)
 #define DBG(bit) ((a.debug & (bit)) != 0)
 // phase timestamps (100 MHz wall clock) of wave 0 of every workgroup: tools/conv_microbench.py --timeline
 #define TS_PHASES 6
@@ -798,19 +798,29 @@ static int rows_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
     return MI355_EINVAL;
 }
 
+// The 3x3 and the 1x1 instantiations live in two translation units (conv_rows.hip, conv_rows_k1.hip = this file
+// compiled with ROWS_TU_KS1) so that they compile in parallel: 21 kernel instantiations each.
+#ifdef ROWS_TU_KS1
+int conv_rows_launch_k1(ConvArgs &a, hipStream_t st, int bm, int bn)
+{
+    const int need = a.W + 2;
+    if (need <= 16) return rows_launch_tile<16, 1>(a, st, bm, bn);
+    if (need <= 32) return rows_launch_tile<32, 1>(a, st, bm, bn);
+    if (need <= 64) return rows_launch_tile<64, 1>(a, st, bm, bn);
+    return MI355_EINVAL;
+}
+#else
+int conv_rows_launch_k1(ConvArgs &a, hipStream_t st, int bm, int bn);
+
 // returns MI355_EINVAL when the shape is outside this kernel's domain (caller falls back to conv_igemm.hip)
 int conv_rows_launch(ConvArgs &a, hipStream_t st, int bm, int bn)
 {
     if (a.cb != 64) return MI355_EINVAL;
+    if (a.ksize != 3) return conv_rows_launch_k1(a, st, bm, bn);
     const int need = a.W + 2;
-    if (a.ksize == 3) {
-        if (need <= 16) return rows_launch_tile<16, 3>(a, st, bm, bn);
-        if (need <= 32) return rows_launch_tile<32, 3>(a, st, bm, bn);
-        if (need <= 64) return rows_launch_tile<64, 3>(a, st, bm, bn);
-    } else {
-        if (need <= 16) return rows_launch_tile<16, 1>(a, st, bm, bn);
-        if (need <= 32) return rows_launch_tile<32, 1>(a, st, bm, bn);
-        if (need <= 64) return rows_launch_tile<64, 1>(a, st, bm, bn);
-    }
+    if (need <= 16) return rows_launch_tile<16, 3>(a, st, bm, bn);
+    if (need <= 32) return rows_launch_tile<32, 3>(a, st, bm, bn);
+    if (need <= 64) return rows_launch_tile<64, 3>(a, st, bm, bn);
     return MI355_EINVAL;
 }
+#endif
