@@ -32,8 +32,9 @@ struct ConvBlobHeader {
     int32_t pad_;
     uint64_t off_mprime; // f64[mpad]: M_value * shift_value (exact product when pow2)
     uint64_t off_cwb;    // int32[mpad]: cw + biases_int32 (the two per-channel additive constants folded)
-    uint64_t off_ws;     // conv_small.hip shapes only (3x3, c 16|32, n 32|64), else 0: A fragments of every K-step in
-                         // MFMA lane order, [n/32][k-step][64 lanes][16 B] (c 16: 5 steps of two taps; c 32: 9 taps)
+    uint64_t off_ws;     // conv_small.hip shapes only (3x3, c 16|32 with n 32|64, c 64 with n 64..128), else 0: A fragments of
+                         // every K-step in MFMA lane order, [n/32][k-step][64 lanes][16 B] (c 16: 5 steps of two taps;
+                         // c 32: 9 taps; c 64: 18 steps, two per tap)
 };
 
 // ---------------------------------------------------------------------------------------------------------

@@ -32,6 +32,47 @@
 constexpr int SM_PPB = 128;  // pooled pixels per workgroup tile (4 waves x 32 lanes)
 constexpr int SM_KMAX = 6;    // DMA instructions per wave and piece per tile image (image <= 4 * 6 * 64 cells)
 
+
+// The pooled store of four channels x one 2x2 window held by a lane: accb[r][j] = accumulator (bias and zero-point terms
+// included) of channel r at window position j.  Wave-uniform control flow inside (ballots): call it from uniform code.
+template <int ACT, bool SAT>
+__device__ __forceinline__ uint32_t pool_requant_quad(const int32_t (&accb)[4][4], const double (&mp)[4], const int (&lov)[4],
+                                                      const int (&hiv)[4], int zp_act, bool pow2, const double *mval4,
+                                                      const double *sval4)
+{
+    int32_t amax[4][1];
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int32_t mx = max(max(accb[r][0], accb[r][1]), max(accb[r][2], accb[r][3]));
+        const int32_t mn = min(min(accb[r][0], accb[r][1]), min(accb[r][2], accb[r][3]));
+        bad |= (mx > hiv[r]) | (mn < lov[r]);
+        amax[r][0] = mx;
+    }
+    int32_t m[4];
+    if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {  // no window of this wave can wrap: requantise the maxima
+        int32_t v[4][1];
+        requant_values<ACT, SAT, 1>(amax, mp, zp_act, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = v[r][0];
+    } else if (pow2) {  // some window of this wave wraps: the reference's order, bytes first, then the max
+        int32_t v[4][4];
+        requant_values<ACT, SAT, 4>(accb, mp, zp_act, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
+    } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int32_t t = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                t = max(t, (int32_t)requant_u8(accb[r][j], 0, mval4[r], sval4[r], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
+            m[r] = t;
+        }
+    }
+    return pack4_biased(m[0], m[1], m[2], m[3]);
+}
+
 template <int C, int NM, int ACT, bool SAT>
 __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs a)
 {
@@ -288,46 +329,237 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
                 const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
                 const int lov[4] = {lo4.x, lo4.y, lo4.z, lo4.w}, hiv[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
                 int32_t accb[4][4];  // [channel r][window position j]
-                int32_t amax[4][1];
                 double mp[4];
-                bool bad = false;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     mp[r] = ldsMP[ch0 + r];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) accb[r][j] = DZM ? acc[j][grp * 4 + r] : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
-                    const int32_t mx = max(max(accb[r][0], accb[r][1]), max(accb[r][2], accb[r][3]));
-                    const int32_t mn = min(min(accb[r][0], accb[r][1]), min(accb[r][2], accb[r][3]));
-                    bad |= (mx > hiv[r]) | (mn < lov[r]);
-                    amax[r][0] = mx;
                 }
-                int32_t m[4];
-                if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {
-                    int32_t v[4][1];
-                    requant_values<ACT, SAT, 1>(amax, mp, a.zp_act, v);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m[r] = v[r][0];
-                } else if (pow2) {  // some window of this wave wraps: the reference's order, bytes first, then the max
-                    int32_t v[4][4];
-                    requant_values<ACT, SAT, 4>(accb, mp, a.zp_act, v);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
-                } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int32_t t = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            t = max(t, (int32_t)requant_u8(accb[r][j], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
-                                                           SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
-                        m[r] = t;
-                    }
-                }
-                if (valid) *reinterpret_cast<uint32_t *>(outp + ch0) = pack4_biased(m[0], m[1], m[2], m[3]);
+                const uint32_t packed = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
+                if (valid) *reinterpret_cast<uint32_t *>(outp + ch0) = packed;
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 64 input channels (layer 6 of yolov3-tiny, 64 -> 128 at 52x52, + its maxpool): the same idea with the output
+// channels split over the waves.  A workgroup is n / 32 waves; wave w keeps the A fragments of channels [32w, 32w + 32)
+// for all 18 K-steps (tap = s / 2, channel half = s % 2, the k-half selects the 16-byte piece) and walks the tile's 128
+// pooled pixels in four groups of 32.  The image (four piece planes), its per-cell channel sums, the 3x3 box sums and
+// the image address / output cell of every pooled pixel are prepared once per tile by all waves together.  One tile
+// per workgroup, single-buffered: with 57 KB of LDS two workgroups share a CU and cover each other's load phase.
+// Against the row-image kernel + stand-alone maxpool this does a quarter of the requantisations, keeps the weights out
+// of the loop and has no K-loop barriers: 36 + 5 us -> see profiles/.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ACT, bool SAT>
+__global__ __launch_bounds__(256, 2) void conv_mid_pool_kernel(const ConvArgs a)
+{
+    constexpr int KST = 18, PIECES = 4, G = SM_PPB / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ncell = a.sm_ncell, rowb = ncell * 16, pieceb = a.sm_pieceb;
+    const bool patch = a.tiles_x > 0;
+    const int N = a.n;
+    int *ldsS = reinterpret_cast<int *>(smem + PIECES * pieceb);          // [rows_cap * ncell] per-cell channel sums
+    int *ldsSX = ldsS + ((a.rows_cap * ncell + 1) & ~1);                  // [G][4][32] 3x3 box sums per pre-pool pixel
+    int *ldsBase = ldsSX + G * 128;                                       // [G][4][32] image byte offset of tap (0,0)
+    long *ldsCell = reinterpret_cast<long *>(ldsBase + G * 128);          // [G][32] pooled output cell, -1: no pixel
+    double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier
+    int *ldsDZ = reinterpret_cast<int *>(ldsMP + N);
+    int *ldsCB = ldsDZ + N;
+    int *ldsLO = ldsCB + N, *ldsHI = ldsLO + N;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = NT >> 6;
+    const int kh = lane >> 5, lj = lane & 31;
+    const int W1 = a.W + 1;
+    const int OH = a.H >> 1, OW = a.W >> 1, ohw = OH * OW;
+    const int total_p = a.B * ohw;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const bool pow2 = a.hdr->pow2 == 1;
+    const int tile = blockIdx.x;
+
+    // ---- tile geometry (as in conv_small_pool_kernel)
+    int gr_first, col0, nrows, pb = 0, pty = 0, ptx = 0;
+    if (patch) {
+        pb = tile / tpi;
+        const int t = tile - pb * tpi;
+        pty = t / a.tiles_x;
+        ptx = t - pty * a.tiles_x;
+        gr_first = pb * (a.H + 1) + 16 * pty + 1;
+        col0 = 32 * ptx - 1;
+        nrows = 18;
+    } else {
+        const int p0 = tile * SM_PPB;
+        const int p1 = min(p0 + SM_PPB, total_p) - 1;
+        const int b0 = p0 / ohw, r0 = (p0 - b0 * ohw) / OW;
+        const int b1 = p1 / ohw, r1 = (p1 - b1 * ohw) / OW;
+        gr_first = b0 * (a.H + 1) + 2 * r0 + 1;
+        col0 = -1;
+        nrows = b1 * (a.H + 1) + 2 * r1 + 2 - gr_first + 3;
+    }
+    // ---- image DMA: instruction k fills cells [64k, 64k + 64) of every piece plane (the last one shifted back)
+    {
+        const int ncells = nrows * ncell;
+        const long org = (long)a.in_lead + (long)(gr_first - 1) * W1 + col0;
+        for (int k = wave; k * 64 < ncells; k += nwave) {
+            const int start = min(k * 64, a.rows_cap * ncell - 64);
+            const int slot = start + lane;
+            const int r = slot / ncell, c = slot - r * ncell;
+            long f = org + (long)r * W1 + c;
+            f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
+            const unsigned voff = (unsigned)(f * a.in_cs);
+#pragma unroll
+            for (int p = 0; p < PIECES; ++p) {
+                const unsigned dst = lds0 + p * pieceb + start * 16;
+                const unsigned v = voff + p * 16;
+                DMA_S(dst, a.x, v);
+            }
+        }
+    }
+    // ---- per-channel parameters, wrap-safe ranges, this wave's A fragments (overlap the DMA)
+    for (int i = tid; i < N; i += NT) {
+        const double mp = a.mprime[i];
+        ldsMP[i] = mp;
+        ldsDZ[i] = a.dzp[i];
+        ldsCB[i] = a.cwb[i];
+        int32_t lo = -2147483647 - 1, hi = 2147483647;
+        if (!SAT) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
+        ldsLO[i] = lo;
+        ldsHI[i] = hi;
+    }
+    v4i wf[KST];
+#pragma unroll
+    for (int s = 0; s < KST; ++s) wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(wave * KST + s) * 64 + lane) * 16);
+    // K-step s: tap s / 2, channels 32 * (s % 2) + 16 * kh .. + 15 -> piece plane 2 * (s % 2) + kh.  The lane's k-half goes
+    // into its pixel base, the tap row and the channel half are wave-uniform scalars, the tap column an immediate.
+    const int khoff = kh * pieceb;
+
+    // ---- pooled pixels of the tile: image offsets, output cells (one thread per (group, lane, window position))
+    for (int idx = tid; idx < G * 128; idx += NT) {
+        const int g = idx >> 7, j = (idx >> 5) & 3, l = idx & 31;
+        int b, prow, pcol;
+        bool valid;
+        if (patch) {
+            b = pb;
+            prow = 8 * pty + 2 * g + (l >> 4);
+            pcol = 16 * ptx + (l & 15);
+            valid = prow < OH && pcol < OW;
+        } else {
+            const int pp = tile * SM_PPB + g * 32 + l;
+            valid = pp < total_p;
+            const int ppc = valid ? pp : total_p - 1;
+            b = ppc / ohw;
+            const int prem = ppc - b * ohw;
+            prow = prem / OW;
+            pcol = prem - prow * OW;
+        }
+        const int rr = b * (a.H + 1) + 2 * prow + 1 - gr_first + (j >> 1);
+        const int cc = 2 * pcol - 1 - col0 + (j & 1);
+        ldsBase[idx] = rr * rowb + cc * 16;
+        if (j == 0)
+            ldsCell[g * 32 + l] = valid ? (long)a.pool_lead + ((long)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol : -1L;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // image, parameters, pixel tables
+
+    // ---- per-cell channel sums, then the 3x3 box sum of every pre-pool pixel
+    const char *X = smem;
+    for (int id = tid; id < nrows * ncell; id += NT) {
+        int t = 0;
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) {
+            const v4i v = *reinterpret_cast<const v4i *>(X + p * pieceb + id * 16);
+            t = __builtin_amdgcn_sdot4(v[0], 0x01010101, t, false);
+            t = __builtin_amdgcn_sdot4(v[1], 0x01010101, t, false);
+            t = __builtin_amdgcn_sdot4(v[2], 0x01010101, t, false);
+            t = __builtin_amdgcn_sdot4(v[3], 0x01010101, t, false);
+        }
+        ldsS[id] = t;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * 128; idx += NT) {
+        const int c0 = ldsBase[idx] >> 4;  // cell index of tap (0,0): rr * ncell + cc
+        int t = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) t += ldsS[c0 + dy * ncell + dx];
+        ldsSX[idx] = t;
+    }
+    __syncthreads();
+
+    // ---- this wave's 32 channels over the tile's four pixel groups
+    const int chw = 32 * wave;
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        int base[4], sx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            base[j] = ldsBase[(g * 4 + j) * 32 + lj] + khoff;
+            sx[j] = ldsSX[(g * 4 + j) * 32 + lj];
+        }
+        const long pcell = ldsCell[g * 32 + lj];
+        v16i acc[4];
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + chw + 8 * grp + 4 * kh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j][grp * 4 + 0] = c4.x; acc[j][grp * 4 + 1] = c4.y;
+                acc[j][grp * 4 + 2] = c4.z; acc[j][grp * 4 + 3] = c4.w;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KST; ++s) {
+            const int soff = ((s >> 1) / 3) * rowb + (s & 1) * 2 * pieceb;  // scalar
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4i bf = *reinterpret_cast<const v4i *>(X + base[j] + soff + ((s >> 1) % 3) * 16);
+                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s], bf, acc[j], 0, 0, 0);
+            }
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);  // keep the B fragments of at most two K-steps live (registers)
+        }
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int ch0 = chw + 8 * grp + 4 * kh;
+            const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
+            const int4 lo4 = *reinterpret_cast<const int4 *>(ldsLO + ch0);
+            const int4 hi4 = *reinterpret_cast<const int4 *>(ldsHI + ch0);
+            const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
+            const int lov[4] = {lo4.x, lo4.y, lo4.z, lo4.w}, hiv[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
+            int32_t accb[4][4];
+            double mp[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mp[r] = ldsMP[ch0 + r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accb[r][j] = acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
+            }
+            const uint32_t packed = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
+            if (pcell >= 0) *reinterpret_cast<uint32_t *>(a.ypool + (size_t)pcell * a.pool_cs + ch0) = packed;
+        }
+    }
+}
+
+template <int ACT>
+static int mid_launch_sat(ConvArgs &a, hipStream_t st, int grid, int threads, size_t lds)
+{
+    if (a.store_mode == MI355_STORE_SATURATE) {
+        auto kern = conv_mid_pool_kernel<ACT, true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MI355_EHIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+    } else {
+        auto kern = conv_mid_pool_kernel<ACT, false>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MI355_EHIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -356,7 +588,12 @@ static int small_launch_act(ConvArgs &a, hipStream_t st, int grid, size_t lds)
     return small_launch_sat<C, NM, MI355_ACT_LINEAR>(a, st, grid, lds);
 }
 
-bool conv_small_eligible(int n, int c, int ksize) { return ksize == 3 && (c == 16 || c == 32) && (n == 32 || n == 64); }
+bool conv_small_eligible(int n, int c, int ksize)
+{
+    if (ksize != 3) return false;
+    if (c == 64) return n % 32 == 0 && n >= 64 && n <= 128;  // conv_mid_pool_kernel: n / 32 waves (2..4) per workgroup
+    return (c == 16 || c == 32) && (n == 32 || n == 64);
+}
 
 // returns MI355_EINVAL when the shape is outside this kernel's domain (the caller falls back to conv_igemm.hip)
 int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
@@ -383,6 +620,18 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
         ntiles = (int)((total_p + SM_PPB - 1) / SM_PPB);
     }
     a.sm_pieceb = a.rows_cap * a.sm_ncell * 16;
+    if (c == 64) {  // channels split over n / 32 waves, one single-buffered tile per workgroup
+        if (a.rows_cap * a.sm_ncell < 64) return MI355_EINVAL;
+        size_t l64 = 4 * (size_t)a.sm_pieceb + (size_t)((a.rows_cap * a.sm_ncell + 1) & ~1) * 4 + (SM_PPB / 32) * 128 * 8 + SM_PPB * 8;
+        l64 = (l64 + 15) & ~(size_t)15;
+        a.lds_param_off = (int)l64;
+        l64 += (size_t)a.n * 24;
+        if (l64 > 160 * 1024) return MI355_EINVAL;
+        const int threads = a.n / 32 * 64;
+        if (a.act == MI355_ACT_LEAKY) return mid_launch_sat<MI355_ACT_LEAKY>(a, st, ntiles, threads, l64);
+        if (a.act == MI355_ACT_RELU6) return mid_launch_sat<MI355_ACT_RELU6>(a, st, ntiles, threads, l64);
+        return mid_launch_sat<MI355_ACT_LINEAR>(a, st, ntiles, threads, l64);
+    }
     if (a.rows_cap * a.sm_ncell < 64 || a.rows_cap * a.sm_ncell > 4 * SM_KMAX * 64) return MI355_EINVAL;
     size_t lds = 2 * (size_t)(c / 16) * a.sm_pieceb + (size_t)a.rows_cap * a.sm_ncell * 4;
     lds = (lds + 15) & ~(size_t)15;

@@ -239,7 +239,7 @@ static int blob_layout(int n, int c, int ksize, ConvBlobHeader *h)
     h->off_cwb = off; off = align16(off + (size_t)h->mpad * 4);
     if (conv_small_eligible(n, c, ksize)) {
         h->off_ws = off;
-        off = align16(off + (size_t)(n / 32) * (c == 16 ? 5 : 9) * 1024);
+        off = align16(off + (size_t)(n / 32) * (c == 16 ? 5 : (c == 32 ? 9 : 18)) * 1024);
     }
     h->total = off;
     return MI355_OK;
@@ -303,15 +303,16 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
     }
     if (h.off_ws) {  // weights-stationary plane of conv_small.hip: lane (row lj, k-half kh) of K-step s
         int8_t *ws = (int8_t *)(base + h.off_ws);
-        const int kst = (c == 16) ? 5 : 9;
+        const int kst = (c == 16) ? 5 : (c == 32 ? 9 : 18);
         for (int mt = 0; mt < n / 32; ++mt)
             for (int s = 0; s < kst; ++s)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int oc = 32 * mt + (lane & 31), khalf = lane >> 5;
-                    const int tap = (c == 16) ? 2 * s + khalf : s;  // c 16: the k-half is the tap parity (tap 9: zeros)
+                    // c 16: the k-half is the tap parity (tap 9: zeros); c 32: one tap per step; c 64: two steps per tap
+                    const int tap = (c == 16) ? 2 * s + khalf : (c == 32 ? s : s / 2);
                     int8_t *dst = ws + ((size_t)(mt * kst + s) * 64 + lane) * 16;
                     for (int e = 0; e < 16; ++e) {
-                        const int ci = (c == 16) ? e : 16 * khalf + e;
+                        const int ci = (c == 16) ? e : (c == 32 ? 16 * khalf + e : 32 * (s & 1) + 16 * khalf + e);
                         dst[e] = tap > 8 ? 0 : (int8_t)(wq[(size_t)oc * K + (ci * 3 + tap / 3) * 3 + tap % 3] ^ 0x80);
                     }
                 }

@@ -295,7 +295,8 @@ static void plan_fusion(network *net)
         if (c->type != CONVOLUTIONAL || p->type != MAXPOOL) continue;
         if (c->size != 3 || c->quant_stop_flag || p->size != 2 || p->stride != 2 || p->pad / 2 != 0) continue;
         if ((c->out_h & 1) || (c->out_w & 1) || (c->c != 3 && c->c % 16)) continue;
-        if (c->c % 64 == 0) continue; /* 64-byte-chunk layers use the row-image kernel, which has no fused form yet */
+        /* 64-byte-chunk layers use the row-image kernel, which has no fused form; 64 -> 64..128 has its own fused kernel */
+        if (c->c % 64 == 0 && !(c->c == 64 && c->n % 32 == 0 && c->n >= 64 && c->n <= 128)) continue;
         int used = 0;
         for (int j = 0; j < net->n; ++j)
             if (net->layers[j].type == ROUTE)
