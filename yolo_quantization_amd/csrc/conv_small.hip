@@ -30,6 +30,7 @@
                  : "memory")
 
 constexpr int SM_PPB = 128;  // pooled pixels per workgroup tile (4 waves x 32 lanes)
+constexpr int SM_GMAX = 8;    // conv_mid_pool_kernel: groups of 32 pooled pixels per tile (tile <= 256 pooled pixels)
 constexpr int SM_KMAX = 6;    // DMA instructions per wave and piece per tile image (image <= 4 * 6 * 64 cells)
 
 
@@ -346,25 +347,26 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
 // ---------------------------------------------------------------------------------------------------------------
 // 64 input channels (layer 6 of yolov3-tiny, 64 -> 128 at 52x52, + its maxpool): the same idea with the output
 // channels split over the waves.  A workgroup is n / 32 waves; wave w keeps the A fragments of channels [32w, 32w + 32)
-// for all 18 K-steps (tap = s / 2, channel half = s % 2, the k-half selects the 16-byte piece) and walks the tile's 128
-// pooled pixels in four groups of 32.  The image (four piece planes), its per-cell channel sums, the 3x3 box sums and
+// for all 18 K-steps (tap = s / 2, channel half = s % 2, the k-half selects the 16-byte piece); two such sets of waves
+// share a workgroup and deal the tile's groups of 32 pooled pixels between them, so that every SIMD holds two waves whose
+// MFMA and requantise phases overlap.  The tile size is chosen by the launcher so that the tiles fill whole rounds of CUs.  The image (four piece planes), its per-cell channel sums, the 3x3 box sums and
 // the image address / output cell of every pooled pixel are prepared once per tile by all waves together.  One tile
-// per workgroup, single-buffered: with 57 KB of LDS two workgroups share a CU and cover each other's load phase.
+// per workgroup, single-buffered.
 // Against the row-image kernel + stand-alone maxpool this does a quarter of the requantisations, keeps the weights out
 // of the loop and has no K-loop barriers: 36 + 5 us -> see profiles/.
 // ---------------------------------------------------------------------------------------------------------------
 template <int ACT, bool SAT>
-__global__ __launch_bounds__(256, 2) void conv_mid_pool_kernel(const ConvArgs a)
+__global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
 {
-    constexpr int KST = 18, PIECES = 4, G = SM_PPB / 32;
+    constexpr int KST = 18, PIECES = 4, GMAX = SM_GMAX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ncell = a.sm_ncell, rowb = ncell * 16, pieceb = a.sm_pieceb;
     const bool patch = a.tiles_x > 0;
     const int N = a.n;
     int *ldsS = reinterpret_cast<int *>(smem + PIECES * pieceb);          // [rows_cap * ncell] per-cell channel sums
     int *ldsSX = ldsS + ((a.rows_cap * ncell + 1) & ~1);                  // [G][4][32] 3x3 box sums per pre-pool pixel
-    int *ldsBase = ldsSX + G * 128;                                       // [G][4][32] image byte offset of tap (0,0)
-    long *ldsCell = reinterpret_cast<long *>(ldsBase + G * 128);          // [G][32] pooled output cell, -1: no pixel
+    int *ldsBase = ldsSX + GMAX * 128;                                    // [G][4][32] image byte offset of tap (0,0)
+    long *ldsCell = reinterpret_cast<long *>(ldsBase + GMAX * 128);       // [G][32] pooled output cell, -1: no pixel
     double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier
     int *ldsDZ = reinterpret_cast<int *>(ldsMP + N);
     int *ldsCB = ldsDZ + N;
@@ -374,6 +376,9 @@ __global__ __launch_bounds__(256, 2) void conv_mid_pool_kernel(const ConvArgs a)
     const int tid = threadIdx.x, NT = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = NT >> 6;
+    const int nq = N >> 5;                      // 32-channel quads = waves of one set
+    const int wq = wave % nq, wset = wave / nq, nset = nwave / nq;  // this wave: channels [32 wq, +32), pixel groups wset, wset + nset, ..
+    const int TP = a.sm_tp, G = (TP + 31) >> 5;  // pooled pixels per tile (patches: 128), groups of 32
     const int kh = lane >> 5, lj = lane & 31;
     const int W1 = a.W + 1;
     const int OH = a.H >> 1, OW = a.W >> 1, ohw = OH * OW;
@@ -393,8 +398,8 @@ __global__ __launch_bounds__(256, 2) void conv_mid_pool_kernel(const ConvArgs a)
         col0 = 32 * ptx - 1;
         nrows = 18;
     } else {
-        const int p0 = tile * SM_PPB;
-        const int p1 = min(p0 + SM_PPB, total_p) - 1;
+        const int p0 = tile * TP;
+        const int p1 = min(p0 + TP, total_p) - 1;
         const int b0 = p0 / ohw, r0 = (p0 - b0 * ohw) / OW;
         const int b1 = p1 / ohw, r1 = (p1 - b1 * ohw) / OW;
         gr_first = b0 * (a.H + 1) + 2 * r0 + 1;
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void conv_mid_pool_kernel(const ConvArgs a)
     }
     v4i wf[KST];
 #pragma unroll
-    for (int s = 0; s < KST; ++s) wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(wave * KST + s) * 64 + lane) * 16);
+    for (int s = 0; s < KST; ++s) wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(wq * KST + s) * 64 + lane) * 16);
     // K-step s: tap s / 2, channels 32 * (s % 2) + 16 * kh .. + 15 -> piece plane 2 * (s % 2) + kh.  The lane's k-half goes
     // into its pixel base, the tap row and the channel half are wave-uniform scalars, the tap column an immediate.
     const int khoff = kh * pieceb;
@@ -449,9 +454,9 @@ __global__ __launch_bounds__(256, 2) void conv_mid_pool_kernel(const ConvArgs a)
             pcol = 16 * ptx + (l & 15);
             valid = prow < OH && pcol < OW;
         } else {
-            const int pp = tile * SM_PPB + g * 32 + l;
-            valid = pp < total_p;
-            const int ppc = valid ? pp : total_p - 1;
+            const int pp = tile * TP + g * 32 + l;
+            valid = pp < total_p && g * 32 + l < TP;
+            const int ppc = valid ? pp : min(tile * TP + TP, total_p) - 1;  // idle lanes shadow the tile's last pixel
             b = ppc / ohw;
             const int prem = ppc - b * ohw;
             prow = prem / OW;
@@ -493,9 +498,9 @@ __global__ __launch_bounds__(256, 2) void conv_mid_pool_kernel(const ConvArgs a)
     __syncthreads();
 
     // ---- this wave's 32 channels over the tile's four pixel groups
-    const int chw = 32 * wave;
+    const int chw = 32 * wq;
 #pragma unroll 1
-    for (int g = 0; g < G; ++g) {
+    for (int g = wset; g < G; g += nset) {
         int base[4], sx[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -620,14 +625,25 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
         ntiles = (int)((total_p + SM_PPB - 1) / SM_PPB);
     }
     a.sm_pieceb = a.rows_cap * a.sm_ncell * 16;
-    if (c == 64) {  // channels split over n / 32 waves, one single-buffered tile per workgroup
+    if (c == 64) {  // channels split over n / 32 waves x 2 sets, one single-buffered tile per workgroup
+        int tp = SM_PPB;
+        if (a.tiles_x == 0) {
+            // flat tiles: as few rounds of 256 workgroups as the 256-pixel tile limit allows, tiles of equal size
+            const long rounds = (total_p + 256L * SM_GMAX * 32 - 1) / (256L * SM_GMAX * 32);
+            tp = (int)((total_p + 256 * rounds - 1) / (256 * rounds));
+            if (tp < 32) tp = 32;
+            a.rows_cap = 2 * ((tp - 2 + OW) / OW + 1) + (tp - 2 + OH * OW) / (OH * OW) + 2;
+            a.sm_pieceb = a.rows_cap * a.sm_ncell * 16;
+            ntiles = (int)((total_p + tp - 1) / tp);
+        }
+        a.sm_tp = tp;
         if (a.rows_cap * a.sm_ncell < 64) return MI355_EINVAL;
-        size_t l64 = 4 * (size_t)a.sm_pieceb + (size_t)((a.rows_cap * a.sm_ncell + 1) & ~1) * 4 + (SM_PPB / 32) * 128 * 8 + SM_PPB * 8;
+        size_t l64 = 4 * (size_t)a.sm_pieceb + (size_t)((a.rows_cap * a.sm_ncell + 1) & ~1) * 4 + SM_GMAX * 128 * 8 + SM_GMAX * 32 * 8;
         l64 = (l64 + 15) & ~(size_t)15;
         a.lds_param_off = (int)l64;
         l64 += (size_t)a.n * 24;
         if (l64 > 160 * 1024) return MI355_EINVAL;
-        const int threads = a.n / 32 * 64;
+        const int threads = 2 * (a.n / 32) * 64;
         if (a.act == MI355_ACT_LEAKY) return mid_launch_sat<MI355_ACT_LEAKY>(a, st, ntiles, threads, l64);
         if (a.act == MI355_ACT_RELU6) return mid_launch_sat<MI355_ACT_RELU6>(a, st, ntiles, threads, l64);
         return mid_launch_sat<MI355_ACT_LINEAR>(a, st, ntiles, threads, l64);

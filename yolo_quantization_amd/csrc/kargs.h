@@ -34,6 +34,7 @@ struct ConvArgs {
     int debug;               // timing-ablation switches (results are wrong when non-zero): see mi355_debug_flags
     const int8_t *ws;        // conv_small: weights-stationary A fragments [m-tile][k-step][lane][16 B] or null
     int sm_ncell, sm_pieceb; // conv_small: cells per LDS image row; bytes of one 16-channel piece plane
+    int sm_tp;               // conv_mid_pool: pooled pixels per tile
     int up;                  // conv_rows: fused nearest-neighbour upsample factor of the stored tensor (1 = none)
     float *yolo_out;         // fused yolo head: activated copy of y_f32 (same layout) or null
     int yolo_per;            // classes + 5
