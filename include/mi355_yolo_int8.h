@@ -150,7 +150,8 @@ int mi355_conv_set_tile(int bm, int bn);
 /* Development switches.  Bits 0..8 are timing ablations of the K loop (no DMA / no s_barrier / no MFMA / ...), compiled
  * in only with -DMI355_ABLATE: results are WRONG when set; tools/conv_microbench.py --ablate only.  Two bits select
  * among equivalent kernels and leave results unchanged (tests use them to cross-check): 512 = conv_rows.hip walks the
- * channel chunks unrotated, 1024 = fused conv+maxpool never uses conv_small.hip. */
+ * channel chunks unrotated, 1024 = fused conv+maxpool never uses conv_small.hip / the first-layer MFMA kernel, 8192 = 1x1
+ * layers never use conv1x1.hip. */
 int mi355_debug_flags(int flags);
 
 /* ---- glue layers ---------------------------------------------------------------------------------------- */

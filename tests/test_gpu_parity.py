@@ -124,6 +124,33 @@ def test_conv_stride2(B, c, n, H, W, k, store):
     assert np.array_equal(fast["u8"].reshape(B, n, OH * OW), u8), "uint8 activations, fast epilogue"
 
 
+@pytest.mark.parametrize("B,c,n,H,W,act", [(1, 128, 30, 13, 13, "linear"), (3, 256, 96, 26, 26, "leaky"), (2, 512, 255, 13, 13, "linear"),
+                                           (1, 1024, 256, 13, 13, "leaky"), (64, 256, 128, 13, 13, "leaky"), (2, 128, 33, 5, 7, "relu6"),
+                                           (1, 1024, 1, 9, 9, "relu")])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+def test_conv1x1_weights_stationary_kernel(B, c, n, H, W, act, store):
+    """The 1x1 kernel for the network's neck and heads (conv1x1.hip: weights held in registers, one balanced pixel
+    tile per workgroup) against the oracle, and against the row-image kernel it replaces (debug flag 8192 routes the
+    same call there): every channel depth it is compiled for, ragged output-channel counts, tiles that end mid-image."""
+    rng = np.random.default_rng(B + c + n + H + W)
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 1)
+    xt = binding.DevTensor.from_nchw(x, 23)
+    args = (xt, wq, zp_w, 1, bias, mv, sv, 23, 128, 0.05, binding.ACT[act], store, binding.ACC_EXACT)
+    got = binding.conv_forward(*args, want_acc=False, want_f32=True)
+    if B <= 3:
+        _, u8 = _oracle_layer(x, wq, zp_w, 1, 23, bias, mv, sv, 128, oracle.ACT[act], store, oracle.ACC_EXACT)
+        assert np.array_equal(got["u8"].reshape(B, n, H * W), u8)
+        assert np.array_equal(got["f32"], oracle.dequant(u8, 128, np.float32(0.05)))
+    binding.shim().mi355_debug_flags(8192)
+    try:
+        rows = binding.conv_forward(*args, want_acc=False, want_f32=True)
+    finally:
+        binding.shim().mi355_debug_flags(0)
+    assert np.array_equal(got["u8"], rows["u8"])
+    assert np.array_equal(got["f32"], rows["f32"])
+
+
 @pytest.mark.parametrize("bm,bn,nt", [(128, 256, 0), (128, 128, 0), (64, 256, 0), (64, 128, 0), (32, 256, 0), (32, 128, 0),
                                       (128, 384, 0), (128, 384, 3), (128, 384, 7), (128, 256, 5), (64, 128, 13)])
 def test_conv_every_tile_config(bm, bn, nt):

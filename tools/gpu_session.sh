@@ -13,6 +13,7 @@ fi
 if [[ $what == all || $what == bench ]]; then
   timeout 900 python bench.py --steps 20 --warmup 3 --layers 2>gpurun_out/bench.err | tee gpurun_out/bench.json
   tail -40 gpurun_out/bench.err
+  cp gpurun_out/bench_layers_n1.json gpurun_out/bench_layers_clean.json   # the rocprofv3 legs below rewrite the former
 fi
 if [[ $what == all || $what == prof ]]; then
   rm -rf gpurun_out/prof

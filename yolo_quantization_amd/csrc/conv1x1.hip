@@ -1,0 +1,223 @@
+// conv1x1.hip -- 1x1 INT8 convolution with the weights stationary in registers: the bottleneck / head layers of
+// yolov3-tiny (1024->256, 512->30, 256->128, 256->30 at 13x13 / 26x26).  Through the row-image kernel these layers
+// spent 12-21 us each on 1-6 GOP: a K loop of 4-16 barrier-synchronised steps behind 11 us of per-launch fixed cost.
+// Here a workgroup of 8 waves owns one tile of consecutive pixels (sized so that the tiles fill whole rounds of the
+// 256 CUs); the output channels are split in quads of 32 over the waves, a wave keeps the A fragments of its quad for
+// the whole K (C / 32 K-steps, up to 128 VGPRs at C = 1024), `sets` such wave sets deal the tile's groups of 32 pixels
+// between them.  The tile's input cells are DMAed once (global_load_lds) into LDS in the rows kernel's chunk layout
+// [64-channel chunk][16 pixels x 4 pieces x 16 B]; there is no K loop, no barrier besides the one after the load, and
+// the receptive field of a 1x1 tap is the pixel itself, so sum(x') comes from the B fragments in registers.
+// Same mathematics and the same bytes as conv_rows.hip (signed-operand decomposition: see conv_igemm.hip); optional
+// float tail of a quant_stop head, fused yolo activations (byte -> logistic table) and nearest-neighbour upsample store.
+#include "kargs.h"
+
+#define DMA_S(ldsdst_u32, sbase_ptr, voff_u32)                                                                   \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst_u32), "v"(voff_u32), \
+                 "s"(sbase_ptr)                                                                                  \
+                 : "memory")
+
+constexpr int P1_GMAX = 8;  // groups of 32 pixels per tile
+
+template <int KST, int ACT, bool SAT>
+__global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N32 = (a.n + 31) & ~31;
+    const int chunks = a.sm_ncell;               // 16-pixel chunks of the tile image (2 per group)
+    const int qb = chunks * 1024;                // bytes of one 64-channel chunk plane
+    double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N32] folded multiplier
+    int *ldsDZ = reinterpret_cast<int *>(ldsMP + N32);                    // [N32] 128 - zp_w
+    int *ldsCB = ldsDZ + N32;                                             // [N32] cw + bias
+    float *ldsYL = reinterpret_cast<float *>(ldsCB + N32);                // [256] fused yolo head: logistic per byte
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = NT >> 6;
+    const int kh = lane >> 5, lj = lane & 31;
+    const int nq = N32 >> 5;
+    const int wq = wave % nq, wset = wave / nq, nset = nwave / nq;
+    const int W1 = a.W + 1, hw = a.H * a.W;
+    const int TP = a.sm_tp, G = (TP + 31) >> 5;
+    const int tile = blockIdx.x;
+    const int n0 = tile * TP, n1 = min(n0 + TP, a.total_n);  // this tile's pixels [n0, n1)
+    const bool pow2 = a.hdr->pow2 == 1;
+
+    // ---- tile image DMA: instruction (Q, chunk) = 16 pixels x 4 pieces of 64-channel chunk Q; lane -> (piece lane >> 4,
+    //      pixel lane & 15).  The pixel -> cell division is done once per chunk and reused for every Q.
+    {
+        const int nck = (n1 - n0 + 15) >> 4;
+        const int nQ = KST >> 1;
+        for (int ck = wave; ck < nck; ck += nwave) {
+            const int n = min(n0 + ck * 16 + (lane & 15), n1 - 1);
+            const int b = n / hw, rem = n - b * hw;
+            const int y = rem / a.W, x = rem - y * a.W;
+            const long cell = (long)a.in_lead + ((long)b * (a.H + 1) + (y + 1)) * W1 + x;
+            const unsigned voff = (unsigned)(cell * a.in_cs) + (lane >> 4) * 16;
+            for (int Q = 0; Q < nQ; ++Q) {
+                const unsigned dst = lds0 + Q * qb + ck * 1024;
+                const unsigned v = voff + Q * 64;
+                DMA_S(dst, a.x, v);
+            }
+        }
+    }
+    // ---- parameters and this wave's A fragments (overlap the DMA)
+    for (int i = tid; i < N32; i += NT) {
+        ldsMP[i] = a.mprime[i];
+        ldsDZ[i] = a.dzp[i];
+        ldsCB[i] = a.cwb[i];
+    }
+    if (a.yolo_out)
+        for (int i = tid; i < 256; i += NT) ldsYL[i] = yolo_entry_act((float)(i - a.zp_act) * a.s_act, 0);
+    v4i wf[KST];
+#pragma unroll
+    for (int s = 0; s < KST; ++s) wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(wq * KST + s) * 64 + lane) * 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const char *X = smem;
+    const int chw = 32 * wq;
+#pragma unroll 1
+    for (int g = wset; g < G; g += nset) {
+        // K-step s: channels 32 s + 16 kh .. + 15 = chunk s / 2, piece 2 (s % 2) + kh
+        const int base = (2 * g + (lj >> 4)) * 1024 + (lj & 15) * 16 + kh * 256;
+        v16i acc;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + chw + 8 * grp + 4 * kh);
+            acc[grp * 4 + 0] = c4.x; acc[grp * 4 + 1] = c4.y; acc[grp * 4 + 2] = c4.z; acc[grp * 4 + 3] = c4.w;
+        }
+        int sxr = 0;
+#pragma unroll
+        for (int s = 0; s < KST; ++s) {
+            const v4i bf = *reinterpret_cast<const v4i *>(X + base + (s >> 1) * qb + (s & 1) * 512);
+            sxr = __builtin_amdgcn_sdot4(bf[0], 0x01010101, sxr, false);
+            sxr = __builtin_amdgcn_sdot4(bf[1], 0x01010101, sxr, false);
+            sxr = __builtin_amdgcn_sdot4(bf[2], 0x01010101, sxr, false);
+            sxr = __builtin_amdgcn_sdot4(bf[3], 0x01010101, sxr, false);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s], bf, acc, 0, 0, 0);
+            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the number of B fragments in flight (registers)
+        }
+        const int sx = sxr + __shfl_xor(sxr, 32);  // the two 16-byte k-halves of every K-step
+
+        // ---- this lane's pixel
+        const int n = n0 + g * 32 + lj;
+        const bool valid = n < n1;
+        const int nn = valid ? n : n1 - 1;
+        const int b = nn / hw, rem = nn - b * hw;
+        const int y = rem / a.W, x = rem - y * a.W;
+        const int up = a.up;
+        const long ocell = up == 1 ? (long)a.out_lead + ((long)b * (a.H + 1) + (y + 1)) * W1 + x
+                                   : (long)a.out_lead + ((long)b * (up * a.H + 1) + (up * y + 1)) * (up * a.W + 1) + up * x;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int ch0 = chw + 8 * grp + 4 * kh;
+            const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
+            const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
+            int32_t accb[4][1], v[4][1];
+            double mp[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mp[r] = ldsMP[ch0 + r];
+                accb[r][0] = acc[grp * 4 + r] + __mul24(dzv[r], sx);
+            }
+            if (pow2) {
+                requant_values<ACT, SAT, 1>(accb, mp, a.zp_act, v);
+            } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r][0] = (int32_t)requant_u8(accb[r][0], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
+                                                  SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+            }
+            if (valid && ch0 < a.out_w) {
+                const uint32_t packed = pack4_biased(v[0][0], v[1][0], v[2][0], v[3][0]);
+                if (up == 1) {
+                    *reinterpret_cast<uint32_t *>(a.y + (size_t)ocell * a.out_cs + ch0) = packed;
+                } else {
+                    const int rowc = up * a.W + 1;
+                    for (int uy = 0; uy < up; ++uy)
+                        for (int ux = 0; ux < up; ++ux)
+                            *reinterpret_cast<uint32_t *>(a.y + (size_t)(ocell + uy * rowc + ux) * a.out_cs + ch0) = packed;
+                }
+                if (a.y_f32) {  // quant_stop tail (ref :752-760) and, fused, the yolo layer's activations
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int oc = ch0 + r;
+                        if (oc < a.n) {
+                            const int u8 = v[r][0] & 0xFF;
+                            const float f = (float)(u8 - a.zp_act) * a.s_act;
+                            const size_t ridx = ((size_t)b * a.n + oc) * hw + rem;
+                            a.y_f32[ridx] = f;
+                            if (a.yolo_out) {
+                                const int e = oc % a.yolo_per;
+                                a.yolo_out[ridx] = (e == 2 || e == 3) ? f : ldsYL[u8];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KST, int ACT>
+static int c1_launch_sat(ConvArgs &a, hipStream_t st, int grid, int threads, size_t lds)
+{
+    if (a.store_mode == MI355_STORE_SATURATE) {
+        auto kern = conv1x1_ws_kernel<KST, ACT, true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MI355_EHIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+    } else {
+        auto kern = conv1x1_ws_kernel<KST, ACT, false>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MI355_EHIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
+template <int KST>
+static int c1_launch_act(ConvArgs &a, hipStream_t st, int grid, int threads, size_t lds)
+{
+    if (a.act == MI355_ACT_LEAKY) return c1_launch_sat<KST, MI355_ACT_LEAKY>(a, st, grid, threads, lds);
+    if (a.act == MI355_ACT_RELU6) return c1_launch_sat<KST, MI355_ACT_RELU6>(a, st, grid, threads, lds);
+    return c1_launch_sat<KST, MI355_ACT_LINEAR>(a, st, grid, threads, lds);
+}
+
+// shapes whose blob carries the weights-stationary plane (off_ws) for this kernel
+bool conv1x1_ws_eligible(int n, int c, int ksize)
+{
+    return ksize == 1 && (c == 128 || c == 256 || c == 512 || c == 1024) && n >= 1 && n <= 256;
+}
+
+// returns MI355_EINVAL when the shape is outside this kernel's domain (the caller falls back to conv_rows / conv_igemm)
+int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
+{
+    const int c = a.cb * a.nchunks;
+    if (!conv1x1_ws_eligible(a.n, c, a.ksize) || !a.ws || !a.y || a.acc_out || a.ypool || a.stride != 1) return MI355_EINVAL;
+    if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
+    // tiles of equal size, as few rounds of 256 workgroups as the 256-pixel tile limit allows
+    const long total = a.total_n;
+    const long rounds = (total + 256L * P1_GMAX * 32 - 1) / (256L * P1_GMAX * 32);
+    int tp = (int)((total + 256 * rounds - 1) / (256 * rounds));
+    if (tp < 16) tp = 16;
+    const int ntiles = (int)((total + tp - 1) / tp);
+    const int G = (tp + 31) / 32;
+    a.sm_tp = tp;
+    a.sm_ncell = 2 * G;  // 16-pixel chunks
+    size_t lds = (size_t)(c / 64) * a.sm_ncell * 1024;
+    a.lds_param_off = (int)lds;
+    const int n32 = (a.n + 31) & ~31;
+    lds += (size_t)n32 * 16 + 1024;
+    if (lds > 96 * 1024) return MI355_EINVAL;  // two workgroups per CU when a layer needs more than one round
+    const int nq = n32 / 32;
+    const int sets = 8 / nq > 0 ? 8 / nq : 1;  // at most 8 waves per workgroup
+    const int threads = sets * nq * 64;
+    switch (c) {
+    case 128: return c1_launch_act<4>(a, st, ntiles, threads, lds);
+    case 256: return c1_launch_act<8>(a, st, ntiles, threads, lds);
+    case 512: return c1_launch_act<16>(a, st, ntiles, threads, lds);
+    default: return c1_launch_act<32>(a, st, ntiles, threads, lds);
+    }
+}

@@ -89,6 +89,8 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st);
 int conv_rows_launch(ConvArgs &a, hipStream_t st, int bm, int bn);
 int conv_small_pool_launch(ConvArgs &a, hipStream_t st);
 bool conv_small_eligible(int n, int c, int ksize);
+int conv1x1_ws_launch(ConvArgs &a, hipStream_t st);
+bool conv1x1_ws_eligible(int n, int c, int ksize);
 int mi355_debug_flags_get();
 int conv_first_launch(AuxArgs &a, hipStream_t st);
 int conv_first_pool_launch(AuxArgs &a, hipStream_t st);

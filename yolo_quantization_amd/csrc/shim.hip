@@ -237,6 +237,10 @@ static int blob_layout(int n, int c, int ksize, ConvBlobHeader *h)
     h->off_shift = off; off = align16(off + (size_t)h->mpad * 4);
     h->off_mprime = off; off = align16(off + (size_t)h->mpad * 8);
     h->off_cwb = off; off = align16(off + (size_t)h->mpad * 4);
+    if (conv1x1_ws_eligible(n, c, ksize)) {  // conv1x1.hip: [n/32 quads][c/32 K-steps][64 lanes][16 B]
+        h->off_ws = off;
+        off = align16(off + (size_t)((n + 31) / 32) * (c / 32) * 1024);
+    }
     if (conv_small_eligible(n, c, ksize)) {
         h->off_ws = off;
         off = align16(off + (size_t)(n / 32) * (c == 16 ? 5 : (c == 32 ? 9 : 18)) * 1024);
@@ -301,7 +305,19 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
             }
         return MI355_OK;
     }
-    if (h.off_ws) {  // weights-stationary plane of conv_small.hip: lane (row lj, k-half kh) of K-step s
+    if (h.off_ws && ksize == 1) {  // weights-stationary plane of conv1x1.hip: K-step s = channels 32 s + 16 kh .. + 15
+        int8_t *ws = (int8_t *)(base + h.off_ws);
+        const int kst = c / 32;
+        for (int q = 0; q < (n + 31) / 32; ++q)
+            for (int s = 0; s < kst; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int oc = 32 * q + (lane & 31), khalf = lane >> 5;
+                    int8_t *dst = ws + ((size_t)(q * kst + s) * 64 + lane) * 16;
+                    for (int e = 0; e < 16; ++e)
+                        dst[e] = oc < n ? (int8_t)(wq[(size_t)oc * K + 32 * s + 16 * khalf + e] ^ 0x80) : 0;
+                }
+    }
+    if (h.off_ws && ksize == 3) {  // weights-stationary plane of conv_small.hip: lane (row lj, k-half kh) of K-step s
         int8_t *ws = (int8_t *)(base + h.off_ws);
         const int kst = (c == 16) ? 5 : (c == 32 ? 9 : 18);
         for (int mt = 0; mt < n / 32; ++mt)
@@ -428,6 +444,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     if (up != 1 && (h.cb != 64 || ypool)) return einval("conv_upsample_forward: 64-channel-chunk layers only");
     int rc = MI355_EINVAL;
     if (ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) rc = conv_small_pool_launch(a, st);  // few-channel layers
+    if (rc == MI355_EINVAL && a.ws && d->ksize == 1 && !(mi355_debug_flags_get() & 8192)) rc = conv1x1_ws_launch(a, st);  // 1x1 layers
     if (rc == MI355_EINVAL) rc = conv_igemm_launch(a, st);
     if (rc == MI355_EINVAL) return einval("conv_forward: no tile configuration fits this shape");
     if (rc != MI355_OK) return hip_fail(hipGetLastError(), "conv_igemm launch");
