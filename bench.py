@@ -201,13 +201,9 @@ def main():
                  if (i > 0 and fused[i - 1]) or inf["type"] in (binding.T_ROUTE, binding.T_YOLO)]
         ev_cost = min(empty) if empty else 0.0
         def on_rows_kernel(i, inf):
-            """conv_rows_i8_kernel launches (shim dispatch order): 64-byte channel chunks, not one of the conv + pool
-            kernels (conv_small.hip takes the fused pools) and not the weights-stationary 1x1 kernel (conv1x1.hip)."""
-            if inf["type"] != binding.T_CONV or inf["c"] % 64:
-                return False
-            if inf["size"] == 1:
-                return not (inf["c"] in (128, 256, 512, 1024) and inf["n"] <= 256)
-            return not fused[i]
+            """conv_rows_i8_kernel launches: 64-byte channel chunks, served by the implicit-GEMM family (the host records
+            which kernel family took each conv of the last step: conv_small / conv1x1 / conv_ws3 take the others)."""
+            return inf["type"] == binding.T_CONV and inf["c"] % 64 == 0 and net.conv_kernel(i) == 5
         mf_ops = mf_ms = all_ops = all_ms = 0.0
         for i, inf in enumerate(net.info):
             t_ms = max(float(ms[i + 1]) / nprof - ev_cost, 1e-6)

@@ -138,6 +138,7 @@ def test_conv1x1_weights_stationary_kernel(B, c, n, H, W, act, store):
     xt = binding.DevTensor.from_nchw(x, 23)
     args = (xt, wq, zp_w, 1, bias, mv, sv, 23, 128, 0.05, binding.ACT[act], store, binding.ACC_EXACT)
     got = binding.conv_forward(*args, want_acc=False, want_f32=True)
+    assert binding.shim().mi355_last_conv_kernel() == 3, "the call should be served by conv1x1.hip"
     if B <= 3:
         _, u8 = _oracle_layer(x, wq, zp_w, 1, 23, bias, mv, sv, 128, oracle.ACT[act], store, oracle.ACC_EXACT)
         assert np.array_equal(got["u8"].reshape(B, n, H * W), u8)
@@ -149,6 +150,36 @@ def test_conv1x1_weights_stationary_kernel(B, c, n, H, W, act, store):
         binding.shim().mi355_debug_flags(0)
     assert np.array_equal(got["u8"], rows["u8"])
     assert np.array_equal(got["f32"], rows["f32"])
+
+
+@pytest.mark.parametrize("B,c,n,H,W,act", [(64, 128, 256, 26, 26, "leaky"),    # layer 8 of yolov3-tiny: whole K per wave, 8 filter quads
+                                           (64, 256, 512, 13, 13, "leaky"),    # layers 10 / 14: two K parts, one image per tile
+                                           (30, 128, 64, 26, 26, "relu6"),     # 2 quads x 4 wave sets, 3 groups: one set idle
+                                           (60, 256, 64, 20, 17, "linear"),    # 2 quads x 2 K parts x 2 sets, ragged tiles across images
+                                           (40, 128, 512, 26, 26, "leaky"),    # 2 filter tiles, 7 groups
+                                           (120, 256, 256, 13, 13, "relu")])   # odd group count: K part 0 owns one more
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+def test_conv_ws3_weights_stationary_kernel(B, c, n, H, W, act, store):
+    """The 3x3 kernel for the middle of the net (conv_ws3.hip: 36 K-steps of weights per wave in registers, K parts
+    chained through LDS, one tile of consecutive pixels per workgroup) against the oracle on the first / last images and
+    against the row-image kernel on every byte (debug flag 16384 routes the same call there)."""
+    rng = np.random.default_rng(B + c + n + H + W)
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3, 2.0 ** -13, 2.0 ** -9)
+    xt = binding.DevTensor.from_nchw(x, 23)
+    args = (xt, wq, zp_w, 3, bias, mv, sv, 23, 23, 1.0, binding.ACT[act], store, binding.ACC_EXACT)
+    got = binding.conv_forward(*args, want_acc=False)
+    assert binding.shim().mi355_last_conv_kernel() == 4, "the call should be served by conv_ws3.hip"
+    sel = [0, B // 2, B - 1]
+    _, u8 = _oracle_layer(x[sel], wq, zp_w, 3, 23, bias, mv, sv, 23, oracle.ACT[act], store, oracle.ACC_EXACT)
+    assert np.array_equal(got["u8"][sel].reshape(3, n, H * W), u8)
+    binding.shim().mi355_debug_flags(16384)
+    try:
+        rows = binding.conv_forward(*args, want_acc=False)
+        assert binding.shim().mi355_last_conv_kernel() == 5
+    finally:
+        binding.shim().mi355_debug_flags(0)
+    assert np.array_equal(got["u8"], rows["u8"])
 
 
 @pytest.mark.parametrize("bm,bn,nt", [(128, 256, 0), (128, 128, 0), (64, 256, 0), (64, 128, 0), (32, 256, 0), (32, 128, 0),
@@ -453,7 +484,7 @@ def _run_host_net(cfg, wts, x_u8_batch, accum, store=binding.STORE_WRAP, graph=F
         net.forward()
     net.sync()
     outs = [net.pull(i) for i in range(net.n)]
-    info = [dict(inf, fused=net.is_fused(i)) for i, inf in enumerate(net.info)]
+    info = [dict(inf, fused=net.is_fused(i), kernel=net.conv_kernel(i)) for i, inf in enumerate(net.info)]
     net.close()
     return outs, info
 
@@ -562,6 +593,10 @@ def test_yolov3_tiny_batch64_properties(cfg_dir, tmp_path):
     outs, info = _run_host_net(cfg, wts, xb, binding.ACC_EXACT, graph=True, dump_int32=False)
     one, _ = _run_host_net(cfg, wts, x[None], binding.ACC_EXACT)
     assert sum(inf["fused"] for inf in info) == 5  # L0, L2, L4, L6 fused with their maxpools, L18 with its upsample
+    # every specialised kernel is exercised by the batch-64 net: first layer, conv + pool (16 / 32 / 64 channels), the
+    # weights-stationary 3x3 (conv_ws3) and 1x1 (conv1x1) kernels, the row-image kernel on the two deep 3x3 layers
+    assert {i: inf["kernel"] for i, inf in enumerate(info) if inf["type"] == binding.T_CONV} == \
+        {0: 1, 2: 2, 4: 2, 6: 2, 8: 4, 10: 4, 12: 5, 13: 3, 14: 4, 15: 3, 18: 3, 21: 5, 22: 3}
     for i, inf in enumerate(info):
         if inf["type"] == binding.T_YOLO or inf["fused"]:
             continue  # a fused conv's own (pre-pool) tensor is not stored

@@ -72,7 +72,7 @@ if __name__ == "__main__":
     ap.add_argument("--tile", type=int, nargs=2); ap.add_argument("--mode", choices=["flat", "patch"])
     ap.add_argument("--net", action="store_true"); ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--shift", type=int, default=13); ap.add_argument("--plan", action="store_true")
-    ap.add_argument("--nt", type=int, default=0); ap.add_argument("--dbg", type=int, default=0, help="mi355_debug_flags value (512 = no chunk rotation)"); ap.add_argument("--timeline", action="store_true"); ap.add_argument("--waveprof", action="store_true")
+    ap.add_argument("--nt", type=int, default=0); ap.add_argument("--dbg", type=int, default=0, help="mi355_debug_flags value (512 = no chunk rotation)"); ap.add_argument("--timeline", action="store_true"); ap.add_argument("--timeline3", action="store_true"); ap.add_argument("--waveprof", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="timing ablation of the K loop (results are wrong)")
     a = ap.parse_args()
     SHIFT = a.shift
@@ -108,6 +108,39 @@ if __name__ == "__main__":
         late = order[256:] if nb > 256 else []
         if len(late):
             print(f"  second-round blocks: {len(late)}, start p50 {np.median(t[0][late]) - t0:.2f} us")
+    elif a.timeline3:  # conv_ws3.hip per-wave phase timestamps (needs the -DMI355_ABLATE build)
+        S = binding.shim()
+        r = run(a.c, a.n, a.hw, a.k, a.batch, 1, None, None)
+        S.mi355_stream_sync(None)
+        ts = np.zeros((8, 4096, 8), np.int64)
+        S.mi355_debug_read_ts3.argtypes = [C.c_void_p]
+        assert S.mi355_debug_read_ts3(ts.ctypes.data) == 0
+        nb = int((ts[0, :, 0] > 0).sum())
+        t = ts[:, :nb, :].astype(np.float64) / 100.0
+        t0 = t[0].min()
+        print(json.dumps(r), "last kernel", S.mi355_last_conv_kernel())
+        print(f"blocks {nb}; span {t[7].max() - t0:.2f} us; start skew p50 {np.median(t[0]) - t0:.2f} max {t[0].max() - t0:.2f}")
+        names = ["stage image (loads + A issue + LDS writes)", "params + tables -> barrier", "box sums -> barrier", "A fragments landed", "phase 1 (partner's groups)", "barrier", "phase 2 / all groups (+ epilogue)"]
+        for i, nm in enumerate(names):
+            d = t[i + 1] - t[i]
+            if (t[i + 1] > 0).all() and (t[i] > 0).all():
+                print(f"  {nm:46s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
+        print("  phase 4->7:", f"p50 {np.median(t[7] - t[4]):6.2f}  max {(t[7] - t[4]).max():6.2f}")
+        d47 = (t[7] - t[4]).mean(axis=1)
+        print("  4->7 mean per workgroup, by blockIdx % 8 (XCD):", [round(float(d47[k::8].mean()), 2) for k in range(8)])
+        print("  4->7 of workgroups 0..31:", [round(float(v), 1) for v in d47[:32]])
+        print("  4->7 per wave index (mean):", [round(float(v), 2) for v in (t[7] - t[4]).mean(axis=0)])
+        wp = np.zeros((4096, 8, 4), np.int64)
+        S.mi355_debug_read_wp3.argtypes = [C.c_void_p]
+        assert S.mi355_debug_read_wp3(wp.ctypes.data) == 0
+        w = wp[:nb].astype(np.float64)
+        ng = np.full_like(w[:, :, 3], float(os.environ.get("WS3_GROUPS", "6")))
+        print("  shader clock over phases 4->7 (cycle counter / wall clock), GHz, by wave:", [round(float(v), 3) for v in (w[:, :, 3] / ((t[7] - t[4]) * 1e3)).mean(axis=0)])
+        for k, nm in enumerate(["tap offsets + first 4 B reads", "36-MFMA loop", "epilogue / partial store"]):
+            print(f"  shader clocks per group, {nm:32s} mean {np.mean(w[:, :, k] / ng):8.0f}   by wave {[int(v) for v in (w[:, :, k] / ng).mean(axis=0)]}")
+        print("  start (t4 - t0min) of workgroups 0..31:", [round(float(v), 1) for v in (t[4].mean(axis=1) - t0)[:32]])
+        d = t[7] - t[0]
+        print(f"  {'whole wave':46s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
     elif a.waveprof:  # per-wave stall profile of the 3x3 K loop (needs the -DMI355_ABLATE build)
         S = binding.shim()
         S.mi355_debug_flags(256 | a.dbg)

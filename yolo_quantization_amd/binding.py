@@ -77,6 +77,8 @@ def shim():
         L.mi355_conv_set_tile.argtypes = [ci, ci]
         L.mi355_conv_pool_forward.argtypes = [C.POINTER(ConvDesc), C.POINTER(Tensor), vp, C.POINTER(Tensor), C.POINTER(Tensor), vp]
         L.mi355_debug_flags.argtypes = [ci]
+        L.mi355_last_conv_kernel.argtypes = []
+        L.mi355_last_conv_kernel.restype = ci
         L.mi355_conv_yolo_forward.argtypes = [C.POINTER(ConvDesc), C.POINTER(Tensor), vp, C.POINTER(Tensor), vp, vp, ci, vp]
         L.mi355_conv_upsample_forward.argtypes = [C.POINTER(ConvDesc), C.POINTER(Tensor), vp, C.POINTER(Tensor), ci, vp]
         L.mi355_maxpool_forward.argtypes = [C.POINTER(Tensor), C.POINTER(Tensor), ci, ci, ci, vp]
@@ -255,6 +257,8 @@ def host():
             getattr(L, n).argtypes = [vp, ci]
         L.dnq_layer_prep.argtypes = [vp, ci] + [vp] * 6
         L.dnq_layer_is_fused.argtypes = [vp, ci]
+        L.dnq_layer_conv_kernel.argtypes = [vp, ci]
+        L.dnq_layer_conv_kernel.restype = ci
         _host = L
     return _host
 
@@ -340,6 +344,10 @@ class Net:
         if ty == T_YOLO or self.info[i]["quant_stop"]:
             out["f32"] = _as(self.H.dnq_layer_f32(self.h, i), cnt, C.c_float).copy()
         return out
+
+    def conv_kernel(self, i):
+        """mi355_last_conv_kernel code of the kernel that served conv layer i in the last forward pass (5 = conv_rows / conv_igemm)"""
+        return int(self.H.dnq_layer_conv_kernel(self.h, i))
 
     def is_fused(self, i):
         """conv i runs fused with the maxpool after it: its own uint8 tensor is not stored."""

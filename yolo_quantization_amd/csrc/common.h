@@ -150,6 +150,55 @@ __device__ __forceinline__ void requant_values(const int32_t (&accb)[4][NS], con
     }
 }
 
+// The same for NV independent values with a multiplier each (conv_ws3.hip requantises 8 channels of one pixel per call:
+// one fallback ballot, eight independent dependency chains).
+template <int ACT, bool SAT, int NV>
+__device__ __forceinline__ void requant_values_mp(const int32_t (&accb)[NV], const double (&mp)[NV], int zp_act, int32_t (&v)[NV])
+{
+    const int kleaky = (zp_act << 19) + ((1 << 19) - 1 - 5 * 0xCCCD);
+    // convert / multiply / convert in three passes over the NV values: left alone the compiler threads all of them
+    // through one register pair, and every FP64 instruction then waits for the full latency of the one before it
+    double d[NV];
+    int32_t q[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) d[i] = (double)accb[i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) d[i] = d[i] * mp[i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) q[i] = (int32_t)d[i];
+    __builtin_amdgcn_sched_barrier(0);
+    int32_t qmin = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int32_t qq = q[i];
+        if (ACT == MI355_ACT_LEAKY) {
+            qmin = min(qmin, qq);
+            if (SAT) qq = min(qq, 2047);
+            const int32_t p = max(qq, 0);
+            const int32_t nq = p - qq;
+            const int32_t m = __mul24(nq, -0xCCCD) + kleaky;
+            v[i] = (int32_t)(((uint32_t)p << 19) + (uint32_t)m) >> 19;
+        } else if (ACT == MI355_ACT_RELU6) {
+            v[i] = zp_act + max(qq, 0);
+        } else {
+            v[i] = zp_act + qq;
+        }
+    }
+    if (ACT == MI355_ACT_LEAKY && __builtin_amdgcn_ballot_w64(qmin < -40000) != 0) {  // keeps exactness on any data
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const uint32_t x = (0u - (uint32_t)q[i]) + 5u;
+            v[i] = q[i] < 0 ? zp_act - (int32_t)(x / 10u) : q[i] + zp_act;
+        }
+    }
+    if (SAT) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = min(max(v[i], 0), 255);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Wrap-safe accumulator ranges: max-pooling commutes with the requantisation where no stored byte wraps.
 // ---------------------------------------------------------------------------------------------------------

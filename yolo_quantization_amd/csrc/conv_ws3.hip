@@ -1,0 +1,425 @@
+// conv_ws3.hip -- 3x3 stride-1 INT8 convolution with the weights stationary in registers, for the middle of the net:
+// 128 or 256 input channels (K = 1152 / 2304: layers 8, 10 and 14 of yolov3-tiny at batch 64), when the whole layer is
+// one round of workgroups.  Through the row-image kernel these layers ran 18-36 barrier-synchronised K-steps behind
+// ~13 us of per-launch fixed cost with a third of every 128 x 384 tile idle (169-pixel images); here
+//   * a wave keeps 36 K-steps (tap x 4 blocks of 32 channels = 144 VGPRs) of the A fragments of its 32 filters for the
+//     whole launch.  With 128 input channels that is the whole K and a workgroup of 8 waves covers 256 filters; with
+//     256 input channels two waves (K parts) share a filter quad and a workgroup covers 128 filters;
+//   * the workgroup's tile is TP consecutive pixels (a whole 13x13 image, a quarter of a 26x26 one), staged once with
+//     coalesced 16-byte loads into a cell-major LDS image (cell = its C channels + 16 B of bank skew); per-cell channel
+//     sums come from the staging registers, 3x3 box sums and the pixel tables are built once per tile;
+//   * the K loop of a group of 32 pixels is 36 MFMAs fed by one ds_read_b128 each, four K-steps ahead, whose tap and
+//     channel-block offsets are immediates: no A reads from LDS, no barriers, no address arithmetic; the wave inside
+//     its MFMA loop runs at raised priority so that the other wave's requantisation fills the gaps, not the reverse;
+//   * K parts are chained through LDS with a single barrier: every wave first computes the partial sums of the groups
+//     it does not own and parks them; after the barrier it seeds the accumulators of its own groups with its
+//     partner's partial sums and finishes them (no extra additions).
+// Same mathematics and the same bytes as conv_rows.hip (signed-operand decomposition: see conv_igemm.hip).
+#include "kargs.h"
+
+#ifdef MI355_ABLATE
+// per-wave phase timestamps (100 MHz wall clock): tools/conv_microbench.py --timeline3
+#define W3_PHASES 8
+__device__ long long g_ws3_ts[W3_PHASES][4096][8];
+#define TS3(k)                                                                                                      \
+    do {                                                                                                            \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_ws3_ts[k][blockIdx.x][threadIdx.x >> 6] = wall_clock64(); \
+    } while (0)
+extern "C" int mi355_debug_read_ts3(long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws3_ts), sizeof(long long) * W3_PHASES * 4096 * 8) == hipSuccess ? 0 : -5;
+}
+// shader-clock sums per wave: [0] tap offsets + first B reads, [1] 36-MFMA loop, [2] epilogue / partial store, [3] groups
+__device__ long long g_ws3_wp[4096][8][4];
+#define WP3_DECL long long wp3[4] = {0, 0, 0, 0}; long long wp3_t = 0
+#define WP3_START() do { wp3_t = __builtin_readcyclecounter(); } while (0)
+#define WP3_MARK(k)                                              \
+    do {                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        const long long n_ = __builtin_readcyclecounter();       \
+        wp3[k] += n_ - wp3_t;                                    \
+        wp3_t = n_;                                              \
+    } while (0)
+#define WP3_STORE()                                                                                      \
+    do {                                                                                                 \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                                \
+            for (int k = 0; k < 4; ++k) g_ws3_wp[blockIdx.x][threadIdx.x >> 6][k] = wp3[k];              \
+    } while (0)
+extern "C" int mi355_debug_read_wp3(long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws3_wp), sizeof(long long) * 4096 * 8 * 4) == hipSuccess ? 0 : -5;
+}
+#else
+#define TS3(k) do { } while (0)
+#define WP3_DECL do { } while (0)
+#define WP3_START() do { } while (0)
+#define WP3_MARK(k) do { } while (0)
+#define WP3_STORE() do { } while (0)
+#endif
+
+constexpr int WS3_GMAX = 8;    // groups of 32 pixels per tile
+constexpr int WS3_UB = 8;      // 16-byte staging loads in flight per thread
+
+template <int KP, int ACT, bool SAT>
+__global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
+{
+    constexpr int KST = 36, PIECES = 8 * KP, PSH = (KP == 1) ? 3 : 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CELLB = (PIECES + 1) * 16;                    // bytes of an LDS image cell: its channels + 16 B of bank skew
+    const int ncell = a.sm_ncell;                               // cells per LDS image row = W + 2
+    const int RS = a.rows_cap;                                  // LDS image rows (row R lives at R % RS)
+    const int NQ = a.sm_nq, NF = 32 * NQ;
+    const int TP = a.sm_tp, G = (TP + 31) >> 5;
+    int *ldsS = reinterpret_cast<int *>(smem + a.sm_pieceb);              // [RS * ncell] per-cell channel sums
+    int *ldsSX = ldsS + ((RS * ncell + 3) & ~3);                          // [G][32] 3x3 box sum of the pixel
+    int *ldsBase = ldsSX + G * 32;                                        // [G][32] image row | column << 16 of tap (0,0)
+    int *ldsCell = ldsBase + G * 32;                                      // [G][32] output cell, -1: no pixel
+    double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [NF] folded multiplier
+    int *ldsDZ = reinterpret_cast<int *>(ldsMP + NF);                     // [NF] 128 - zp_w
+    int *ldsCB = ldsDZ + NF;                                              // [NF] cw + bias
+    char *ldsRed = smem + a.sm_red_off;                                   // K-part partial sums, 4 KiB per (quad, set, group)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = lane >> 5, lj = lane & 31;
+    const int wq = wave % NQ, kp = (wave / NQ) % KP, wset = wave / (NQ * KP), nset = 8 / (NQ * KP);
+    const int mt = blockIdx.x % a.mtiles, tile = blockIdx.x / a.mtiles;
+    const int f0 = mt * NF;                      // first filter of the workgroup
+    const int W1 = a.W + 1, hw = a.H * a.W;
+    const int p0 = tile * TP, p1 = min(p0 + TP, a.total_n);  // this tile's pixels [p0, p1)
+    const bool pow2 = a.hdr->pow2 == 1;
+    TS3(0);
+
+    // ---- tile geometry: image rows [first - 1, last + 1] of the flattened (b, y) row space, columns -1 .. W
+    const int b0 = p0 / hw, r0 = (p0 - b0 * hw) / a.W;
+    const int b1 = (p1 - 1) / hw, r1 = ((p1 - 1) - b1 * hw) / a.W;
+    const int gr_first = b0 * (a.H + 1) + r0 + 1;
+    const int nrows = b1 * (a.H + 1) + r1 + 1 - gr_first + 3;
+    const long org = (long)a.in_lead + (long)(gr_first - 1) * W1 - 1;
+    // LDS image: cell-major, row R (0 = the row above the tile's first pixel row) at cells [(R % RS) ncell, +ncell), cell
+    // c = column c - 1; a cell is its C channels followed by 16 B of skew (CELLB / 16 is odd: the 16 lanes of a
+    // B-fragment read, one cell apart, hit 16 different 16-byte bank groups).  Every tap / channel-block offset of a
+    // K-step is then a compile-time immediate of the ds_read.  RS < nrows only for tiles that are one whole image:
+    // the pad row below it aliases the pad row above it.
+    const int srows = min(nrows, RS);
+
+    // ---- stage the image: unit u = (cell, piece); a wave instruction reads 1 KiB of consecutive bytes
+    v4i wf[KST];
+    {
+        const int total_u = (srows * ncell) << PSH;
+        for (int u0 = 0; u0 < total_u; u0 += 512 * WS3_UB) {
+            v4i v[WS3_UB];
+#pragma unroll
+            for (int i = 0; i < WS3_UB; ++i) {
+                const int u = min(u0 + i * 512 + tid, total_u - 1);
+                const int lin = u >> PSH, piece = u & (PIECES - 1);
+                const int r = lin / ncell, c = lin - r * ncell;
+                long f = org + (long)r * W1 + c;
+                f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
+                v[i] = *reinterpret_cast<const v4i *>(a.x + (size_t)f * a.in_cs + piece * 16);
+            }
+            if (u0 == 0) {  // this wave's A fragments queue behind the first image batch
+#pragma unroll
+                for (int s = 0; s < KST; ++s)
+                    wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(((f0 >> 5) + wq) * KP + kp) * KST + s) * 1024 + lane * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < WS3_UB; ++i) {
+                const int u = u0 + i * 512 + tid;
+                const int lin = u >> PSH, piece = u & (PIECES - 1);
+                int t = 0;
+                t = __builtin_amdgcn_sdot4(v[i][0], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(v[i][1], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(v[i][2], 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4(v[i][3], 0x01010101, t, false);
+#pragma unroll
+                for (int m = 1; m < PIECES; m <<= 1) t += __shfl_xor(t, m);
+                if (u < total_u) {
+                    *reinterpret_cast<v4i *>(smem + lin * CELLB + piece * 16) = v[i];
+                    if (piece == 0) ldsS[lin] = t;
+                }
+            }
+        }
+    }
+    TS3(1);
+    // ---- per-channel parameters of the workgroup's filters
+    for (int i = tid; i < NF; i += 512) {
+        ldsMP[i] = a.mprime[f0 + i];
+        ldsDZ[i] = a.dzp[f0 + i];
+        ldsCB[i] = a.cwb[f0 + i];
+    }
+    // ---- pixels of the tile: image offset of tap (0,0), output cell
+    for (int idx = tid; idx < G * 32; idx += 512) {
+        const int p = p0 + idx;
+        const bool valid = p < p1;
+        const int pc = valid ? p : p1 - 1;  // idle lanes shadow the tile's last pixel
+        const int b = pc / hw, rem = pc - b * hw;
+        const int y = rem / a.W, x = rem - y * a.W;
+        ldsBase[idx] = (b * (a.H + 1) + y + 1 - gr_first) | (x << 16);
+        ldsCell[idx] = valid ? a.out_lead + (b * (a.H + 1) + (y + 1)) * W1 + x : -1;
+    }
+    __syncthreads();
+    TS3(2);
+    // first cell of image row rr + dy (rows past RS alias row 0: whole-image tiles)
+    auto row_cell = [&](int rr, int dy) {
+        const int R = rr + dy;
+        return (R >= RS ? R - RS : R) * ncell;
+    };
+    for (int idx = tid; idx < G * 32; idx += 512) {
+        const int rx = ldsBase[idx], rr = rx & 0xFFFF, x = rx >> 16;
+        int t = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) t += ldsS[row_cell(rr, dy) + x + dx];
+        ldsSX[idx] = t;
+    }
+    __syncthreads();
+    TS3(3);
+#ifdef MI355_ABLATE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    TS3(4);
+
+    // K-step s of this wave: tap s / 4, channels 128 kp + 32 (s % 4) + 16 kh .. + 15 = bytes [128 kp + 32 (s % 4) + 16 kh, +16)
+    // of the tap's cell.  The lane's k-half and the wave's K part go into its three row bases; the tap column and the
+    // channel block are immediates of the ds_read: no address arithmetic inside the K loop.
+    const char *X = smem;
+    const int lane_off = (8 * kp + kh) * 16;
+    const int lw = 32 * wq;  // first filter of the wave within the workgroup's parameter tables
+    const int Gs = (G - wset + nset - 1) / nset;      // groups of this wave set: wset, wset + nset, ..
+    const int hown = (Gs + 1) >> 1;                   // K part 0 owns the first hown of them, K part 1 the rest
+    const int gsmax = (G + nset - 1) / nset;
+    char *red = ldsRed + (size_t)((wset * NQ + wq) * gsmax) * 4096 + lane * 16;
+
+    // B fragments are fetched four K-steps ahead of the MFMA that consumes them (a ring of four register sets; the
+    // sched_barrier after every step keeps the compiler from sinking the reads back to their use)
+    WP3_DECL;
+#ifdef MI355_ABLATE
+    const long long wp3_c4 = __builtin_readcyclecounter();
+#endif
+    auto kloop = [&](v16i &acc, int rx) {
+        WP3_START();
+        int rowoff[3];
+        {
+            const int rr = rx & 0xFFFF, x = rx >> 16;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) rowoff[dy] = (row_cell(rr, dy) + x) * CELLB + lane_off;
+        }
+        auto ldb = [&](int s) {
+            const int tap = s >> 2;
+            return *reinterpret_cast<const v4i *>(X + rowoff[tap / 3] + (tap % 3) * CELLB + (s & 3) * 32);
+        };
+        v4i bq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[j] = ldb(j);
+        __builtin_amdgcn_sched_barrier(0);
+        WP3_MARK(0);
+        // the wave inside its MFMA loop outranks the one that requantises: the matrix pipe never waits for VALU traffic
+        __builtin_amdgcn_s_setprio(3);
+#ifdef MI355_ABLATE
+        if (a.debug & (1 << 17)) {  // timing ablation: no MFMA loop
+            __builtin_amdgcn_s_setprio(0);
+            WP3_MARK(1);
+            return;
+        }
+#endif
+#pragma unroll
+        for (int s = 0; s < KST; ++s) {
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s], bq[s & 3], acc, 0, 0, 0);
+            if (s + 4 < KST) bq[s & 3] = ldb(s + 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+#ifdef MI355_ABLATE
+        asm volatile("s_nop 0" ::"v"(acc[0]));  // the last MFMA's result: the mark below waits for it
+#endif
+        WP3_MARK(1);
+    };
+    auto seed_bias = [&](v16i &acc) {
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + lw + 8 * grp + 4 * kh);
+            acc[grp * 4 + 0] = c4.x; acc[grp * 4 + 1] = c4.y; acc[grp * 4 + 2] = c4.z; acc[grp * 4 + 3] = c4.w;
+        }
+    };
+    auto finish = [&](const v16i &acc, int g) {
+        const int sx = ldsSX[g * 32 + lj];
+        const int cell = ldsCell[g * 32 + lj];
+        uint8_t *dst = a.y + (size_t)(cell < 0 ? 0 : cell) * a.out_cs + f0 + lw + 4 * kh;
+#ifdef MI355_ABLATE
+        if (a.debug & (1 << 18)) {  // timing ablation: stores only
+            if (cell >= 0)
+                for (int grp = 0; grp < 4; ++grp) *reinterpret_cast<uint32_t *>(dst + 8 * grp) = acc[grp * 4] + sx;
+            return;
+        }
+        if (a.debug & (1 << 19)) return;  // timing ablation: no epilogue at all
+#endif
+        if (pow2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {  // 8 channels per call: eight independent chains, one fallback ballot
+                int32_t accb[8], v[8];
+                double mp[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int grp = 2 * half + h, cl = lw + 8 * grp + 4 * kh;
+                    const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + cl);
+                    const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        mp[4 * h + r] = ldsMP[cl + r];
+                        accb[4 * h + r] = acc[grp * 4 + r] + __mul24(dzv[r], sx);
+                    }
+                }
+                requant_values_mp<ACT, SAT, 8>(accb, mp, a.zp_act, v);
+                if (cell >= 0) {
+                    *reinterpret_cast<uint32_t *>(dst + 16 * half) = pack4_biased(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<uint32_t *>(dst + 16 * half + 8) = pack4_biased(v[4], v[5], v[6], v[7]);
+                }
+            }
+        } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int cl = lw + 8 * grp + 4 * kh, ch0 = f0 + cl;
+                int32_t v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (int32_t)requant_u8(acc[grp * 4 + r] + __mul24(ldsDZ[cl + r], sx), 0, a.mval[ch0 + r], a.sval[ch0 + r],
+                                               a.zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+                if (cell >= 0) *reinterpret_cast<uint32_t *>(dst + 8 * grp) = pack4_biased(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    if (KP == 1) {
+#pragma unroll 1
+        for (int i = 0; i < Gs; ++i) {
+            const int g = wset + i * nset;
+            v16i acc;
+            seed_bias(acc);
+            kloop(acc, ldsBase[g * 32 + lj]);
+            finish(acc, g);
+            WP3_MARK(2);
+        }
+    } else {
+        // phase 1: partial sums of the partner's groups
+        const int i0 = kp == 0 ? hown : 0, i1 = kp == 0 ? Gs : hown;
+#pragma unroll 1
+        for (int i = i0; i < i1; ++i) {
+            const int g = wset + i * nset;
+            v16i acc;
+            seed_bias(acc);
+            kloop(acc, ldsBase[g * 32 + lj]);
+            v4i *dst = reinterpret_cast<v4i *>(red + i * 4096);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j * 64] = v4i{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+            WP3_MARK(2);
+        }
+        TS3(5);
+        __syncthreads();
+        TS3(6);
+        // phase 2: this wave's own groups, seeded with the partner's partial sums
+        const int j0 = kp == 0 ? 0 : hown, j1 = kp == 0 ? hown : Gs;
+#pragma unroll 1
+        for (int i = j0; i < j1; ++i) {
+            const int g = wset + i * nset;
+            v16i acc;
+            const v4i *src = reinterpret_cast<const v4i *>(red + i * 4096);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4i t = src[j * 64];
+                acc[4 * j] = t[0]; acc[4 * j + 1] = t[1]; acc[4 * j + 2] = t[2]; acc[4 * j + 3] = t[3];
+            }
+            kloop(acc, ldsBase[g * 32 + lj]);
+            finish(acc, g);
+            WP3_MARK(2);
+        }
+    }
+    TS3(7);
+#ifdef MI355_ABLATE
+    wp3[3] = __builtin_readcyclecounter() - wp3_c4;
+#endif
+    WP3_STORE();
+}
+
+template <int KP, int ACT>
+static int w3_launch_sat(ConvArgs &a, hipStream_t st, int grid, size_t lds)
+{
+    if (a.store_mode == MI355_STORE_SATURATE) {
+        auto kern = conv_ws3_kernel<KP, ACT, true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MI355_EHIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    } else {
+        auto kern = conv_ws3_kernel<KP, ACT, false>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MI355_EHIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
+template <int KP>
+static int w3_launch_act(ConvArgs &a, hipStream_t st, int grid, size_t lds)
+{
+    if (a.act == MI355_ACT_LEAKY) return w3_launch_sat<KP, MI355_ACT_LEAKY>(a, st, grid, lds);
+    if (a.act == MI355_ACT_RELU6) return w3_launch_sat<KP, MI355_ACT_RELU6>(a, st, grid, lds);
+    return w3_launch_sat<KP, MI355_ACT_LINEAR>(a, st, grid, lds);
+}
+
+static int ws3_quads(int n, int c)
+{
+    const int kp = c / 128, q = n / 32, qmax = 8 / kp;
+    return q < qmax ? q : qmax;
+}
+
+// shapes whose blob carries the weights-stationary plane (off_ws) for this kernel: [n/32 quads][K part][36][64 lanes][16 B]
+bool conv_ws3_eligible(int n, int c, int ksize)
+{
+    if (ksize != 3 || (c != 128 && c != 256) || n % 32) return false;
+    const int nq = ws3_quads(n, c);
+    return (nq & (nq - 1)) == 0 && (n / 32) % nq == 0;
+}
+
+// returns MI355_EINVAL when the shape is outside this kernel's domain (the caller falls back to conv_rows / conv_igemm)
+int conv_ws3_launch(ConvArgs &a, hipStream_t st)
+{
+    const int c = a.cb * a.nchunks;
+    if (!conv_ws3_eligible(a.n, c, a.ksize) || !a.ws || !a.y || a.acc_out || a.ypool || a.y_f32 || a.yolo_out) return MI355_EINVAL;
+    if (a.stride != 1 || a.up != 1 || a.out_w < a.n) return MI355_EINVAL;
+    const int kp = c / 128, nq = ws3_quads(a.n, c), pieces = 8 * kp;
+    const int mtiles = a.n / (32 * nq), nset = 8 / (nq * kp);
+    // one round of workgroups: equal tiles of consecutive pixels
+    const long total = a.total_n;
+    const int want = 256 / mtiles > 0 ? 256 / mtiles : 1;
+    const int tp = (int)((total + want - 1) / want);
+    if (tp > WS3_GMAX * 32 || tp < 64) return MI355_EINVAL;  // several rounds / tiny batches: the row-image kernel is the better fit
+    const int ntiles = (int)((total + tp - 1) / tp);
+    const int G = (tp + 31) / 32, hw = a.H * a.W;
+    int rows_cap = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const long p0 = (long)t * tp, p1 = (p0 + tp < total ? p0 + tp : total) - 1;
+        const int b0 = (int)(p0 / hw), r0 = (int)((p0 - (long)b0 * hw) / a.W);
+        const int b1 = (int)(p1 / hw), r1 = (int)((p1 - (long)b1 * hw) / a.W);
+        const int nrows = b1 * (a.H + 1) + r1 - b0 * (a.H + 1) - r0 + 3;
+        if (nrows > rows_cap) rows_cap = nrows;
+    }
+    a.debug = mi355_debug_flags_get();
+    a.sm_tp = tp;
+    a.sm_nq = nq;
+    a.mtiles = mtiles;
+    if (tp == hw && total % hw == 0 && rows_cap == a.H + 2) rows_cap = a.H + 1;  // whole-image tiles: the two pad rows alias
+    a.sm_ncell = a.W + 2;
+    a.rows_cap = rows_cap;
+    const int cells = rows_cap * a.sm_ncell;
+    a.sm_pieceb = cells * (pieces + 1) * 16;  // bytes of the LDS image
+    size_t lds = (size_t)a.sm_pieceb;
+    lds += (size_t)((cells + 3) & ~3) * 4 + (size_t)G * 32 * 12;
+    lds = (lds + 15) & ~(size_t)15;
+    a.lds_param_off = (int)lds;
+    lds += (size_t)32 * nq * 16;
+    a.sm_red_off = (int)lds;
+    if (kp == 2) lds += (size_t)nq * nset * ((G + nset - 1) / nset) * 4096;
+    if (lds > 160 * 1024) return MI355_EINVAL;
+    return kp == 1 ? w3_launch_act<1>(a, st, mtiles * ntiles, lds) : w3_launch_act<2>(a, st, mtiles * ntiles, lds);
+}

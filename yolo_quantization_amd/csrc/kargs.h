@@ -35,6 +35,7 @@ struct ConvArgs {
     const int8_t *ws;        // conv_small: weights-stationary A fragments [m-tile][k-step][lane][16 B] or null
     int sm_ncell, sm_pieceb; // conv_small: cells per LDS image row; bytes of one 16-channel piece plane
     int sm_tp;               // conv_mid_pool: pooled pixels per tile
+    int sm_nq, sm_red_off;   // conv_ws3: filter quads (waves) per K part and workgroup; LDS offset of the K-part partial sums
     int up;                  // conv_rows: fused nearest-neighbour upsample factor of the stored tensor (1 = none)
     float *yolo_out;         // fused yolo head: activated copy of y_f32 (same layout) or null
     int yolo_per;            // classes + 5
@@ -91,6 +92,8 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st);
 bool conv_small_eligible(int n, int c, int ksize);
 int conv1x1_ws_launch(ConvArgs &a, hipStream_t st);
 bool conv1x1_ws_eligible(int n, int c, int ksize);
+int conv_ws3_launch(ConvArgs &a, hipStream_t st);
+bool conv_ws3_eligible(int n, int c, int ksize);
 int mi355_debug_flags_get();
 int conv_first_launch(AuxArgs &a, hipStream_t st);
 int conv_first_pool_launch(AuxArgs &a, hipStream_t st);

@@ -205,6 +205,9 @@ int mi355_tensor_to_nchw(const mi355_tensor *t, uint8_t *nchw, void *stream)
 static int default_bm(int n) { return n >= 128 ? 128 : (n > 32 ? 64 : 32); }
 static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+static thread_local int g_last_kernel = 0;
+extern "C" int mi355_last_conv_kernel(void) { return g_last_kernel; }
+
 static int blob_layout(int n, int c, int ksize, ConvBlobHeader *h)
 {
     if (n <= 0 || c <= 0 || (ksize != 1 && ksize != 3)) return MI355_EINVAL;
@@ -240,6 +243,10 @@ static int blob_layout(int n, int c, int ksize, ConvBlobHeader *h)
     if (conv1x1_ws_eligible(n, c, ksize)) {  // conv1x1.hip: [n/32 quads][c/32 K-steps][64 lanes][16 B]
         h->off_ws = off;
         off = align16(off + (size_t)((n + 31) / 32) * (c / 32) * 1024);
+    }
+    if (conv_ws3_eligible(n, c, ksize)) {  // conv_ws3.hip: [n/32 quads][c/128 K parts][36 K-steps][64 lanes][16 B]
+        h->off_ws = off;
+        off = align16(off + (size_t)n * c * 9);
     }
     if (conv_small_eligible(n, c, ksize)) {
         h->off_ws = off;
@@ -317,7 +324,22 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
                         dst[e] = oc < n ? (int8_t)(wq[(size_t)oc * K + 32 * s + 16 * khalf + e] ^ 0x80) : 0;
                 }
     }
-    if (h.off_ws && ksize == 3) {  // weights-stationary plane of conv_small.hip: lane (row lj, k-half kh) of K-step s
+    if (h.off_ws && conv_ws3_eligible(n, c, ksize)) {  // conv_ws3.hip: K-step s of part kp = tap s / 4, channels 128 kp + 32 (s % 4) + 16 kh ..
+        int8_t *ws = (int8_t *)(base + h.off_ws);
+        const int kparts = c / 128;
+        for (int q = 0; q < n / 32; ++q)
+            for (int kp = 0; kp < kparts; ++kp)
+                for (int s = 0; s < 36; ++s)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int oc = 32 * q + (lane & 31), khalf = lane >> 5, tap = s >> 2;
+                        int8_t *dst = ws + ((size_t)((q * kparts + kp) * 36 + s) * 64 + lane) * 16;
+                        for (int e = 0; e < 16; ++e) {
+                            const int ci = 128 * kp + 32 * (s & 3) + 16 * khalf + e;
+                            dst[e] = (int8_t)(wq[(size_t)oc * K + (ci * 3 + tap / 3) * 3 + tap % 3] ^ 0x80);
+                        }
+                    }
+    }
+    if (h.off_ws && conv_small_eligible(n, c, ksize)) {  // weights-stationary plane of conv_small.hip: lane (row lj, k-half kh) of K-step s
         int8_t *ws = (int8_t *)(base + h.off_ws);
         const int kst = (c == 16) ? 5 : (c == 32 ? 9 : 18);
         for (int mt = 0; mt < n / 32; ++mt)
@@ -404,8 +426,10 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
         if (d->accum_mode == MI355_ACC_REF_F32) {
             if (ypool) return einval("conv_pool_forward: not in ref-f32 mode");
             if (!w_u8 || !zp_w) return einval("conv_forward: ref-f32 mode needs the raw weights_uint8 / zp_w");
+            g_last_kernel = 6;
             return conv_ref_f32_launch(a, st);
         }
+        g_last_kernel = 1;
         if (x->cs != 4) return einval("conv_forward: first layer expects a cs==4 image tensor");
         if (ypool) {
             int rc = (mi355_debug_flags_get() & 1024) ? MI355_EINVAL : conv_first_mfma_pool_launch(a, st);
@@ -443,9 +467,10 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     a.up = up;
     if (up != 1 && (h.cb != 64 || ypool)) return einval("conv_upsample_forward: 64-channel-chunk layers only");
     int rc = MI355_EINVAL;
-    if (ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) rc = conv_small_pool_launch(a, st);  // few-channel layers
-    if (rc == MI355_EINVAL && a.ws && d->ksize == 1 && !(mi355_debug_flags_get() & 8192)) rc = conv1x1_ws_launch(a, st);  // 1x1 layers
-    if (rc == MI355_EINVAL) rc = conv_igemm_launch(a, st);
+    if (ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) { rc = conv_small_pool_launch(a, st); g_last_kernel = 2; }  // few-channel layers
+    if (rc == MI355_EINVAL && a.ws && d->ksize == 1 && !(mi355_debug_flags_get() & 8192)) { rc = conv1x1_ws_launch(a, st); g_last_kernel = 3; }  // 1x1 layers
+    if (rc == MI355_EINVAL && a.ws && d->ksize == 3 && !ypool && !(mi355_debug_flags_get() & 16384)) { rc = conv_ws3_launch(a, st); g_last_kernel = 4; }  // mid layers
+    if (rc == MI355_EINVAL) { rc = conv_igemm_launch(a, st); g_last_kernel = 5; }
     if (rc == MI355_EINVAL) return einval("conv_forward: no tile configuration fits this shape");
     if (rc != MI355_OK) return hip_fail(hipGetLastError(), "conv_igemm launch");
     return rc;

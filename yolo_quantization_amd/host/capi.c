@@ -64,6 +64,13 @@ int dnq_layer_prep(network *net, int i, int32_t *biases_int32, double *M_value, 
 
 /* 1 when layer i (a conv) runs fused with the maxpool / upsample after it in the current configuration: its own uint8
  * tensor is then not stored (only the pooled / upsampled one is) */
+/* kernel family (mi355_last_conv_kernel codes) that served conv layer i in the last forward pass, 0 for other layers */
+int dnq_layer_conv_kernel(network *net, int i)
+{
+    if (i < 0 || i >= net->n) return 0;
+    return net->layers[i].conv_kernel;
+}
+
 int dnq_layer_is_fused(network *net, int i)
 {
     if (i < 0 || i >= net->n) return 0;

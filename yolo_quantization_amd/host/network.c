@@ -412,6 +412,7 @@ static void run_layers(network *netp)
         net.fused_up_t = fuse_up ? &netp->layers[i + 1].out_t : NULL;
         net.fused_up_stride = fuse_up ? netp->layers[i + 1].stride : 1;
         l.forward_gpu(l, net);
+        if (l.type == CONVOLUTIONAL) netp->layers[i].conv_kernel = mi355_last_conv_kernel();
         if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
         if (fuse_up) { /* the upsample layer's tensor was written by the conv kernel: hand it on and skip the layer */
             ++i;
