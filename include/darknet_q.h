@@ -116,6 +116,8 @@ struct network {
     int gpu_index;
     void *stream;
     uint8_t *input_uint8_gpu; /* reference layout on the device */
+    float *quant_mm_gpu;      /* device scratch of the layer-0 quantiser: max, min of the float image */
+    float *input_gpu;         /* batch x inputs floats on the device: the letterboxed images of the device input path */
     mi355_tensor input_t;     /* cs==4 image tensor */
     const mi355_tensor *cur_t; /* uint8 hand-off: the reference's `net.input_uint8 = l.output_uint8_final` */
     const float *cur_f32_gpu;  /* float hand-off: `net.input = l.output` */
@@ -156,6 +158,13 @@ void quantization_weights_and_activations(network *net);
 /* same, but with the layer-0 input scale / zero point given instead of derived from net->input (serving mode:
  * uint8 images arrive already quantised) */
 void quantization_weights_and_activations_fixed_input(network *net, float in_scale, uint8_t in_zp);
+/* the layer-0 quantiser (ref: src/blas.c:279 -> :108-168) on float images already in HBM: device min / max + quantise,
+ * layer 0 re-derived only when scale / zero point change */
+void quantization_weights_and_activations_gpu(network *net, const float *input_gpu);
+/* Input path on the device: letterbox_image (ref: src/image.c:812-831) of a planar float image in HBM
+ * into batch slot `slot` of the network's float input, then the layer-0 quantiser over the whole batch. */
+void network_letterbox_input_gpu(network *net, int slot, const float *im_gpu, int imw, int imh);
+void network_quantize_input_gpu(network *net);
 /* the host half of the prep only (per-channel integers + packed blobs, no device needed) */
 void quantization_prep_host(network *net, float in_scale, uint8_t in_zp);
 

@@ -165,6 +165,16 @@ int mi355_maxpool_forward(const mi355_tensor *x, const mi355_tensor *y, int size
 int mi355_upsample_forward(const mi355_tensor *x, const mi355_tensor *y, int stride, void *stream);
 /* forward_route_layer_quant (ref: src/route_layer.c:107-130): channel concat of n inputs, no rescale */
 int mi355_route_forward(const mi355_tensor *const *xs, int n, const mi355_tensor *y, void *stream);
+/* letterbox_image (ref: src/image.c:812-831; bilinear resize_image :1199-1242, embed_image :428-439, fill 0.5): planar
+ * float image [c][imh][imw] in device memory -> [c][h][w], aspect ratio kept, centred.  Bit-identical floats. */
+int mi355_letterbox_forward(const float *im_f32, int imw, int imh, int c, float *out_f32, int w, int h, void *stream);
+/* Layer-0 input quantiser (ref: quant_weights_with_min_max_channel with one channel, src/blas.c:108-168, called on the
+ * float image at src/blas.c:279), both halves on device memory.  mi355_image_minmax: minmax[0] = max(x, 0.0f),
+ * minmax[1] = min(x, 0.0f) (-0.0f when no element is negative) over `count` floats, the reference's seeds and
+ * comparisons (NaNs are skipped).  mi355_image_quantize: out[k] = clamp((int)(float)(round((double)(x[k] / scale)) +
+ * (double)zero_point), 0, 255), the reference's evaluation order (:160-165). */
+int mi355_image_minmax(const float *x_f32, long count, float *minmax, void *stream);
+int mi355_image_quantize(const float *x_f32, long count, float scale, int zero_point, uint8_t *out_u8, void *stream);
 /* yolo head activations (ref: src/yolo_layer.c:132-146) on the float head tensor [B][n*(classes+5)][H*W] */
 int mi355_yolo_forward(const float *in, float *out, int B, int n, int classes, int H, int W, void *stream);
 

@@ -281,6 +281,63 @@ int orc_quantize_image(const float *x, int count, uint8_t *out, float *scale, ui
     return 0;
 }
 
+/* ------------------------------------------------------------------ src/image.c:1199-1242 (resize_image) and
+ * :812-831 (letterbox_image), planar float images [c][h][w].  Two separable passes, each product rounded to float on its
+ * own and the two terms added afterwards (set_pixel then add_pixel); the last column copies the source's last column;
+ * the last row takes only its first term -- with whatever (int)(r * h_scale) turns out to be.  The reference's -Ofast
+ * build targets baseline x86-64 (no FMA) and these expressions leave nothing to reassociate, so plain IEEE float
+ * arithmetic reproduces it (pinned by the 'lbx_*' golden vectors). */
+static void orc_resize_image(const float *im, int imw, int imh, int c, int w, int h, float *out)
+{
+    float *part = malloc(sizeof(float) * (size_t)w * imh * c);
+    const float w_scale = (float)(imw - 1) / (w - 1);
+    const float h_scale = (float)(imh - 1) / (h - 1);
+    for (int k = 0; k < c; ++k)
+        for (int r = 0; r < imh; ++r)
+            for (int x = 0; x < w; ++x) {
+                float val;
+                if (x == w - 1 || imw == 1) {
+                    val = im[((size_t)k * imh + r) * imw + imw - 1];
+                } else {
+                    const float sx = x * w_scale;
+                    const int ix = (int)sx;
+                    const float dx = sx - ix;
+                    val = (1 - dx) * im[((size_t)k * imh + r) * imw + ix] + dx * im[((size_t)k * imh + r) * imw + ix + 1];
+                }
+                part[((size_t)k * imh + r) * w + x] = val;
+            }
+    for (int k = 0; k < c; ++k)
+        for (int r = 0; r < h; ++r) {
+            const float sy = r * h_scale;
+            const int iy = (int)sy;
+            const float dy = sy - iy;
+            for (int x = 0; x < w; ++x) {
+                float val = (1 - dy) * part[((size_t)k * imh + iy) * w + x];
+                if (!(r == h - 1 || imh == 1)) val += dy * part[((size_t)k * imh + iy + 1) * w + x];
+                out[((size_t)k * h + r) * w + x] = val;
+            }
+        }
+    free(part);
+}
+
+int orc_letterbox_image(const float *im, int imw, int imh, int c, int w, int h, float *out)
+{
+    int new_w, new_h;
+    if (((float)w / imw) < ((float)h / imh)) { new_w = w; new_h = (imh * w) / imw; }
+    else { new_h = h; new_w = (imw * h) / imh; }
+    if (new_w < 2 || new_h < 2 || imw < 1 || imh < 1) return -1; /* the reference divides by (w - 1), (h - 1) */
+    float *res = malloc(sizeof(float) * (size_t)new_w * new_h * c);
+    orc_resize_image(im, imw, imh, c, new_w, new_h, res);
+    for (size_t i = 0; i < (size_t)w * h * c; ++i) out[i] = .5f; /* fill_image(boxed, .5) */
+    const int dx = (w - new_w) / 2, dy = (h - new_h) / 2;
+    for (int k = 0; k < c; ++k)
+        for (int y = 0; y < new_h; ++y)
+            for (int x = 0; x < new_w; ++x)
+                out[((size_t)k * h + dy + y) * w + dx + x] = res[((size_t)k * new_h + y) * new_w + x];
+    free(res);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ src/yolo_layer.c:132-146 */
 static float logistic(float x) { return (float)(1. / (1. + exp(-(double)x))); } /* src/activations.h:39 */
 void orc_yolo_forward(const float *in, int n, int classes, int h, int w, float *out)

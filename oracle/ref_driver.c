@@ -202,6 +202,16 @@ void refdrv_quantize_image(float *x, int n, uint8_t *out, float *scale, uint8_t 
     free(tmp16);
 }
 
+/* letterbox_image of the reference itself (src/image.c:812-831) on a planar float image */
+void refdrv_letterbox(float *im, int imw, int imh, int c, int w, int h, float *out)
+{
+    image src;
+    src.w = imw; src.h = imh; src.c = c; src.data = im;
+    image boxed = letterbox_image(src, w, h);
+    memcpy(out, boxed.data, sizeof(float) * (size_t)w * h * c);
+    free_image(boxed);
+}
+
 /* get_yolo_detections of the reference itself (src/yolo_layer.c:316-345) on yolo layer i after a forward: records in
  * the layout of orc_yolo_detections (oracle.c).  Also hands out the layer's anchors / mask for the restatement. */
 int refdrv_yolo_detections(void *h, int i, int imw, int imh, float thresh, int relative, float *recs, int max_recs)

@@ -76,6 +76,10 @@ def tiny_unit(seed, act_gain, name="tiny_unit"):
     print(f"{name} seed {seed}: wrote {len(d)} arrays")
 
 
+LBX_CASES = {"wide": (3, 37, 53, 48, 48), "tall": (3, 64, 20, 32, 32), "up": (3, 9, 7, 40, 40), "same": (3, 24, 24, 24, 24),
+             "odd": (3, 31, 45, 26, 38), "gray": (1, 50, 33, 20, 28)}
+
+
 def funcs():
     L = refdrv.lib()
     rng = np.random.default_rng(42)
@@ -116,6 +120,14 @@ def funcs():
         L.refdrv_quantize_image(xx.ctypes.data, x.size, out.ctypes.data, C.byref(s), C.byref(z))
         d[f"qimg_{name}_x"] = x; d[f"qimg_{name}_u8"] = out
         d[f"qimg_{name}_scale"] = np.float32(s.value); d[f"qimg_{name}_zp"] = np.uint8(z.value)
+    # letterbox_image (bilinear resize + centre on 0.5 grey): wide, tall, up-scaled, same-size and odd-sized sources
+    L.refdrv_letterbox.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    for name, (c, imh, imw, h, w) in LBX_CASES.items():
+        im = rng.uniform(0, 1, (c, imh, imw)).astype(np.float32)
+        out = np.zeros((c, h, w), np.float32)
+        src = im.copy()
+        L.refdrv_letterbox(src.ctypes.data, imw, imh, c, w, h, out.ctypes.data)
+        d[f"lbx_{name}_im"] = im; d[f"lbx_{name}_out"] = out
     np.savez_compressed(os.path.join(HERE, "funcs.npz"), **d)
     print("funcs: wrote", len(d), "arrays")
 

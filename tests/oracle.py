@@ -42,6 +42,7 @@ def lib():
         L.orc_quant_multiplier.argtypes = [cf, vp, vp]
         L.orc_prep_conv.argtypes = [ci, ci, ci, vp, vp, vp, cf, u8, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_quantize_image.argtypes = [vp, ci, vp, vp, vp]
+        L.orc_letterbox_image.argtypes = [vp, ci, ci, ci, ci, ci, vp]
         L.orc_yolo_forward.argtypes = [vp, ci, ci, ci, ci, vp]
         L.orc_yolo_detections.restype = ci
         L.orc_yolo_detections.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, C.c_float, ci, vp, ci]
@@ -138,6 +139,16 @@ def quant_multiplier(m):
     m0 = C.c_int32(); sh = C.c_int()
     rc = lib().orc_quant_multiplier(float(m), C.byref(m0), C.byref(sh))
     return rc, m0.value, sh.value
+
+
+def letterbox_image(im, h, w):
+    """im: float32 [c][imh][imw] -> [c][h][w]"""
+    im = np.ascontiguousarray(im, np.float32)
+    c, imh, imw = im.shape
+    out = np.empty((c, h, w), np.float32)
+    rc = lib().orc_letterbox_image(_p(im), imw, imh, c, w, h, _p(out))
+    assert rc == 0
+    return out
 
 
 def quantize_image(x):

@@ -608,6 +608,129 @@ def test_yolov3_tiny_batch64_properties(cfg_dir, tmp_path):
         assert hs[0] != hs[1]
 
 
+def _device_quantize(x):
+    S = binding.shim()
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    xd = binding.DevBuf.from_numpy(x)
+    mm = binding.DevBuf(16)
+    binding.check(S.mi355_image_minmax(xd.ptr, x.size, mm.ptr, None), "image_minmax")
+    mx, mn = mm.to_numpy(np.float32, 2)
+    return xd, mx, mn
+
+
+@pytest.mark.parametrize("case", ["qimg_signed", "qimg_unit", "image_like", "negatives", "odd_count", "ties", "tiny_values", "nan"])
+def test_image_quantiser_on_device(golden_dir, case):
+    """SURVEY 8(f) row 2, quantiser half: mi355_image_minmax / mi355_image_quantize against the oracle's layer-0
+    quantiser (itself pinned on vectors the reference produced: funcs.npz qimg_*): min / max, then every byte."""
+    rng = np.random.default_rng(len(case))
+    if case.startswith("qimg_"):
+        x = np.load(os.path.join(golden_dir, "funcs.npz"))[case + "_x"]
+    elif case == "image_like":
+        x = rng.random(3 * 416 * 416, dtype=np.float32)
+    elif case == "negatives":
+        x = rng.uniform(-0.7, 1.3, 70001).astype(np.float32)
+    elif case == "odd_count":
+        x = rng.random(1001, dtype=np.float32)
+    elif case == "ties":  # x / scale lands on k + 0.5 exactly: round half away from zero
+        x = (np.arange(0, 511, dtype=np.float32) * np.float32(0.5)) * np.float32(1.0)
+        x = np.concatenate([x, [np.float32(255.0)]]).astype(np.float32)  # scale == 1
+    elif case == "tiny_values":
+        x = (rng.random(4099, dtype=np.float32) * np.float32(3e-30)).astype(np.float32)
+    else:
+        x = rng.random(5000, dtype=np.float32)
+        x[::97] = np.nan  # comparisons with NaN are false in the reference's min / max loops: skipped
+    want_u8, s, z = oracle.quantize_image(x)
+    xd, mx, mn = _device_quantize(x)
+    finite = x[np.isfinite(x)]
+    assert mx == max(np.float32(0), finite.max()) and mn == min(np.float32(0), finite.min())
+    out = binding.DevBuf(x.size + 16)
+    binding.check(binding.shim().mi355_image_quantize(xd.ptr, x.size, s, int(z), out.ptr, None), "image_quantize")
+    got = out.to_numpy(np.uint8, x.size)
+    if case == "nan":  # (int)NaN is undefined in C: compare the defined elements
+        keep = np.isfinite(x)
+        assert np.array_equal(got[keep], want_u8.ravel()[keep])
+    else:
+        assert np.array_equal(got, want_u8.ravel())
+
+
+@pytest.mark.parametrize("name", ["wide", "tall", "up", "same", "odd", "gray"])
+def test_letterbox_on_device_vs_reference_vectors(golden_dir, name):
+    """mi355_letterbox_forward against the images the reference's letterbox_image produced (funcs.npz lbx_*): bit for bit."""
+    f = np.load(os.path.join(golden_dir, "funcs.npz"))
+    im, want = f[f"lbx_{name}_im"], f[f"lbx_{name}_out"]
+    c, imh, imw = im.shape
+    _, h, w = want.shape
+    src = binding.DevBuf.from_numpy(im)
+    dst = binding.DevBuf(want.nbytes)
+    binding.check(binding.shim().mi355_letterbox_forward(src.ptr, imw, imh, c, dst.ptr, w, h, None), "letterbox")
+    got = dst.to_numpy(np.float32, want.size).reshape(want.shape)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("imh,imw", [(480, 640), (375, 500), (1080, 1920), (416, 416), (300, 200)])
+def test_letterbox_416_vs_oracle(imh, imw):
+    """camera-sized sources into the 416 x 416 network input, against the oracle restatement"""
+    rng = np.random.default_rng(imh + imw)
+    im = rng.random((3, imh, imw), dtype=np.float32)
+    want = oracle.letterbox_image(im, 416, 416)
+    src = binding.DevBuf.from_numpy(im)
+    dst = binding.DevBuf(want.nbytes)
+    binding.check(binding.shim().mi355_letterbox_forward(src.ptr, imw, imh, 3, dst.ptr, 416, 416, None), "letterbox")
+    got = dst.to_numpy(np.float32, want.size).reshape(want.shape)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_net_device_input_path_equals_host_path(cfg_dir, tmp_path):
+    """network_letterbox_input_gpu + network_quantize_input_gpu == oracle letterbox + host quantiser: same uint8 network
+    input for a batch of differently sized images, same layer outputs."""
+    cfg = os.path.join(cfg_dir, "tiny_unit.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=6)
+    rng = np.random.default_rng(10)
+    dev = binding.Net(cfg, wts, batch=3, accum=binding.ACC_EXACT, dump_int32=False)
+    host = binding.Net(cfg, wts, batch=3, accum=binding.ACC_EXACT, dump_int32=False)
+    c, h, w = dev.info[0]["c"], dev.info[0]["h"], dev.info[0]["w"]
+    images = [rng.random((c, ih, iw), dtype=np.float32) for ih, iw in [(30, 40), (17, 9), (12, 12)]]
+    boxed = np.stack([oracle.letterbox_image(im, h, w) for im in images])
+    want_in = host.prepare_from_float(boxed)
+    got_in = dev.prepare_from_images_gpu(images)
+    assert np.array_equal(got_in, want_in)
+    host.forward(); host.sync(); dev.forward(); dev.sync()
+    for i in range(dev.n):
+        if not dev.is_fused(i):
+            a, b = dev.pull(i), host.pull(i)
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (i, k)
+    host.close(); dev.close()
+
+
+def test_net_input_quantiser_on_device_equals_host(cfg_dir, tmp_path):
+    """quantization_weights_and_activations_gpu == quantization_weights_and_activations: same uint8 input, same layer
+    outputs; a second batch with a different dynamic range re-derives layer 0 in place (and refills the input pads)."""
+    cfg = os.path.join(cfg_dir, "tiny_unit.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=5)
+    rng = np.random.default_rng(9)
+    dev = binding.Net(cfg, wts, batch=2, accum=binding.ACC_EXACT, dump_int32=False)
+    n_in = dev.inputs
+    for lo, hi in [(0.0, 1.0), (-0.4, 0.8), (0.0, 0.37)]:
+        x = rng.uniform(lo, hi, 2 * n_in).astype(np.float32)
+        host = binding.Net(cfg, wts, batch=2, accum=binding.ACC_EXACT, dump_int32=False)
+        want_in = host.prepare_from_float(x)
+        host.forward(); host.sync()
+        got_in = dev.prepare_from_float_gpu(x)
+        dev.forward(); dev.sync()
+        assert np.array_equal(got_in, want_in), (lo, hi)
+        for i in range(dev.n):
+            if dev.is_fused(i):
+                continue
+            a, b = dev.pull(i), host.pull(i)
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (lo, hi, i, k)
+        host.close()
+    dev.close()
+
+
 @pytest.mark.parametrize("name", ["tiny_unit", "s2_unit"])
 def test_yolo_detections_on_device_vs_reference(golden_dir, cfg_dir, tmp_path, name):
     """get_yolo_detections + correct_yolo_boxes on the device (network_yolo_detections_gpu ->

@@ -55,6 +55,15 @@ def test_quantize_image_known_answer(funcs, name):
     assert np.array_equal(u8, funcs[f"qimg_{name}_u8"])
 
 
+@pytest.mark.parametrize("name", ["wide", "tall", "up", "same", "odd", "gray"])
+def test_letterbox_image_known_answer(funcs, name):
+    """letterbox_image + resize_image (src/image.c:812-831, :1199-1242) against images the reference produced: every
+    float bit for bit (the quirk of the last row -- only its first term, with (int)(r * h_scale) as it comes -- included)."""
+    want = funcs[f"lbx_{name}_out"]
+    got = oracle.letterbox_image(funcs[f"lbx_{name}_im"], want.shape[1], want.shape[2])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("name", ["tiny_unit", "s2_unit"])
 @pytest.mark.parametrize("seed", [1, 2])
 @pytest.mark.parametrize("accum", [oracle.ACC_REF_F32, oracle.ACC_EXACT])

@@ -85,6 +85,9 @@ def shim():
         L.mi355_upsample_forward.argtypes = [C.POINTER(Tensor), C.POINTER(Tensor), ci, vp]
         L.mi355_route_forward.argtypes = [C.POINTER(C.POINTER(Tensor)), ci, C.POINTER(Tensor), vp]
         L.mi355_yolo_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+        L.mi355_image_minmax.argtypes = [vp, C.c_long, vp, vp]
+        L.mi355_letterbox_forward.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp]
+        L.mi355_image_quantize.argtypes = [vp, C.c_long, C.c_float, ci, vp, vp]
         _shim = L
     return _shim
 
@@ -227,6 +230,9 @@ def host():
         L.free_network.argtypes = [vp]
         L.quantization_weights_and_activations.argtypes = [vp]
         L.quantization_weights_and_activations_fixed_input.argtypes = [vp, C.c_float, C.c_uint8]
+        L.quantization_weights_and_activations_gpu.argtypes = [vp, vp]
+        L.network_letterbox_input_gpu.argtypes = [vp, ci, vp, ci, ci]
+        L.network_quantize_input_gpu.argtypes = [vp]
         L.quantization_prep_host.argtypes = [vp, C.c_float, C.c_uint8]
         L.forward_network_gpu.argtypes = [vp]
         L.network_predict.restype = vp
@@ -313,6 +319,39 @@ class Net:
         C.memmove(self.H.dnq_net_input_float(self.h), x.ctypes.data, x.nbytes)
         self.H.quantization_weights_and_activations(self.h)
         return _as(self.H.dnq_net_input_host(self.h), self.batch * self.inputs, C.c_uint8).copy()
+
+    def prepare_from_float_gpu(self, x_float):
+        """The same with the quantiser on the device: the floats are uploaded as they are, min / max and the per-element
+        quantiser run in HBM (quantization_weights_and_activations_gpu).  Returns the uint8 input the device produced."""
+        x = np.ascontiguousarray(x_float, np.float32).ravel()
+        assert x.size == self.batch * self.inputs
+        buf = DevBuf.from_numpy(x)
+        self.H.quantization_weights_and_activations_gpu(self.h, buf.ptr)
+        self.sync()
+        out = np.empty(x.size, np.uint8)
+        check(shim().mi355_d2h(out.ctypes.data, self.input_gpu_ptr(), out.nbytes, None), "d2h")
+        check(shim().mi355_stream_sync(None), "sync")
+        buf.free()
+        return out
+
+    def prepare_from_images_gpu(self, images):
+        """Device input path: every image (float32 [c][h][w], any size) is uploaded, letterboxed into its batch slot and
+        the batch quantised on the device.  Returns the uint8 network input the device produced."""
+        assert len(images) == self.batch
+        bufs = []
+        for slot, im in enumerate(images):
+            im = np.ascontiguousarray(im, np.float32)
+            b = DevBuf.from_numpy(im)
+            bufs.append(b)
+            self.H.network_letterbox_input_gpu(self.h, slot, b.ptr, im.shape[2], im.shape[1])
+        self.H.network_quantize_input_gpu(self.h)
+        self.sync()
+        out = np.empty(self.batch * self.inputs, np.uint8)
+        check(shim().mi355_d2h(out.ctypes.data, self.input_gpu_ptr(), out.nbytes, None), "d2h")
+        check(shim().mi355_stream_sync(None), "sync")
+        for b in bufs:
+            b.free()
+        return out
 
     def push_input(self, x_u8):
         x = np.ascontiguousarray(x_u8, np.uint8).ravel()

@@ -227,6 +227,127 @@ int fill_u32_launch(uint32_t *p, uint32_t v, long n, hipStream_t st)
     hipLaunchKernelGGL(fill_u32_kernel, dim3(nblk(n)), dim3(256), 0, st, p, v, n);
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
+// ---------------------------------------------------------------------------------------------------------------
+// Layer-0 input quantiser on the device (ref: quant_weights_with_min_max_channel with one channel, src/blas.c:108-168,
+// called on the float image at src/blas.c:279).  Pass 1: min / max of the image against the reference's 0.0f seeds;
+// the host turns them into (scale, zero point) with the reference's own expressions; pass 2: the per-element
+// round(x / scale) + zp, clamped, with the reference's float / double evaluation order.
+// mm[0] holds max(x, +0) as float bits (monotone as signed int for x >= 0), mm[1] the bits of min(x, -0) (monotone as
+// unsigned for x <= 0): both seeds are the reference's 0.0f, NaNs compare false and are skipped exactly as there.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void image_minmax_kernel(const float *x, long count, uint32_t *mm)
+{
+    float mx = 0.0f, mn = 0.0f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        mx = v > mx ? v : mx;
+        mn = v < mn ? v : mn;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float omx = __shfl_xor(mx, m), omn = __shfl_xor(mn, m);
+        mx = omx > mx ? omx : mx;
+        mn = omn < mn ? omn : mn;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mx > 0.0f) atomicMax(reinterpret_cast<int *>(mm), __float_as_int(mx));
+        if (mn < 0.0f) atomicMax(mm + 1, (uint32_t)__float_as_int(mn));
+    }
+}
+
+__global__ __launch_bounds__(256) void image_quantize_kernel(const float *x, long count, float scale, int zp, uint8_t *out)
+{
+    // four elements per thread: one 16-byte load, one 4-byte store
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= count) return;
+    float v[4];
+    if (i4 + 3 < count && (reinterpret_cast<size_t>(x) & 15) == 0) {
+        const float4 t = *reinterpret_cast<const float4 *>(x + i4);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i4 + k < count ? x[i4 + k] : 0.0f;
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float t = (float)(round((double)(v[k] / scale)) + (double)zp);  // ref :160-165
+        const int q = (int)t;
+        packed |= (uint32_t)(q < 0 ? 0 : (q > 255 ? 255 : q)) << (8 * k);
+    }
+    if (i4 + 3 < count && (reinterpret_cast<size_t>(out) & 3) == 0) {
+        *reinterpret_cast<uint32_t *>(out + i4) = packed;
+    } else {
+        for (int k = 0; k < 4 && i4 + k < count; ++k) out[i4 + k] = (uint8_t)(packed >> (8 * k));
+    }
+}
+
+// letterbox_image (ref: src/image.c:812-831) with its separable bilinear resize_image (:1199-1242) in one pass: an output
+// pixel inside the embedded rectangle interpolates its two source rows horizontally (the reference's intermediate
+// `part` image, same expressions, each product and sum rounded to float on its own: built with -ffp-contract=off) and
+// combines them vertically; outside it is the 0.5 fill.  Last column = the source's last column, last row = first term
+// only, as in the reference.
+__global__ __launch_bounds__(256) void letterbox_kernel(const float *im, int imw, int imh, int c, float *out, int w, int h,
+                                                        int new_w, int new_h, int ox, int oy, float w_scale, float h_scale)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)c * h * w) return;
+    const int x = (int)(idx % w), y = (int)((idx / w) % h), k = (int)(idx / ((long)w * h));
+    const int xx = x - ox, r = y - oy;
+    if (xx < 0 || xx >= new_w || r < 0 || r >= new_h) {
+        out[idx] = .5f;
+        return;
+    }
+    const float *plane = im + (size_t)k * imh * imw;
+    auto hval = [&](int row) {
+        const float *p = plane + (size_t)row * imw;
+        if (xx == new_w - 1 || imw == 1) return p[imw - 1];
+        const float sx = xx * w_scale;
+        const int ix = (int)sx;
+        const float dx = sx - ix;
+        return (1 - dx) * p[ix] + dx * p[ix + 1];
+    };
+    const float sy = r * h_scale;
+    const int iy = (int)sy;
+    const float dy = sy - iy;
+    float val = (1 - dy) * hval(iy);
+    if (!(r == new_h - 1 || imh == 1)) val += dy * hval(iy + 1);
+    out[idx] = val;
+}
+
+int letterbox_launch(const float *im, int imw, int imh, int c, float *out, int w, int h, hipStream_t st)
+{
+    int new_w, new_h;
+    if (((float)w / imw) < ((float)h / imh)) { new_w = w; new_h = (imh * w) / imw; }
+    else { new_h = h; new_w = (imw * h) / imh; }
+    if (new_w < 2 || new_h < 2) return MI355_EINVAL;  // the reference divides by (w - 1), (h - 1)
+    const float w_scale = (float)(imw - 1) / (new_w - 1), h_scale = (float)(imh - 1) / (new_h - 1);
+    // (int)(r * h_scale) must stay a row of the source image (the reference asserts it)
+    if ((int)((new_h - 1) * h_scale) > imh - 1 || (new_h > 1 && (int)((new_h - 2) * h_scale) + 1 > imh - 1) ||
+        (new_w > 1 && (int)((new_w - 2) * w_scale) + 1 > imw - 1))
+        return MI355_EINVAL;
+    const long total = (long)c * h * w;
+    hipLaunchKernelGGL(letterbox_kernel, dim3(nblk(total)), dim3(256), 0, st, im, imw, imh, c, out, w, h, new_w, new_h,
+                       (w - new_w) / 2, (h - new_h) / 2, w_scale, h_scale);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
+int image_minmax_launch(const float *x, long count, uint32_t *mm, hipStream_t st)
+{
+    if (hipMemsetAsync(mm, 0, 4, st) != hipSuccess) return MI355_EHIP;                 // +0.0f
+    if (fill_u32_launch(mm + 1, 0x80000000u, 1, st) != MI355_OK) return MI355_EHIP;   // -0.0f
+    const long want = (count + 255) / 256;
+    const int grid = (int)(want < 2048 ? (want > 0 ? want : 1) : 2048);
+    hipLaunchKernelGGL(image_minmax_kernel, dim3(grid), dim3(256), 0, st, x, count, mm);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
+int image_quantize_launch(const float *x, long count, float scale, int zp, uint8_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(image_quantize_kernel, dim3(nblk((count + 3) / 4)), dim3(256), 0, st, x, count, scale, zp, out);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
 int yolo_logistic_launch(const float *in, float *out, int B, int n, int classes, int hw, hipStream_t st)
 {
     const long total = (long)B * n * (classes + 5) * hw;

@@ -104,4 +104,7 @@ int copy_cells_launch(const CopyArgs &a, hipStream_t st);
 int nchw_to_phwc_launch(const LayoutArgs &a, hipStream_t st);
 int phwc_to_nchw_launch(const LayoutArgs &a, hipStream_t st);
 int fill_u32_launch(uint32_t *p, uint32_t v, long n, hipStream_t st);
+int letterbox_launch(const float *im, int imw, int imh, int c, float *out, int w, int h, hipStream_t st);
+int image_minmax_launch(const float *x, long count, uint32_t *mm, hipStream_t st);
+int image_quantize_launch(const float *x, long count, float scale, int zp, uint8_t *out, hipStream_t st);
 int yolo_logistic_launch(const float *in, float *out, int B, int n, int classes, int hw, hipStream_t st);

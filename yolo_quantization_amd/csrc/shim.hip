@@ -546,6 +546,26 @@ int mi355_route_forward(const mi355_tensor *const *xs, int n, const mi355_tensor
     return MI355_OK;
 }
 
+int mi355_letterbox_forward(const float *im_f32, int imw, int imh, int c, float *out_f32, int w, int h, void *stream)
+{
+    if (!im_f32 || !out_f32 || imw < 1 || imh < 1 || c < 1 || w < 2 || h < 2) return einval("letterbox: null / bad size");
+    const int rc = letterbox_launch(im_f32, imw, imh, c, out_f32, w, h, (hipStream_t)stream);
+    return rc == MI355_EINVAL ? einval("letterbox: degenerate aspect (resized side < 2)") : rc;
+}
+
+int mi355_image_minmax(const float *x_f32, long count, float *minmax, void *stream)
+{
+    if (!x_f32 || !minmax || count <= 0) return einval("image_minmax: null / empty");
+    return image_minmax_launch(x_f32, count, reinterpret_cast<uint32_t *>(minmax), (hipStream_t)stream);
+}
+
+int mi355_image_quantize(const float *x_f32, long count, float scale, int zero_point, uint8_t *out_u8, void *stream)
+{
+    if (!x_f32 || !out_u8 || count <= 0) return einval("image_quantize: null / empty");
+    if (!(scale > 0.0f) || zero_point < 0 || zero_point > 255) return einval("image_quantize: need scale > 0 and 0 <= zero_point <= 255");
+    return image_quantize_launch(x_f32, count, scale, zero_point, out_u8, (hipStream_t)stream);
+}
+
 int mi355_yolo_forward(const float *in, float *out, int B, int n, int classes, int H, int W, void *stream)
 {
     if (!in || !out) return einval("yolo: null");

@@ -78,13 +78,9 @@ void quant_multi_smaller_than_one_to_scale_and_shift(float real_multiplier, int3
     *right_shift = s;
 }
 
-void quant_image_with_min_max(int count, const float *input, uint8_t *out, float *scale, uint8_t *zero_point)
+/* scale / zero point of the layer-0 quantiser from the image's min / max (both seeded with 0.0f), ref: src/blas.c:125-150 */
+static void image_scale_zero_point(float min_value, float max_value, float *scale, uint8_t *zero_point)
 {
-    float min_value = 0.0f, max_value = 0.0f;
-    for (int j = 0; j < count; ++j) {
-        max_value = input[j] > max_value ? input[j] : max_value;
-        min_value = input[j] < min_value ? input[j] : min_value;
-    }
     if (min_value == 0 && max_value == 0) error("input image is all zero (ref: src/blas.c:125-128 assert)");
     /* the reference binary (gcc -Ofast) multiplies by the reciprocal constant here; see oracle/oracle.c */
     float nudged_scale = (max_value - min_value) * (1.0f / 255.0f);
@@ -96,6 +92,18 @@ void quant_image_with_min_max(int count, const float *input, uint8_t *out, float
     else zp = (uint8_t)round(initial_zero_point);
     *scale = nudged_scale;
     *zero_point = zp;
+}
+
+void quant_image_with_min_max(int count, const float *input, uint8_t *out, float *scale, uint8_t *zero_point)
+{
+    float min_value = 0.0f, max_value = 0.0f;
+    for (int j = 0; j < count; ++j) {
+        max_value = input[j] > max_value ? input[j] : max_value;
+        min_value = input[j] < min_value ? input[j] : min_value;
+    }
+    image_scale_zero_point(min_value, max_value, scale, zero_point);
+    const float nudged_scale = *scale;
+    const uint8_t zp = *zero_point;
     for (int k = 0; k < count; ++k) {
         float t = (float)(round((double)(input[k] / nudged_scale)) + (double)zp);
         int v = (int)t;
@@ -331,6 +339,59 @@ void quantization_weights_and_activations(network *net)
         }
     }
     push_network_input_uint8(net, net->input_uint8);
+}
+
+/* The same on the device (quantiser half): `input_gpu` holds batch x inputs floats in HBM.  Image 0
+ * defines scale / zero point as in the reference (src/blas.c:279); min / max are reduced on the device, the two floats
+ * come back to the host, which evaluates the reference's scale / zero-point expressions and -- only when they differ
+ * from the ones layer 0 was prepared with -- re-derives and re-uploads layer 0's multipliers and blob in place (no other
+ * layer depends on the input scale); the per-element quantiser then runs on the device straight into the network's uint8
+ * input.  Byte-identical to quantization_weights_and_activations() on the same floats. */
+void quantization_weights_and_activations_gpu(network *net, const float *input_gpu)
+{
+    if (!input_gpu) error("quantization_weights_and_activations_gpu: null input");
+    check_mi355(mi355_init(net->gpu_index), "mi355_init");
+    if (!net->stream) check_mi355(mi355_stream_create(&net->stream), "stream");
+    if (!net->quant_mm_gpu) check_mi355(mi355_alloc((void **)&net->quant_mm_gpu, 2 * sizeof(float)), "alloc minmax");
+    float mm[2];
+    check_mi355(mi355_image_minmax(input_gpu, net->inputs, net->quant_mm_gpu, net->stream), "mi355_image_minmax");
+    check_mi355(mi355_d2h(mm, net->quant_mm_gpu, sizeof(mm), net->stream), "minmax d2h");
+    check_mi355(mi355_stream_sync(net->stream), "sync");
+    float s; uint8_t zp;
+    image_scale_zero_point(mm[1] + 0.0f, mm[0], &s, &zp);
+    layer *l0 = &net->layers[0];
+    if (!net->prepared) {
+        quantization_weights_and_activations_fixed_input(net, s, zp);
+    } else if (l0->input_data_uint8_scales[0] != s || l0->input_data_uint8_zero_point[0] != zp) {
+        const int zp_changed = l0->input_data_uint8_zero_point[0] != zp;
+        l0->input_data_uint8_scales[0] = s;
+        l0->input_data_uint8_zero_point[0] = zp;
+        prep_conv_layer(net, 0);
+        check_mi355(mi355_conv_pack(l0->n, l0->c, l0->size, l0->weights_uint8, l0->weight_data_uint8_zero_point,
+                                    l0->biases_int32, l0->M_value, l0->M0_right_shift_value, l0->blob_host), "mi355_conv_pack");
+        check_mi355(mi355_h2d(l0->blob_gpu, l0->blob_host, l0->blob_bytes, net->stream), "upload blob 0");
+        if (zp_changed) check_mi355(mi355_tensor_fill(&net->input_t, zp, net->stream), "fill input");  /* pad cells = zero point */
+        check_mi355(mi355_stream_sync(net->stream), "sync");  /* blob_host may be repacked by the next call */
+    }
+    check_mi355(mi355_image_quantize(input_gpu, (long)net->batch * net->inputs, s, zp, net->input_uint8_gpu, net->stream),
+                "mi355_image_quantize");
+}
+
+void network_letterbox_input_gpu(network *net, int slot, const float *im_gpu, int imw, int imh)
+{
+    if (slot < 0 || slot >= net->batch || !im_gpu) error("network_letterbox_input_gpu: bad slot / null image");
+    check_mi355(mi355_init(net->gpu_index), "mi355_init");
+    if (!net->stream) check_mi355(mi355_stream_create(&net->stream), "stream");
+    if (!net->input_gpu)
+        check_mi355(mi355_alloc((void **)&net->input_gpu, (size_t)net->batch * net->inputs * sizeof(float)), "alloc float input");
+    check_mi355(mi355_letterbox_forward(im_gpu, imw, imh, net->c, net->input_gpu + (size_t)slot * net->inputs, net->w, net->h,
+                                        net->stream), "mi355_letterbox_forward");
+}
+
+void network_quantize_input_gpu(network *net)
+{
+    if (!net->input_gpu) error("network_quantize_input_gpu before network_letterbox_input_gpu");
+    quantization_weights_and_activations_gpu(net, net->input_gpu);
 }
 
 void set_batch_network(network *net, int b)
