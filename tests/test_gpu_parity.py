@@ -182,6 +182,47 @@ def test_conv_ws3_weights_stationary_kernel(B, c, n, H, W, act, store):
     assert np.array_equal(got["u8"], rows["u8"])
 
 
+def _fuzz_cases():
+    rng = np.random.default_rng(20260928)
+    cases = []
+    for i in range(36):
+        k = int(rng.choice([1, 3, 3]))
+        c = int(rng.choice([16, 32, 48, 64, 128, 192, 256, 384]))
+        n = int(rng.integers(1, 9)) * int(rng.choice([1, 4, 16, 32]))
+        H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        B = int(rng.integers(1, 5))
+        stride = 2 if (k == 3 and rng.random() < 0.25 and H > 2 and W > 2) else 1
+        while n * c * k * k * B * H * W > 6e8:  # keep the oracle fast
+            H, W = max(1, H // 2), max(1, W // 2)
+        cases.append((B, c, n, H, W, k, stride, str(rng.choice(["leaky", "relu6", "linear", "relu"])),
+                      int(rng.integers(0, 256)), int(rng.integers(0, 256)), int(rng.integers(0, 2)), i))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: "f%d_B%d_c%d_n%d_%dx%d_k%d_s%d_%s" % (c[-1], *c[:8]))
+def test_conv_random_shapes_vs_oracle(case):
+    """Seeded random shapes over the whole supported domain (1x1 / 3x3, stride 1 / 2, any map size down to 1x1, ragged
+    channel counts, every activation, arbitrary zero points, both store modes): accumulators, bytes and the float tail
+    against the oracle through the dump path, bytes again through the throughput path."""
+    B, c, n, H, W, k, stride, act, zp_in, zp_act, sat, seed = case
+    store = binding.STORE_SATURATE if sat else binding.STORE_WRAP
+    rng = np.random.default_rng(1000 + seed)
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, k)
+    zp_w[rng.integers(0, n)] = rng.choice([0, 255])  # extreme weight zero points: dz = 128 and -127
+    xt = binding.DevTensor.from_nchw(x, zp_in)
+    args = (xt, wq, zp_w, k, bias, mv, sv, zp_in, zp_act, 0.03, binding.ACT[act], store, binding.ACC_EXACT)
+    got = binding.conv_forward(*args, want_acc=True, want_f32=True, stride=stride)
+    acc, u8 = _oracle_layer(x, wq, zp_w, k, zp_in, bias, mv, sv, zp_act, oracle.ACT[act], store, oracle.ACC_EXACT, stride=stride)
+    OH, OW = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    assert np.array_equal(got["int32"], acc)
+    assert np.array_equal(got["u8"].reshape(B, n, OH * OW), u8)
+    assert np.array_equal(got["f32"], oracle.dequant(u8, zp_act, np.float32(0.03)))
+    fast = binding.conv_forward(*args, want_acc=False, want_f32=True, stride=stride)
+    assert np.array_equal(fast["u8"].reshape(B, n, OH * OW), u8)
+    assert np.array_equal(fast["f32"], got["f32"])
+
+
 @pytest.mark.parametrize("bm,bn,nt", [(128, 256, 0), (128, 128, 0), (64, 256, 0), (64, 128, 0), (32, 256, 0), (32, 128, 0),
                                       (128, 384, 0), (128, 384, 3), (128, 384, 7), (128, 256, 5), (64, 128, 13)])
 def test_conv_every_tile_config(bm, bn, nt):
