@@ -97,6 +97,17 @@ def cpu_baseline(cfg, wts, nimg, omp=False):
             "sample": f"{nimg} x yolov3-tiny 416x416 image, whole net, batch 1, {os.cpu_count()} host cores present"}
 
 
+def flush_c_stdio():
+    """RCCL prints its version banner through C stdio; when stdout is a pipe that text would otherwise appear at process
+    exit, after the JSON line."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -150,6 +161,7 @@ def main():
         dist.broadcast(blob, 0)
         torch.cuda.synchronize()
         bcast_ms = (time.time() - t0) * 1e3
+        flush_c_stdio()
         if rank != 0 or force_dist:
             if force_dist and rank == 0:  # single-rank self test: re-import what was exported
                 net.close()
@@ -256,14 +268,17 @@ def main():
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             json.dump({"ms_per_step": ms_per_step, "layers": layers},
                       open(os.path.join(ROOT, "gpurun_out", f"bench_layers_n{world}.json"), "w"), indent=1)
-        print(json.dumps(out), flush=True)
     try:
         os.remove(wts)
     except OSError:
         pass
     net.close()
     if world > 1 or force_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:  # the ONE JSON line, last on stdout (RCCL's start-up banner sits in C stdio's buffer until flushed)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
