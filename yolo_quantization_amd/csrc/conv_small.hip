@@ -226,12 +226,27 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
         issue_tile(gr_first, col0, nrows, 0);
     }
     int parity = 0;
+    // The packed bytes of a tile are stored one tile late, right after the next tile's barrier: vmcnt counts loads and
+    // stores alike on gfx9-class hardware, so stores issued just before the `s_waitcnt vmcnt(0)` that guards the image
+    // DMA would make every tile wait for a full store round trip; issued after it they have a whole tile to drain.
+    uint32_t pk[NM][4];
+    uint8_t *pk_outp = a.ypool;
+    bool pk_valid = false;
+    auto flush_stores = [&]() {
+        if (pk_valid) {
+#pragma unroll
+            for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) *reinterpret_cast<uint32_t *>(pk_outp + 32 * mt + 8 * grp + 4 * kh) = pk[mt][grp];
+        }
+    };
     for (; tile < ntiles; tile += gridDim.x, parity ^= 1, cur = nxp) {
         tile_geom(tile, cur, gr_first, col0, nrows);
         const char *X = smem + parity * bbytes;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the tile's image has landed (and the parameters, first time round); every wave is past the
                           // previous tile, so its buffer may be overwritten
+        flush_stores();
         advance(nxp);
         if (tile + gridDim.x < ntiles) {
             int g2, c2, n2;
@@ -337,11 +352,13 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) accb[r][j] = DZM ? acc[j][grp * 4 + r] : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
                 }
-                const uint32_t packed = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
-                if (valid) *reinterpret_cast<uint32_t *>(outp + ch0) = packed;
+                pk[mt][grp] = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
             }
         }
+        pk_outp = outp;
+        pk_valid = valid;
     }
+    flush_stores();
 }
 
 // ---------------------------------------------------------------------------------------------------------------

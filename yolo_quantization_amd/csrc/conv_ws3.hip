@@ -177,9 +177,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     }
     __syncthreads();
     TS3(3);
-#ifdef MI355_ABLATE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    // All A fragments have to be in before the group loops: with the waits inside the (shared) loop body every group
+    // would end on an s_waitcnt vmcnt(0), and vmcnt also counts the previous group's stores -- a store round trip per
+    // group.  As a builtin, so that the compiler's wait-count pass knows nothing is pending any more.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     TS3(4);
 
     // K-step s of this wave: tap s / 4, channels 128 kp + 32 (s % 4) + 16 kh .. + 15 = bytes [128 kp + 32 (s % 4) + 16 kh, +16)
