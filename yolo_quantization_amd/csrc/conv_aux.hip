@@ -329,14 +329,10 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         if (p.tx >= tiles_x) { p.tx -= tiles_x; ++p.ty; }
         if (p.ty >= tiles_y) { p.ty -= tiles_y; ++p.b; }
     };
-    auto fetch = [&](const Pos &p, uint32_t(&v)[3]) {
-        const long org = (long)a.in_lead + (long)(p.b * (a.H + 1) + 16 * p.ty) * W1 + 32 * p.tx - 1;  // image cell (0, 0)
+    auto fetch = [&](const Pos &p, uint32_t(&v)[3]) {  // cell indices fit an int (the launcher checks in_cells)
+        const int org = a.in_lead + (p.b * (a.H + 1) + 16 * p.ty) * W1 + 32 * p.tx - 1;  // image cell (0, 0)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            long f = org + soff[k];
-            f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
-            v[k] = xc[f];
-        }
+        for (int k = 0; k < 3; ++k) v[k] = xc[min(max(org + soff[k], 0), a.in_cells - 1)];
     };
     auto stash = [&](int buf, const uint32_t(&v)[3]) {
 #pragma unroll
@@ -351,6 +347,10 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         fetch(cur, nxt);
         stash(0, nxt);
     }
+    // Every register loaded so far (weights, per-channel constants) is in: without this the compiler has to keep an
+    // s_waitcnt vmcnt(0) in front of the first MFMA of the (shared) loop body, which then also waits for the image
+    // prefetch issued a few instructions earlier and for the previous tile's stores -- a memory round trip per tile.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     int buf = 0;
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1, cur = nxp) {
         __syncthreads();  // this tile's image is complete; every wave is past the previous tile
@@ -380,10 +380,23 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                 for (int j = 0; j < 4; ++j) {
                     const int jy = j >> 1, jx = j & 1;
                     const v4i bf = {(int)rw[jy][jx], (int)rw[jy][jx + 1], (int)rw[jy][jx + 2], (int)rw[jy][jx + 3]};
-                    v4i t = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[mt], bf, cb[mt], 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd1[mt], bf, t, 0, 0, 0);
-                    if (need_d2) t = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt], bf, t, 0, 0, 0);
-                    acc[j] = t;
+                    acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[mt], bf, cb[mt], 0, 0, 0);
+                }
+                // the correction passes as their own rounds over the four (independent) window positions; the dz = 128
+                // pass is chosen once, not behind a branch after every MFMA
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jy = j >> 1, jx = j & 1;
+                    const v4i bf = {(int)rw[jy][jx], (int)rw[jy][jx + 1], (int)rw[jy][jx + 2], (int)rw[jy][jx + 3]};
+                    acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd1[mt], bf, acc[j], 0, 0, 0);
+                }
+                if (need_d2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int jy = j >> 1, jx = j & 1;
+                        const v4i bf = {(int)rw[jy][jx], (int)rw[jy][jx + 1], (int)rw[jy][jx + 2], (int)rw[jy][jx + 3]};
+                        acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt], bf, acc[j], 0, 0, 0);
+                    }
                 }
                 int32_t accb[4][4], amax[4][1];
                 bool bad = false;
@@ -441,6 +454,7 @@ int conv_first_mfma_pool_launch(AuxArgs &a, hipStream_t st)
 {
     if ((a.n != 16 && a.n != 32) || a.y || a.acc_out || a.y_f32 || (a.H & 1) || (a.W & 1) || !a.cwb || a.in_cs != 4)
         return MI355_EINVAL;
+    if ((long)a.in_cells + 64L * (a.W + 1) >= (1L << 31)) return MI355_EINVAL;  // 32-bit cell arithmetic in the kernel
     const int OH = a.H / 2, OW = a.W / 2;
     const long ntiles = (long)a.B * ((OW + 15) / 16) * ((OH + 7) / 8);
     const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // persistent: four workgroups per CU (five measured slower)
