@@ -157,8 +157,20 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         const int q = nb >> 3, r = nb & 7, xcd = id & 7, idx = id >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int mtile = logical / a.ntiles_n;
-    const int ntile = logical - mtile * a.ntiles_n;
+    // `logical` gives every XCD (workgroup id % 8) one contiguous range of tiles.  M-major ranges make an XCD read few
+    // weight slabs but the whole input; when the launcher found a better split (xcd_gm) the XCD owns a block of
+    // (mtiles / gm) x (ntiles / gn) tiles instead, so that the weights + input slices its L2 has to hold are smallest.
+    int mtile, ntile;
+    if (a.xcd_gm > 0) {
+        const int per = (int)gridDim.x >> 3, x = logical / per, within = logical - x * per;
+        const int gm = a.xcd_gm, mt_per = a.mtiles / gm, nt_per = a.ntiles_n / (8 / gm);
+        const int xm = x % gm, xn = x / gm;
+        mtile = xm * mt_per + within / nt_per;
+        ntile = xn * nt_per + within % nt_per;
+    } else {
+        mtile = logical / a.ntiles_n;
+        ntile = logical - mtile * a.ntiles_n;
+    }
     // N tiles split the flattened pixel range evenly (tile widths differ by at most one pixel and never exceed BN):
     // the host picks ntiles_n so that mtiles * ntiles_n fills whole rounds of workgroups over the 256 CUs.
     const int n0 = (int)(((long)ntile * a.total_n) / a.ntiles_n);
@@ -779,6 +791,19 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return MI355_EHIP;
+    }
+    // XCD grid: minimise the bytes one XCD's L2 has to pull in = its M tiles' weight slabs + its N tiles' input rows
+    a.xcd_gm = 0;
+    if (!(a.debug & (1 << 24))) {
+        const long nb = (long)a.ntiles_n * a.mtiles;
+        const double wslab = (double)BM * a.ksteps * 64, itile = (double)a.total_n / a.ntiles_n * a.cb * a.nchunks;
+        double best = 0;
+        for (int gm = 1; gm <= 8; gm <<= 1) {
+            const int gn = 8 / gm;
+            if (nb % 8 || a.mtiles % gm || a.ntiles_n % gn) continue;
+            const double bytes = (a.mtiles / gm) * wslab + (a.ntiles_n / gn) * itile;
+            if (a.xcd_gm == 0 || bytes < best) { best = bytes; a.xcd_gm = gm; }
+        }
     }
     dim3 grid(a.ntiles_n * a.mtiles), block(NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);

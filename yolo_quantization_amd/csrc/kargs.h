@@ -17,6 +17,7 @@ struct ConvArgs {
     int stride, OH, OW;      // output map = (H + 2*pad - ksize) / stride + 1 (== H, W for the stride-1 kernels)
     int ksize, cb, nchunks, upc, spc, ksteps;
     int total_n, ntiles_n, mtiles;
+    int xcd_gm;              // conv_rows: the 8 XCDs form an xcd_gm x (8 / xcd_gm) grid over (M tiles, N tiles); 0 = M-major ranges
     int zp_act, act, store_mode;
     float s_act;
     int mpad;
