@@ -212,6 +212,14 @@ def main():
         empty = [float(ms[i + 1]) / nprof for i, inf in enumerate(net.info)
                  if (i > 0 and fused[i - 1]) or inf["type"] in (binding.T_ROUTE, binding.T_YOLO)]
         ev_cost = min(empty) if empty else 0.0
+        # ... but an event recorded behind a running kernel is partly processed in that kernel's shadow: subtracting the
+        # empty-interval cost from every interval under-reports the layers (their sum would fall short of a step).  The
+        # steps without events give the truth for the sum: T_unprofiled = (dt - nprof * T_profiled) / (steps - nprof),
+        # and the per-interval cost that makes the profiled steps' intervals add up to it is what gets subtracted.
+        if args.steps > nprof > 0:
+            t_prof = float(sum(ms)) / nprof                       # ms of one profiled step, events included
+            t_unprof = (dt * 1e3 - nprof * t_prof) / (args.steps - nprof)
+            ev_cost = min(ev_cost, max((t_prof - t_unprof) / len(ms), 0.0))
         def on_rows_kernel(i, inf):
             """conv_rows_i8_kernel launches: 64-byte channel chunks, served by the implicit-GEMM family (the host records
             which kernel family took each conv of the last step: conv_small / conv1x1 / conv_ws3 take the others)."""
