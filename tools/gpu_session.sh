@@ -11,7 +11,7 @@ if [[ $what == all || $what == tests ]]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
 fi
 if [[ $what == all || $what == bench ]]; then
-  timeout 900 python bench.py --steps 20 --warmup 3 --layers 2>gpurun_out/bench.err | tee gpurun_out/bench.json
+  timeout 900 python bench.py --steps 200 --warmup 20 --layers 2>gpurun_out/bench.err | tee gpurun_out/bench.json
   tail -40 gpurun_out/bench.err
   cp gpurun_out/bench_layers_n1.json gpurun_out/bench_layers_clean.json   # the rocprofv3 legs below rewrite the former
 fi
