@@ -259,8 +259,9 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     __shared__ uint32_t img[2][18 * 34];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile rows and output rows stay on the scalar unit
     const int pc = lane & 15, g = lane >> 4;
+    const unsigned pc_off = (unsigned)pc * (unsigned)a.pool_cs;  // byte offset of the lane's pooled column inside an output row
     const int W1 = a.W + 1;
     const int OH = a.H >> 1, OW = a.W >> 1;
     const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + 7) >> 3, tpi = tiles_x * tiles_y;
@@ -371,8 +372,9 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                 rw[0][i] = p0[i];
                 rw[1][i] = p0[34 + i];
             }
-            const size_t pcell = (size_t)a.pool_lead + ((size_t)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol;
-            uint8_t *outp = a.ypool + pcell * a.pool_cs;
+            // wave-uniform part of the pooled cell (scalar arithmetic) + the lane's column (precomputed byte offset)
+            const long rowcell = (long)a.pool_lead + ((long)b * (OH + 1) + (prow + 1)) * (OW + 1) + 16 * tx;
+            uint8_t *outp = a.ypool + rowcell * a.pool_cs + pc_off;
 #pragma unroll
             for (int mt = 0; mt < NM; ++mt) {
                 v4i acc[4];
