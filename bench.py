@@ -169,7 +169,8 @@ def main():
             net.import_packed_gpu(blob.data_ptr(), nbytes)
 
     # ---- synthetic input, resident in HBM in the reference layout before the timed region
-    x = synth.synth_image_u8(3, 416, 416, seed=1000 + rank, batch=B)
+    in_c, in_h, in_w = net.info[0]["c"], net.info[0]["h"], net.info[0]["w"]  # 3 x 416 x 416 for the headline cfg
+    x = synth.synth_image_u8(in_c, in_h, in_w, seed=1000 + rank, batch=B)
     net.push_input(x)
     net.sync()
 
@@ -265,7 +266,9 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x s8 -> int32 (f64 requant)",
                "data": "synthetic",
                "config": {"workload": "yolov3-tiny full net (cfg/yolov3-tiny_quant.cfg, leaky, per-channel quant), "
-                                      f"batch {B}/GPU synthetic uint8 416x416, inputs resident in HBM (NCHW uint8)",
+                                      f"batch {B}/GPU synthetic uint8 {in_h}x{in_w}, inputs resident in HBM (NCHW uint8)"
+                                      if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg" else
+                                      f"{os.path.basename(args.cfg)}, batch {B}/GPU synthetic uint8 {in_h}x{in_w}, inputs resident in HBM (NCHW uint8)",
                           "global_batch": world * B, "parallelism": f"image-sharded x{world}, RCCL weight broadcast once",
                           "launch": "hipGraph replay" if args.graph else f"eager; per-layer HIP events on every {prof_stride}th step of the timed region",
                           "weight_broadcast_ms": round(bcast_ms, 3)},

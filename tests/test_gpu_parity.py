@@ -126,6 +126,7 @@ def test_conv_stride2(B, c, n, H, W, k, store):
 
 @pytest.mark.parametrize("B,c,n,H,W,act", [(1, 128, 30, 13, 13, "linear"), (3, 256, 96, 26, 26, "leaky"), (2, 512, 255, 13, 13, "linear"),
                                            (1, 1024, 256, 13, 13, "leaky"), (64, 256, 128, 13, 13, "leaky"), (2, 128, 33, 5, 7, "relu6"),
+                                           (2, 64, 32, 76, 76, "leaky"), (1, 64, 200, 9, 31, "linear"),
                                            (1, 1024, 1, 9, 9, "relu")])
 @pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
 def test_conv1x1_weights_stationary_kernel(B, c, n, H, W, act, store):

@@ -188,7 +188,7 @@ static int c1_launch_act(ConvArgs &a, hipStream_t st, int grid, int threads, siz
 // shapes whose blob carries the weights-stationary plane (off_ws) for this kernel
 bool conv1x1_ws_eligible(int n, int c, int ksize)
 {
-    return ksize == 1 && (c == 128 || c == 256 || c == 512 || c == 1024) && n >= 1 && n <= 256;
+    return ksize == 1 && (c == 64 || c == 128 || c == 256 || c == 512 || c == 1024) && n >= 1 && n <= 256;
 }
 
 // returns MI355_EINVAL when the shape is outside this kernel's domain (the caller falls back to conv_rows / conv_igemm)
@@ -215,6 +215,7 @@ int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
     const int sets = 8 / nq > 0 ? 8 / nq : 1;  // at most 8 waves per workgroup
     const int threads = sets * nq * 64;
     switch (c) {
+    case 64: return c1_launch_act<2>(a, st, ntiles, threads, lds);
     case 128: return c1_launch_act<4>(a, st, ntiles, threads, lds);
     case 256: return c1_launch_act<8>(a, st, ntiles, threads, lds);
     case 512: return c1_launch_act<16>(a, st, ntiles, threads, lds);
