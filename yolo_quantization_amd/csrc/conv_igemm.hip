@@ -646,14 +646,27 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
                 const int rounds = (int)((blocks0 + slots - 1) / slots);
                 int nt = (int)(((long)rounds * slots) / mt);  // fill the last round with more, narrower tiles
                 if (nt < nt0) nt = nt0;
-                const int px = (a.total_n + nt - 1) / nt;
                 const int waves_n = (cbn == 128 && bm == 128) ? 2 : 4;
-                const int sub = ((px + 31) / 32 + waves_n - 1) / waves_n;   // sub-tiles of the busiest wave
+                int px = (a.total_n + nt - 1) / nt;
+                int sub = ((px + 31) / 32 + waves_n - 1) / waves_n;   // sub-tiles of the busiest wave
+                {   // ... unless the narrower tiles keep the busiest wave as busy: then more of them is only more work
+                    const int px0 = (a.total_n + nt0 - 1) / nt0;
+                    const int sub0 = ((px0 + 31) / 32 + waves_n - 1) / waves_n;
+                    if (sub0 == sub && slots == 512) { nt = nt0; px = px0; }
+                }
                 const int ms = (bm >= 64) ? 2 : 1;
                 const double step = 0.2 + 0.04 * (2.0 * ms * sub);
                 // narrow tiles re-load the weights and the halo rows more often (3x3); for 1x1 they are the cheapest
                 const double shape = (cbn == 128) ? (a.ksize == 3 ? 1.15 : 0.85) : 1.0;
-                const double cost = rounds * (10.0 + a.ksteps * step) * shape + 0.005 * cbn;
+                // maps that fill their LDS row image badly (19 + 2 cells in a 32-slot row, 38 + 2 in 64) make the wide
+                // tiles pay for the empty slots in every B-slab DMA and LDS byte: measured 173 / 114 us with 256-column
+                // tiles against 116 / 88 us with two 128-column workgroups per CU (256->512 @38, 512->1024 @19, batch 32)
+                const int rs = a.W + 2 <= 16 ? 16 : (a.W + 2 <= 32 ? 32 : 64);
+                const double rowpen = (cbn != 128 && a.ksize == 3 && (a.W + 2) < 0.7 * rs) ? 1.5 : 1.0;
+                // two 4-wave workgroups per CU are scheduled as they finish: count fractional rounds for them
+                const double nrounds = (slots == 512) ? (double)((long)mt * nt) / slots : (double)rounds;
+                const double cost = (nrounds < 1.0 ? 1.0 : nrounds) * (10.0 + a.ksteps * step) * shape * rowpen + 0.005 * cbn;
+                if (g_debug & (1 << 25)) fprintf(stderr, "[plan] bn %d nt0 %d nt %d px %d sub %d rounds %.2f cost %.1f\n", cbn, nt0, nt, px, sub, nrounds, cost);
                 if (cost < best) { best = cost; best_bn = cbn; best_nt = nt; }
             }
         }
@@ -676,6 +689,11 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
         else tiles = (a.total_n + 255) / 256;
         tiles *= (a.n + bm - 1) / bm;
         if (tiles < 200) bn = 128;  // measured: 256-wide tiles win down to ~0.8 workgroups per CU (r01 sweep)
+        // ... on few-channel stride-1 layers.  With 64-channel chunks (the layers the row-image kernel refuses: maps wider
+        // than 62 pixels, row images it cannot tile) and for stride 2, two 128-column workgroups per CU win: the YOLOv3
+        // shapes at 608 x 608, batch 32, run 470 -> 278 us (3x3 s2 32->64), 163 -> 103 us (256->512 @38), 106 -> 80 us
+        // (512->1024 @19) -- profiles/r01_v6_chain608_layers.log
+        if (a.cb == 64 || a.stride != 1) bn = 128;
     }
     if (a.ksize == 1) patch = false;
     if (a.stride != 1) patch = true;  // strided convs exist as 2-D patches only (input patch = stride x the output patch)
