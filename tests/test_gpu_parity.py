@@ -260,6 +260,30 @@ def test_conv_first_layer_kernel(n):
     assert np.array_equal(got["u8"].reshape(B, n, H * W), u8)
 
 
+@pytest.mark.parametrize("n,act", [(16, "leaky"), (32, "leaky"), (32, "relu6"), (16, "linear")])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+def test_conv_first_layer_mfma_without_pool(n, act, store):
+    """The first layer of the non-tiny nets (3 -> 32 at full resolution, no maxpool behind it) on the matrix pipe
+    (conv_first_mfma_kernel): even maps, ragged patches, weight zero points 0 / 255 (dz = 128 / -127), against the
+    oracle and against the VALU kernel (debug flag 1024)."""
+    rng = np.random.default_rng(n + len(act))
+    B, H, W = 3, 38, 70
+    x = rng.integers(0, 256, (B, 3, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, 3, 3, 2.0 ** -9, 2.0 ** -6)
+    zp_w[1], zp_w[n - 2] = 0, 255
+    xt = binding.DevTensor.from_nchw(x, 9)
+    args = (xt, wq, zp_w, 3, bias, mv, sv, 9, 23, 1.0, binding.ACT[act], store, binding.ACC_EXACT)
+    got = binding.conv_forward(*args, want_acc=False)
+    _, u8 = _oracle_layer(x, wq, zp_w, 3, 9, bias, mv, sv, 23, oracle.ACT[act], store, oracle.ACC_EXACT)
+    assert np.array_equal(got["u8"].reshape(B, n, H * W), u8)
+    binding.shim().mi355_debug_flags(1024)
+    try:
+        valu = binding.conv_forward(*args, want_acc=False)
+    finally:
+        binding.shim().mi355_debug_flags(0)
+    assert np.array_equal(got["u8"], valu["u8"])
+
+
 def test_conv_ref_f32_mode_reproduces_fp32_rounding():
     """accum_mode REF_F32 == the oracle's bit-faithful restatement of src/gemm.c:279-299, on data whose running
     sums exceed 2^24 (so it differs from exact integers)."""

@@ -441,6 +441,178 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     }
 }
 
+// The same kernel without the pool: the first layer of the non-tiny networks (YOLOv3's 3 -> 32 at full resolution) stores
+// every conv pixel.  Same tiling (a lane's four MFMAs are the 2x2 block of conv pixels at (2 prow + jy, 2 pcol + jx)), all
+// sixteen values of a lane requantised, four 4-byte stores per m-tile.
+template <int ACT, bool SAT, int NM>
+__global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a)
+{
+    __shared__ uint32_t img[2][18 * 34];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile rows and output rows stay on the scalar unit
+    const int pc = lane & 15, g = lane >> 4;
+    const unsigned pc_off = 2u * (unsigned)pc * (unsigned)a.out_cs;  // byte offset of the lane's left conv column inside an output row
+    const int W1 = a.W + 1;
+    const int OH = a.H >> 1, OW = a.W >> 1;
+    const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + 7) >> 3, tpi = tiles_x * tiles_y;
+    const int ntiles = a.B * tpi;
+    const bool pow2 = a.hdr->pow2 == 1;
+
+    // ---- per-lane constants: A fragments (row = channel 16*mt + pc, k-group g), channel parameters of the lane's four
+    //      accumulator rows 16*mt + 4*g + r
+    v4i wa[NM], wd1[NM], wd2[NM], cb[NM];
+    int chq[NM];
+    double mp[NM][4];
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt) {
+        const int ch = 16 * mt + pc;
+        const int dz = a.dzp[ch];
+        const int d1 = dz > 127 ? 127 : dz, d2 = dz - d1;  // dz in [-127, 128]
+        const uint32_t m1 = (uint32_t)(d1 & 0xFF) * 0x00010101u, m2 = (uint32_t)(d2 & 0xFF) * 0x00010101u;
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const bool real = g < 3 && dx < 3;
+            wa[mt][dx] = real ? (int)(a.wfirst[ch * 9 + 3 * g + dx] ^ 0x00808080u) : 0;  // w' = w - 128 on the three channels
+            wd1[mt][dx] = real ? (int)m1 : 0;
+            wd2[mt][dx] = real ? (int)m2 : 0;
+        }
+        chq[mt] = 16 * mt + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c2 = chq[mt] + r;
+            const double m = a.mprime[c2];
+            mp[mt][r] = m;
+            cb[mt][r] = a.cwb[c2];
+        }
+    }
+    bool need_d2 = false;
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt) need_d2 |= __builtin_amdgcn_ballot_w64(wd2[mt][0] != 0) != 0;
+
+    // ---- staging: thread t owns image dwords t, t + 256, t + 512 (< 612): their cell offsets from the tile origin
+    int soff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int slot = min(tid + 256 * k, 18 * 34 - 1);
+        const int r = slot / 34, c = slot - r * 34;
+        soff[k] = r * W1 + c;
+    }
+    const uint32_t *xc = reinterpret_cast<const uint32_t *>(a.x);
+    // tile walk without per-tile divisions: (b, ty, tx) advances by the decomposition of gridDim.x with carries
+    struct Pos { int b, ty, tx; };
+    auto pos_of = [&](int t) {
+        Pos p;
+        p.b = t / tpi;
+        const int r = t - p.b * tpi;
+        p.ty = r / tiles_x;
+        p.tx = r - p.ty * tiles_x;
+        return p;
+    };
+    const Pos step = pos_of(gridDim.x);
+    auto advance = [&](Pos &p) {
+        p.tx += step.tx;
+        p.ty += step.ty;
+        p.b += step.b;
+        if (p.tx >= tiles_x) { p.tx -= tiles_x; ++p.ty; }
+        if (p.ty >= tiles_y) { p.ty -= tiles_y; ++p.b; }
+    };
+    auto fetch = [&](const Pos &p, uint32_t(&v)[3]) {  // cell indices fit an int (the launcher checks in_cells)
+        const int org = a.in_lead + (p.b * (a.H + 1) + 16 * p.ty) * W1 + 32 * p.tx - 1;  // image cell (0, 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = xc[min(max(org + soff[k], 0), a.in_cells - 1)];
+    };
+    auto stash = [&](int buf, const uint32_t(&v)[3]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (tid + 256 * k < 18 * 34) img[buf][tid + 256 * k] = v[k] ^ 0x80808080u;  // x' = x - 128 (pad byte: weight 0)
+    };
+
+    int tile = blockIdx.x;
+    Pos cur = pos_of(tile), nxp = cur;
+    uint32_t nxt[3];
+    if (tile < ntiles) {
+        fetch(cur, nxt);
+        stash(0, nxt);
+    }
+    // Every register loaded so far (weights, per-channel constants) is in: without this the compiler has to keep an
+    // s_waitcnt vmcnt(0) in front of the first MFMA of the (shared) loop body, which then also waits for the image
+    // prefetch issued a few instructions earlier and for the previous tile's stores -- a memory round trip per tile.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1, cur = nxp) {
+        __syncthreads();  // this tile's image is complete; every wave is past the previous tile
+        const bool more = tile + gridDim.x < ntiles;
+        advance(nxp);
+        if (more) fetch(nxp, nxt);
+        const int b = cur.b, ty = cur.ty, tx = cur.tx;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int pr = 2 * wave + s;  // pooled row inside the patch
+            const int prow = 8 * ty + pr, pcol = 16 * tx + pc;
+            const bool valid = prow < OH && pcol < OW;
+            // two image rows x five cells feed the four window positions of this lane's k-group
+            const uint32_t *p0 = img[buf] + (2 * pr + (g < 3 ? g : 2)) * 34 + 2 * pc;
+            uint32_t rw[2][5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                rw[0][i] = p0[i];
+                rw[1][i] = p0[34 + i];
+            }
+            // wave-uniform part of the output cells (scalar arithmetic) + the lane's column (precomputed byte offset)
+            const long rowcell = (long)a.out_lead + ((long)b * (a.H + 1) + (2 * prow + 1)) * W1 + 32 * tx;
+            uint8_t *outp = a.y + rowcell * a.out_cs + pc_off;
+#pragma unroll
+            for (int mt = 0; mt < NM; ++mt) {
+                v4i acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jy = j >> 1, jx = j & 1;
+                    const v4i bf = {(int)rw[jy][jx], (int)rw[jy][jx + 1], (int)rw[jy][jx + 2], (int)rw[jy][jx + 3]};
+                    acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[mt], bf, cb[mt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jy = j >> 1, jx = j & 1;
+                    const v4i bf = {(int)rw[jy][jx], (int)rw[jy][jx + 1], (int)rw[jy][jx + 2], (int)rw[jy][jx + 3]};
+                    acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd1[mt], bf, acc[j], 0, 0, 0);
+                }
+                if (need_d2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int jy = j >> 1, jx = j & 1;
+                        const v4i bf = {(int)rw[jy][jx], (int)rw[jy][jx + 1], (int)rw[jy][jx + 2], (int)rw[jy][jx + 3]};
+                        acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt], bf, acc[j], 0, 0, 0);
+                    }
+                }
+                // every window position is an output pixel of its own: requantise all sixteen values of the lane
+                int32_t accb[4][4], v[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accb[r][j] = acc[j][r];
+                if (pow2) {
+                    requant_values<ACT, SAT, 4>(accb, mp[mt], a.zp_act, v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[r][j] = (int32_t)requant_u8(accb[r][j], 0, a.mval[chq[mt] + r], a.sval[chq[mt] + r], a.zp_act, ACT,
+                                                          SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+                }
+                if (valid) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<uint32_t *>(outp + ((size_t)(j >> 1) * W1 + (j & 1)) * a.out_cs + chq[mt]) =
+                            pack4_biased(v[0][j], v[1][j], v[2][j], v[3][j]);
+                }
+            }
+        }
+        if (more) stash(buf ^ 1, nxt);
+    }
+}
+
 template <int ACT, int NM>
 static int first_mfma_launch_sat(AuxArgs &a, hipStream_t st, int grid)
 {
@@ -449,6 +621,35 @@ static int first_mfma_launch_sat(AuxArgs &a, hipStream_t st, int grid)
     else
         hipLaunchKernelGGL((conv_first_mfma_pool_kernel<ACT, false, NM>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
+template <int ACT, int NM>
+static int first_mfma_nopool_launch_sat(AuxArgs &a, hipStream_t st, int grid)
+{
+    if (a.store_mode == MI355_STORE_SATURATE)
+        hipLaunchKernelGGL((conv_first_mfma_kernel<ACT, true, NM>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_first_mfma_kernel<ACT, false, NM>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
+// first layer without a pool on the matrix pipe; MI355_EINVAL outside its domain (the caller uses the VALU kernel)
+int conv_first_mfma_launch(AuxArgs &a, hipStream_t st)
+{
+    if ((a.n != 16 && a.n != 32) || !a.y || a.ypool || a.acc_out || a.y_f32 || (a.H & 1) || (a.W & 1) || !a.cwb || a.in_cs != 4)
+        return MI355_EINVAL;
+    if ((long)a.in_cells + 64L * (a.W + 1) >= (1L << 31)) return MI355_EINVAL;  // 32-bit cell arithmetic in the kernel
+    const int OH = a.H / 2, OW = a.W / 2;
+    const long ntiles = (long)a.B * ((OW + 15) / 16) * ((OH + 7) / 8);
+    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
+    if (a.n == 16) {
+        if (a.act == MI355_ACT_LEAKY) return first_mfma_nopool_launch_sat<MI355_ACT_LEAKY, 1>(a, st, grid);
+        if (a.act == MI355_ACT_RELU6) return first_mfma_nopool_launch_sat<MI355_ACT_RELU6, 1>(a, st, grid);
+        return first_mfma_nopool_launch_sat<MI355_ACT_LINEAR, 1>(a, st, grid);
+    }
+    if (a.act == MI355_ACT_LEAKY) return first_mfma_nopool_launch_sat<MI355_ACT_LEAKY, 2>(a, st, grid);
+    if (a.act == MI355_ACT_RELU6) return first_mfma_nopool_launch_sat<MI355_ACT_RELU6, 2>(a, st, grid);
+    return first_mfma_nopool_launch_sat<MI355_ACT_LINEAR, 2>(a, st, grid);
 }
 
 // returns MI355_EINVAL when the shape is outside the MFMA kernel's domain (the caller uses the VALU kernel)

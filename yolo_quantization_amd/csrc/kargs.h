@@ -99,6 +99,7 @@ int mi355_debug_flags_get();
 int conv_first_launch(AuxArgs &a, hipStream_t st);
 int conv_first_pool_launch(AuxArgs &a, hipStream_t st);
 int conv_first_mfma_pool_launch(AuxArgs &a, hipStream_t st);
+int conv_first_mfma_launch(AuxArgs &a, hipStream_t st);
 int conv_ref_f32_launch(AuxArgs &a, hipStream_t st);
 int maxpool_launch(const PoolArgs &a, hipStream_t st);
 int copy_cells_launch(const CopyArgs &a, hipStream_t st);

@@ -436,6 +436,10 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
             if (rc == MI355_EINVAL) rc = conv_first_pool_launch(a, st);
             return rc == MI355_OK ? MI355_OK : einval("conv_pool_forward: shape not fusable");
         }
+        {  // no pool: the MFMA kernel where it applies (even maps, 16 / 32 filters, no dumps), else the VALU kernel
+            const int rc = (mi355_debug_flags_get() & 1024) ? MI355_EINVAL : conv_first_mfma_launch(a, st);
+            if (rc != MI355_EINVAL) return rc;
+        }
         return conv_first_launch(a, st);
     }
     if (x->cs % 16) return einval("conv_forward: x.cs must be a multiple of 16");
