@@ -158,7 +158,10 @@ def test_conv1x1_weights_stationary_kernel(B, c, n, H, W, act, store):
                                            (30, 128, 64, 26, 26, "relu6"),     # 2 quads x 4 wave sets, 3 groups: one set idle
                                            (60, 256, 64, 20, 17, "linear"),    # 2 quads x 2 K parts x 2 sets, ragged tiles across images
                                            (40, 128, 512, 26, 26, "leaky"),    # 2 filter tiles, 7 groups
-                                           (120, 256, 256, 13, 13, "relu")])   # odd group count: K part 0 owns one more
+                                           (120, 256, 256, 13, 13, "relu"),    # odd group count: K part 0 owns one more
+                                           (16, 256, 256, 38, 38, "leaky"),    # persistent workgroups: several tiles each (40 cells in a 64-slot row image)
+                                           (12, 128, 256, 76, 76, "leaky"),    # whole K per wave, several tiles per workgroup (map wider than 62)
+                                           (40, 256, 512, 19, 19, "relu6")])   # tiles that straddle images, ragged last tile
 @pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
 def test_conv_ws3_weights_stationary_kernel(B, c, n, H, W, act, store):
     """The 3x3 kernel for the middle of the net (conv_ws3.hip: 36 K-steps of weights per wave in registers, K parts

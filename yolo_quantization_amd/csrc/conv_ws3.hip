@@ -16,6 +16,7 @@
 //     partner's partial sums and finishes them (no extra additions).
 // Same mathematics and the same bytes as conv_rows.hip (signed-operand decomposition: see conv_igemm.hip).
 #include "kargs.h"
+#include <type_traits>
 
 #ifdef MI355_ABLATE
 // per-wave phase timestamps (100 MHz wall clock): tools/conv_microbench.py --timeline3
@@ -84,12 +85,79 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = lane >> 5, lj = lane & 31;
     const int wq = wave % NQ, kp = (wave / NQ) % KP, wset = wave / (NQ * KP), nset = 8 / (NQ * KP);
-    const int mt = blockIdx.x % a.mtiles, tile = blockIdx.x / a.mtiles;
+    // persistent over pixel tiles: workgroup (mt, wg) keeps the A fragments of filter tile mt in its registers and walks
+    // the tiles wg, wg + nwg, .. (one tile per workgroup when the whole layer is a single round: the yolov3-tiny layers)
+    const int mt = blockIdx.x % a.mtiles, wg = blockIdx.x / a.mtiles, nwg = gridDim.x / a.mtiles;
     const int f0 = mt * NF;                      // first filter of the workgroup
     const int W1 = a.W + 1, hw = a.H * a.W;
-    const int p0 = tile * TP, p1 = min(p0 + TP, a.total_n);  // this tile's pixels [p0, p1)
     const bool pow2 = a.hdr->pow2 == 1;
+    v4i wf[KST];
+    WP3_DECL;
     TS3(0);
+    // staging of one tile's image (and, for the workgroup's first tile, its A fragments behind the first image batch)
+    auto stage = [&](int tile, auto with_a_c) {
+        constexpr bool WITH_A = decltype(with_a_c)::value;
+        constexpr int UB = WITH_A ? WS3_UB : 4;  // later tiles stage with fewer loads in flight: the A fragments hold 144 VGPRs
+        const int p0 = tile * TP, p1 = min(p0 + TP, a.total_n);  // this tile's pixels [p0, p1)
+
+        // ---- tile geometry: image rows [first - 1, last + 1] of the flattened (b, y) row space, columns -1 .. W
+        const int b0 = p0 / hw, r0 = (p0 - b0 * hw) / a.W;
+        const int b1 = (p1 - 1) / hw, r1 = ((p1 - 1) - b1 * hw) / a.W;
+        const int gr_first = b0 * (a.H + 1) + r0 + 1;
+        const int nrows = b1 * (a.H + 1) + r1 + 1 - gr_first + 3;
+        const long org = (long)a.in_lead + (long)(gr_first - 1) * W1 - 1;
+        // LDS image: cell-major, row R (0 = the row above the tile's first pixel row) at cells [(R % RS) ncell, +ncell), cell
+        // c = column c - 1; a cell is its C channels followed by 16 B of skew (CELLB / 16 is odd: the 16 lanes of a
+        // B-fragment read, one cell apart, hit 16 different 16-byte bank groups).  Every tap / channel-block offset of a
+        // K-step is then a compile-time immediate of the ds_read.  RS < nrows only for tiles that are one whole image:
+        // the pad row below it aliases the pad row above it.
+        const int srows = min(nrows, RS);
+
+        // ---- stage the image: unit u = (cell, piece); a wave instruction reads 1 KiB of consecutive bytes
+        {
+            const int total_u = (srows * ncell) << PSH;
+            for (int u0 = 0; u0 < total_u; u0 += 512 * UB) {
+                v4i v[UB];
+#pragma unroll
+                for (int i = 0; i < UB; ++i) {
+                    const int u = min(u0 + i * 512 + tid, total_u - 1);
+                    const int lin = u >> PSH, piece = u & (PIECES - 1);
+                    const int r = lin / ncell, c = lin - r * ncell;
+                    long f = org + (long)r * W1 + c;
+                    f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
+                    v[i] = *reinterpret_cast<const v4i *>(a.x + (size_t)f * a.in_cs + piece * 16);
+                }
+                if (WITH_A && u0 == 0) {  // this wave's A fragments queue behind the first image batch of the first tile
+#pragma unroll
+                    for (int s = 0; s < KST; ++s)
+                        wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(((f0 >> 5) + wq) * KP + kp) * KST + s) * 1024 + lane * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < UB; ++i) {
+                    const int u = u0 + i * 512 + tid;
+                    const int lin = u >> PSH, piece = u & (PIECES - 1);
+                    int t = 0;
+                    t = __builtin_amdgcn_sdot4(v[i][0], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(v[i][1], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(v[i][2], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(v[i][3], 0x01010101, t, false);
+#pragma unroll
+                    for (int m = 1; m < PIECES; m <<= 1) t += __shfl_xor(t, m);
+                    if (u < total_u) {
+                        *reinterpret_cast<v4i *>(smem + lin * CELLB + piece * 16) = v[i];
+                        if (piece == 0) ldsS[lin] = t;
+                    }
+                }
+            }
+        }
+    };
+    if (wg < a.ntiles_n) stage(wg, std::true_type{});
+    for (int tile = wg, first = 1; tile < a.ntiles_n; tile += nwg, first = 0) {
+    if (!first) {
+        __syncthreads();  // every wave is done with the previous tile's image, tables and parked partial sums
+        stage(tile, std::false_type{});
+    }
+    const int p0 = tile * TP, p1 = min(p0 + TP, a.total_n);  // this tile's pixels [p0, p1)
 
     // ---- tile geometry: image rows [first - 1, last + 1] of the flattened (b, y) row space, columns -1 .. W
     const int b0 = p0 / hw, r0 = (p0 - b0 * hw) / a.W;
@@ -104,47 +172,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     // the pad row below it aliases the pad row above it.
     const int srows = min(nrows, RS);
 
-    // ---- stage the image: unit u = (cell, piece); a wave instruction reads 1 KiB of consecutive bytes
-    v4i wf[KST];
-    {
-        const int total_u = (srows * ncell) << PSH;
-        for (int u0 = 0; u0 < total_u; u0 += 512 * WS3_UB) {
-            v4i v[WS3_UB];
-#pragma unroll
-            for (int i = 0; i < WS3_UB; ++i) {
-                const int u = min(u0 + i * 512 + tid, total_u - 1);
-                const int lin = u >> PSH, piece = u & (PIECES - 1);
-                const int r = lin / ncell, c = lin - r * ncell;
-                long f = org + (long)r * W1 + c;
-                f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
-                v[i] = *reinterpret_cast<const v4i *>(a.x + (size_t)f * a.in_cs + piece * 16);
-            }
-            if (u0 == 0) {  // this wave's A fragments queue behind the first image batch
-#pragma unroll
-                for (int s = 0; s < KST; ++s)
-                    wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(((f0 >> 5) + wq) * KP + kp) * KST + s) * 1024 + lane * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < WS3_UB; ++i) {
-                const int u = u0 + i * 512 + tid;
-                const int lin = u >> PSH, piece = u & (PIECES - 1);
-                int t = 0;
-                t = __builtin_amdgcn_sdot4(v[i][0], 0x01010101, t, false);
-                t = __builtin_amdgcn_sdot4(v[i][1], 0x01010101, t, false);
-                t = __builtin_amdgcn_sdot4(v[i][2], 0x01010101, t, false);
-                t = __builtin_amdgcn_sdot4(v[i][3], 0x01010101, t, false);
-#pragma unroll
-                for (int m = 1; m < PIECES; m <<= 1) t += __shfl_xor(t, m);
-                if (u < total_u) {
-                    *reinterpret_cast<v4i *>(smem + lin * CELLB + piece * 16) = v[i];
-                    if (piece == 0) ldsS[lin] = t;
-                }
-            }
-        }
-    }
     TS3(1);
     // ---- per-channel parameters of the workgroup's filters
-    for (int i = tid; i < NF; i += 512) {
+    if (first) for (int i = tid; i < NF; i += 512) {
         ldsMP[i] = a.mprime[f0 + i];
         ldsDZ[i] = a.dzp[f0 + i];
         ldsCB[i] = a.cwb[f0 + i];
@@ -196,10 +226,6 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
 
     // B fragments are fetched four K-steps ahead of the MFMA that consumes them (a ring of four register sets; the
     // sched_barrier after every step keeps the compiler from sinking the reads back to their use)
-    WP3_DECL;
-#ifdef MI355_ABLATE
-    const long long wp3_c4 = __builtin_readcyclecounter();
-#endif
     auto kloop = [&](v16i &acc, int rx) {
         WP3_START();
         int rowoff[3];
@@ -336,10 +362,8 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
             WP3_MARK(2);
         }
     }
+    }  // tiles
     TS3(7);
-#ifdef MI355_ABLATE
-    wp3[3] = __builtin_readcyclecounter() - wp3_c4;
-#endif
     WP3_STORE();
 }
 
@@ -390,37 +414,68 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
     if (a.stride != 1 || a.up != 1 || a.out_w < a.n) return MI355_EINVAL;
     const int kp = c / 128, nq = ws3_quads(a.n, c), pieces = 8 * kp;
     const int mtiles = a.n / (32 * nq), nset = 8 / (nq * kp);
-    // one round of workgroups: equal tiles of consecutive pixels
     const long total = a.total_n;
-    const int want = 256 / mtiles > 0 ? 256 / mtiles : 1;
-    const int tp = (int)((total + want - 1) / want);
-    if (tp > WS3_GMAX * 32 || tp < 64) return MI355_EINVAL;  // several rounds / tiny batches: the row-image kernel is the better fit
-    const int ntiles = (int)((total + tp - 1) / tp);
-    const int G = (tp + 31) / 32, hw = a.H * a.W;
-    int rows_cap = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        const long p0 = (long)t * tp, p1 = (p0 + tp < total ? p0 + tp : total) - 1;
-        const int b0 = (int)(p0 / hw), r0 = (int)((p0 - (long)b0 * hw) / a.W);
-        const int b1 = (int)(p1 / hw), r1 = (int)((p1 - (long)b1 * hw) / a.W);
-        const int nrows = b1 * (a.H + 1) + r1 - b0 * (a.H + 1) - r0 + 3;
-        if (nrows > rows_cap) rows_cap = nrows;
+    const int hw = a.H * a.W;
+    const int want = 256 / mtiles > 0 ? 256 / mtiles : 1;  // workgroups per filter tile: one round of the chip
+    // LDS need of a plan with tiles of tp pixels (0: does not fit); fills the geometry fields of `a`
+    auto plan = [&](int tp, size_t &lds_out) {
+        const int ntiles = (int)((total + tp - 1) / tp);
+        const int G = (tp + 31) / 32;
+        int rows_cap = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            const long p0 = (long)t * tp, p1 = (p0 + tp < total ? p0 + tp : total) - 1;
+            const int b0 = (int)(p0 / hw), r0 = (int)((p0 - (long)b0 * hw) / a.W);
+            const int b1 = (int)(p1 / hw), r1 = (int)((p1 - (long)b1 * hw) / a.W);
+            const int nrows = b1 * (a.H + 1) + r1 - b0 * (a.H + 1) - r0 + 3;
+            if (nrows > rows_cap) rows_cap = nrows;
+        }
+        if (tp == hw && total % hw == 0 && rows_cap == a.H + 2) rows_cap = a.H + 1;  // whole-image tiles: the two pad rows alias
+        const int cells = rows_cap * (a.W + 2);
+        size_t lds = (size_t)cells * (pieces + 1) * 16;
+        const size_t imgb = lds;
+        lds += (size_t)((cells + 3) & ~3) * 4 + (size_t)G * 32 * 12;
+        lds = (lds + 15) & ~(size_t)15;
+        const size_t poff = lds;
+        lds += (size_t)32 * nq * 16;
+        const size_t roff = lds;
+        if (kp == 2) lds += (size_t)nq * nset * ((G + nset - 1) / nset) * 4096;
+        if (lds > 160 * 1024) return false;
+        a.sm_tp = tp;
+        a.ntiles_n = ntiles;
+        a.sm_ncell = a.W + 2;
+        a.rows_cap = rows_cap;
+        a.sm_pieceb = (int)imgb;
+        a.lds_param_off = (int)poff;
+        a.sm_red_off = (int)roff;
+        lds_out = lds;
+        return true;
+    };
+    size_t lds = 0;
+    int nwg = 0;
+    const int tp1 = (int)((total + want - 1) / want);  // one tile per workgroup
+    if (tp1 < 64) return MI355_EINVAL;                 // tiny batches: the row-image kernel is the better fit
+    if (tp1 <= WS3_GMAX * 32 && plan(tp1, lds)) {
+        nwg = a.ntiles_n;
+    } else {
+        // Several tiles per workgroup cost a staging pass and four barriers per tile: measured 94 us against the row-image
+        // kernel's 68 us on 256->256 @52x52 (BASELINE config[1]), but 70 / 74 us against 104 / 103 us where that kernel
+        // cannot tile the map well (128->256 @76x76: wider than its 62-pixel row image; 256->512 @38x38: 40 cells in
+        // a 64-slot row).  Only those maps take this path.
+        const int rs = a.W + 2 <= 16 ? 16 : (a.W + 2 <= 32 ? 32 : 64);
+        if (a.W <= 62 && (a.W + 2) >= 0.7 * rs) return MI355_EINVAL;
+        // several tiles per (persistent) workgroup: the largest tile that fits LDS, the tile count rounded up to whole
+        // rounds of the `want` workgroups and the tile size shrunk to match, so that every workgroup walks as many tiles
+        bool ok = false;
+        for (int tpm = WS3_GMAX * 32; tpm >= 64 && !ok; tpm -= 32) {
+            const long per = (total + (long)want * tpm - 1) / ((long)want * tpm);  // tiles per workgroup
+            const int tp = (int)((total + per * want - 1) / (per * want));
+            ok = tp >= 48 && plan(tp, lds);
+        }
+        if (!ok) return MI355_EINVAL;
+        nwg = a.ntiles_n < want ? a.ntiles_n : want;
     }
     a.debug = mi355_debug_flags_get();
-    a.sm_tp = tp;
     a.sm_nq = nq;
     a.mtiles = mtiles;
-    if (tp == hw && total % hw == 0 && rows_cap == a.H + 2) rows_cap = a.H + 1;  // whole-image tiles: the two pad rows alias
-    a.sm_ncell = a.W + 2;
-    a.rows_cap = rows_cap;
-    const int cells = rows_cap * a.sm_ncell;
-    a.sm_pieceb = cells * (pieces + 1) * 16;  // bytes of the LDS image
-    size_t lds = (size_t)a.sm_pieceb;
-    lds += (size_t)((cells + 3) & ~3) * 4 + (size_t)G * 32 * 12;
-    lds = (lds + 15) & ~(size_t)15;
-    a.lds_param_off = (int)lds;
-    lds += (size_t)32 * nq * 16;
-    a.sm_red_off = (int)lds;
-    if (kp == 2) lds += (size_t)nq * nset * ((G + nset - 1) / nset) * 4096;
-    if (lds > 160 * 1024) return MI355_EINVAL;
-    return kp == 1 ? w3_launch_act<1>(a, st, mtiles * ntiles, lds) : w3_launch_act<2>(a, st, mtiles * ntiles, lds);
+    return kp == 1 ? w3_launch_act<1>(a, st, mtiles * nwg, lds) : w3_launch_act<2>(a, st, mtiles * nwg, lds);
 }
