@@ -431,6 +431,37 @@ def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain):
     assert np.array_equal(yp2.to_nchw(), want_pool)
 
 
+@pytest.mark.parametrize("B,c,n,H,W,act", [(2, 32, 64, 76, 76, "leaky"),      # flat tiles of 128 window blocks
+                                           (1, 32, 64, 152, 152, "leaky"),    # 8 x 16 patches (wide map), YOLOv3's 32->64 layer shape
+                                           (1, 16, 32, 40, 300, "relu6"),     # very wide rows, ragged patches
+                                           (3, 16, 64, 30, 34, "linear"),     # two m-tiles per wave
+                                           (2, 32, 32, 18, 22, "leaky"),
+                                           (1, 64, 128, 152, 152, "leaky"),   # 64 channels (conv_mid): YOLOv3's 64->128 layer shape
+                                           (3, 64, 64, 26, 38, "relu6"), (2, 64, 96, 52, 52, "linear")])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+def test_conv_small_channel_kernel_without_pool(B, c, n, H, W, act, store):
+    """The 16 / 32-channel weights-stationary kernel without a pool behind it (conv_small.hip, POOL = false: the four
+    window positions of a lane are four output pixels): bytes against the oracle and against the generic implicit GEMM
+    (debug flag 1024), extreme weight zero points included."""
+    rng = np.random.default_rng(B + c + n + H + W)
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3)
+    zp_w[0], zp_w[n - 1] = 0, 255
+    xt = binding.DevTensor.from_nchw(x, 23)
+    args = (xt, wq, zp_w, 3, bias, mv, sv, 23, 23, 1.0, binding.ACT[act], store, binding.ACC_EXACT)
+    got = binding.conv_forward(*args, want_acc=False)
+    assert binding.shim().mi355_last_conv_kernel() == 2, "the call should be served by conv_small.hip"
+    _, u8 = _oracle_layer(x, wq, zp_w, 3, 23, bias, mv, sv, 23, oracle.ACT[act], store, oracle.ACC_EXACT)
+    assert np.array_equal(got["u8"].reshape(B, n, H * W), u8)
+    binding.shim().mi355_debug_flags(1024)
+    try:
+        gen = binding.conv_forward(*args, want_acc=False)
+        assert binding.shim().mi355_last_conv_kernel() == 5
+    finally:
+        binding.shim().mi355_debug_flags(0)
+    assert np.array_equal(got["u8"], gen["u8"])
+
+
 @pytest.mark.parametrize("gain", ["no-wrap", "much-wrap"])
 def test_first_layer_mfma_pool_extreme_weight_zero_points(gain):
     """First-layer MFMA kernel: weight zero points 0 and 255 (128 - zp_w = 128 does not fit the int8 operand of the

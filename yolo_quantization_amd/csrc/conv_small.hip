@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t pool_requant_quad(const int32_t (&accb)[4][4
     return pack4_biased(m[0], m[1], m[2], m[3]);
 }
 
-template <int C, int NM, int ACT, bool SAT>
+template <int C, int NM, int ACT, bool SAT, bool POOL = true>
 __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs a)
 {
     constexpr int KST = (C == 16) ? 5 : 9;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
         ldsDZ[tid] = a.dzp[tid];
         ldsCB[tid] = a.cwb[tid];
         int32_t lo = -2147483647 - 1, hi = 2147483647;
-        if (!SAT) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
+        if (!SAT && POOL) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
         ldsLO[tid] = lo;
         ldsHI[tid] = hi;
     }
@@ -352,11 +352,34 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) accb[r][j] = DZM ? acc[j][grp * 4 + r] : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
                 }
-                pk[mt][grp] = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
+                if constexpr (POOL) {
+                    pk[mt][grp] = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
+                } else {
+                    // no pool behind this layer (the 3x3 layers of the non-tiny nets' residual blocks): the four window
+                    // positions of the lane are four output pixels, all sixteen values are requantised and stored
+                    int32_t v[4][4];
+                    if (pow2) {
+                        requant_values<ACT, SAT, 4>(accb, mp, a.zp_act, v);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                v[r][j] = (int32_t)requant_u8(accb[r][j], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
+                                                              SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+                    }
+                    if (valid) {
+                        uint8_t *oy = a.y + ((size_t)a.out_lead + ((size_t)b * (a.H + 1) + (2 * prow + 1)) * W1 + 2 * pcol) * a.out_cs + ch0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            *reinterpret_cast<uint32_t *>(oy + ((size_t)(j >> 1) * W1 + (j & 1)) * a.out_cs) =
+                                pack4_biased(v[0][j], v[1][j], v[2][j], v[3][j]);
+                    }
+                }
             }
         }
         pk_outp = outp;
-        pk_valid = valid;
+        pk_valid = valid && POOL;
     }
     flush_stores();
 }
@@ -372,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
 // Against the row-image kernel + stand-alone maxpool this does a quarter of the requantisations, keeps the weights out
 // of the loop and has no K-loop barriers: 36 + 5 us -> see profiles/.
 // ---------------------------------------------------------------------------------------------------------------
-template <int ACT, bool SAT>
+template <int ACT, bool SAT, bool POOL = true>
 __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
 {
     constexpr int KST = 18, PIECES = 4, GMAX = SM_GMAX;
@@ -449,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         ldsDZ[i] = a.dzp[i];
         ldsCB[i] = a.cwb[i];
         int32_t lo = -2147483647 - 1, hi = 2147483647;
-        if (!SAT) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
+        if (!SAT && POOL) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
         ldsLO[i] = lo;
         ldsHI[i] = hi;
     }
@@ -482,8 +505,10 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         const int rr = b * (a.H + 1) + 2 * prow + 1 - gr_first + (j >> 1);
         const int cc = 2 * pcol - 1 - col0 + (j & 1);
         ldsBase[idx] = rr * rowb + cc * 16;
-        if (j == 0)
-            ldsCell[g * 32 + l] = valid ? (long)a.pool_lead + ((long)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol : -1L;
+        if (j == 0)  // output cell: the pooled pixel, or (no pool) the top-left of its four conv pixels
+            ldsCell[g * 32 + l] = !valid ? -1L
+                                  : POOL ? (long)a.pool_lead + ((long)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol
+                                         : (long)a.out_lead + ((long)b * (a.H + 1) + (2 * prow + 1)) * W1 + 2 * pcol;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // image, parameters, pixel tables
@@ -561,8 +586,28 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) accb[r][j] = acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
             }
-            const uint32_t packed = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
-            if (pcell >= 0) *reinterpret_cast<uint32_t *>(a.ypool + (size_t)pcell * a.pool_cs + ch0) = packed;
+            if constexpr (POOL) {
+                const uint32_t packed = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
+                if (pcell >= 0) *reinterpret_cast<uint32_t *>(a.ypool + (size_t)pcell * a.pool_cs + ch0) = packed;
+            } else {  // no pool: four output pixels per lane, sixteen requantisations
+                int32_t v[4][4];
+                if (pow2) {
+                    requant_values<ACT, SAT, 4>(accb, mp, a.zp_act, v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[r][j] = (int32_t)requant_u8(accb[r][j], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
+                                                          SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+                }
+                if (pcell >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<uint32_t *>(a.y + (size_t)(pcell + (j >> 1) * W1 + (j & 1)) * a.out_cs + ch0) =
+                            pack4_biased(v[0][j], v[1][j], v[2][j], v[3][j]);
+                }
+            }
         }
     }
 }
@@ -570,36 +615,39 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
 template <int ACT>
 static int mid_launch_sat(ConvArgs &a, hipStream_t st, int grid, int threads, size_t lds)
 {
+    auto go = [&](auto kern) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MI355_EHIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+        return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+    };
+    const bool sat = a.store_mode == MI355_STORE_SATURATE;
+    if (a.ypool) return sat ? go(conv_mid_pool_kernel<ACT, true, true>) : go(conv_mid_pool_kernel<ACT, false, true>);
+    return sat ? go(conv_mid_pool_kernel<ACT, true, false>) : go(conv_mid_pool_kernel<ACT, false, false>);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int C, int NM, int ACT, bool POOL>
+static int small_launch_sat2(ConvArgs &a, hipStream_t st, int grid, size_t lds)
+{
     if (a.store_mode == MI355_STORE_SATURATE) {
-        auto kern = conv_mid_pool_kernel<ACT, true>;
+        auto kern = conv_small_pool_kernel<C, NM, ACT, true, POOL>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
     } else {
-        auto kern = conv_mid_pool_kernel<ACT, false>;
+        auto kern = conv_small_pool_kernel<C, NM, ACT, false, POOL>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
     }
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
 template <int C, int NM, int ACT>
 static int small_launch_sat(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 {
-    if (a.store_mode == MI355_STORE_SATURATE) {
-        auto kern = conv_small_pool_kernel<C, NM, ACT, true>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-    } else {
-        auto kern = conv_small_pool_kernel<C, NM, ACT, false>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-    }
-    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+    return a.ypool ? small_launch_sat2<C, NM, ACT, true>(a, st, grid, lds) : small_launch_sat2<C, NM, ACT, false>(a, st, grid, lds);
 }
 
 template <int C, int NM>
@@ -621,7 +669,9 @@ bool conv_small_eligible(int n, int c, int ksize)
 int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
 {
     const int c = a.cb * a.nchunks;
-    if (!conv_small_eligible(a.n, c, a.ksize) || !a.ypool || a.y || a.acc_out || a.y_f32 || !a.ws) return MI355_EINVAL;
+    // conv + maxpool (ypool, no y), or the same kernels without the pool (y, no ypool): four output pixels per lane
+    if (!conv_small_eligible(a.n, c, a.ksize) || a.acc_out || a.y_f32 || !a.ws) return MI355_EINVAL;
+    if (a.ypool ? a.y != nullptr : (a.y == nullptr || a.out_w < a.n || a.up != 1 || a.stride != 1)) return MI355_EINVAL;
     if ((a.H & 1) || (a.W & 1) || a.in_cs != c) return MI355_EINVAL;
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     const int OH = a.H / 2, OW = a.W / 2;
