@@ -74,9 +74,14 @@ __device__ __forceinline__ uint32_t pool_requant_quad(const int32_t (&accb)[4][4
     return pack4_biased(m[0], m[1], m[2], m[3]);
 }
 
-template <int C, int NM, int ACT, bool SAT, bool POOL = true>
+// MODE 0: conv + 2x2/2 maxpool.  1: no pool, the four window positions of a lane are four output pixels.  2: stride-2
+// convolution = the stride-1 output at the even positions = window position 0 only (a quarter of the MFMAs), stored on the
+// pooled geometry (the output map of a stride-2 3x3 pad-1 convolution on an even map is the pooled map).
+template <int C, int NM, int ACT, bool SAT, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs a)
 {
+    constexpr bool POOL = MODE == 0;
+    constexpr int NJ = MODE == 2 ? 1 : 4;  // window positions computed
     constexpr int KST = (C == 16) ? 5 : 9;
     constexpr int PIECES = C / 16;
     constexpr int N = 32 * NM;
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
             for (int grp = 0; grp < 4; ++grp) {
                 const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + 32 * mt + 8 * grp + 4 * kh);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     acc[j][grp * 4 + 0] = c4.x; acc[j][grp * 4 + 1] = c4.y;
                     acc[j][grp * 4 + 2] = c4.z; acc[j][grp * 4 + 3] = c4.w;
                 }
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
 #pragma unroll
             for (int s = 0; s < KST; ++s)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const v4i bf = *reinterpret_cast<const v4i *>(X + base[j] + toff[s]);
                     acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[mt][s], bf, acc[j], 0, 0, 0);
                     if (DZM) {
@@ -350,10 +355,25 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
                 for (int r = 0; r < 4; ++r) {
                     mp[r] = ldsMP[ch0 + r];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) accb[r][j] = DZM ? acc[j][grp * 4 + r] : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
+                    for (int j = 0; j < 4; ++j) accb[r][j] = j >= NJ ? 0 : (DZM ? acc[j][grp * 4 + r] : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]));
                 }
                 if constexpr (POOL) {
                     pk[mt][grp] = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
+                } else if constexpr (MODE == 2) {  // stride 2: one value per (pixel, channel), plain requantisation
+                    int32_t a1[4][1], v1[4][1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a1[r][0] = accb[r][0];
+                    if (pow2) {
+                        requant_values<ACT, SAT, 1>(a1, mp, a.zp_act, v1);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            v1[r][0] = (int32_t)requant_u8(a1[r][0], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
+                                                           SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+                    }
+                    if (valid)
+                        *reinterpret_cast<uint32_t *>(a.y + ((size_t)a.out_lead + ((size_t)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol) * a.out_cs + ch0) =
+                            pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
                 } else {
                     // no pool behind this layer (the 3x3 layers of the non-tiny nets' residual blocks): the four window
                     // positions of the lane are four output pixels, all sixteen values are requantised and stored
@@ -627,7 +647,7 @@ static int mid_launch_sat(ConvArgs &a, hipStream_t st, int grid, int threads, si
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int C, int NM, int ACT, bool POOL>
+template <int C, int NM, int ACT, int POOL>
 static int small_launch_sat2(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 {
     if (a.store_mode == MI355_STORE_SATURATE) {
@@ -647,7 +667,8 @@ static int small_launch_sat2(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 template <int C, int NM, int ACT>
 static int small_launch_sat(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 {
-    return a.ypool ? small_launch_sat2<C, NM, ACT, true>(a, st, grid, lds) : small_launch_sat2<C, NM, ACT, false>(a, st, grid, lds);
+    if (a.ypool) return small_launch_sat2<C, NM, ACT, 0>(a, st, grid, lds);
+    return a.stride == 2 ? small_launch_sat2<C, NM, ACT, 2>(a, st, grid, lds) : small_launch_sat2<C, NM, ACT, 1>(a, st, grid, lds);
 }
 
 template <int C, int NM>
@@ -671,7 +692,7 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
     const int c = a.cb * a.nchunks;
     // conv + maxpool (ypool, no y), or the same kernels without the pool (y, no ypool): four output pixels per lane
     if (!conv_small_eligible(a.n, c, a.ksize) || a.acc_out || a.y_f32 || !a.ws) return MI355_EINVAL;
-    if (a.ypool ? a.y != nullptr : (a.y == nullptr || a.out_w < a.n || a.up != 1 || a.stride != 1)) return MI355_EINVAL;
+    if (a.ypool ? (a.y != nullptr || a.stride != 1) : (a.y == nullptr || a.out_w < a.n || a.up != 1 || (a.stride == 2 && c == 64))) return MI355_EINVAL;
     if ((a.H & 1) || (a.W & 1) || a.in_cs != c) return MI355_EINVAL;
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     const int OH = a.H / 2, OW = a.W / 2;

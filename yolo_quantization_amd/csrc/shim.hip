@@ -473,7 +473,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     int rc = MI355_EINVAL;
     if (ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) { rc = conv_small_pool_launch(a, st); g_last_kernel = 2; }  // few-channel layers
     // the same kernel without the pool: few-channel 3x3 layers of the non-tiny nets (even maps, no dumps)
-    if (rc == MI355_EINVAL && !ypool && y && a.ws && d->ksize == 3 && d->stride == 1 && up == 1 && !acc_out && !y_f32 && !yolo_out &&
+    if (rc == MI355_EINVAL && !ypool && y && a.ws && d->ksize == 3 && up == 1 && !acc_out && !y_f32 && !yolo_out &&
         (d->c == 16 || d->c == 32 || d->c == 64) && !(mi355_debug_flags_get() & 1024)) { rc = conv_small_pool_launch(a, st); g_last_kernel = 2; }
     if (rc == MI355_EINVAL && a.ws && d->ksize == 1 && !(mi355_debug_flags_get() & 8192)) { rc = conv1x1_ws_launch(a, st); g_last_kernel = 3; }  // 1x1 layers
     if (rc == MI355_EINVAL && a.ws && d->ksize == 3 && !ypool && !(mi355_debug_flags_get() & 16384)) { rc = conv_ws3_launch(a, st); g_last_kernel = 4; }  // mid layers
