@@ -103,7 +103,8 @@ def test_conv_fast_epilogue_huge_requantised_values(c, n, k, H, W, store):
 @pytest.mark.parametrize("B,c,n,H,W,k", [(2, 32, 64, 40, 38, 3), (1, 64, 128, 76, 76, 3), (2, 128, 256, 19, 21, 3),
                                           (1, 16, 32, 31, 50, 3), (1, 256, 512, 38, 38, 3), (3, 48, 40, 9, 11, 3),
                                           # even maps with 16 / 32 channels: the weights-stationary kernel's stride-2 mode
-                                          (2, 16, 32, 24, 300, 3), (1, 32, 32, 64, 64, 3), (2, 16, 64, 18, 22, 3), (1, 32, 64, 304, 304, 3)])
+                                          (2, 16, 32, 24, 300, 3), (1, 32, 32, 64, 64, 3), (2, 16, 64, 18, 22, 3), (1, 32, 64, 304, 304, 3),
+                                          (2, 64, 96, 30, 46, 3), (1, 64, 128, 152, 152, 3)])
 @pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
 def test_conv_stride2(B, c, n, H, W, k, store):
     """Stride-2 convolutions (the downsampling layers of full YOLOv3, BASELINE config[4]; ref: the same

@@ -415,9 +415,11 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
 // Against the row-image kernel + stand-alone maxpool this does a quarter of the requantisations, keeps the weights out
 // of the loop and has no K-loop barriers: 36 + 5 us -> see profiles/.
 // ---------------------------------------------------------------------------------------------------------------
-template <int ACT, bool SAT, bool POOL = true>
+template <int ACT, bool SAT, int MODE = 0>  // MODE as in conv_small_pool_kernel: 0 pool, 1 no pool, 2 stride 2
 __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
 {
+    constexpr bool POOL = MODE == 0;
+    constexpr int NJ = MODE == 2 ? 1 : 4;
     constexpr int KST = 18, PIECES = 4, GMAX = SM_GMAX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ncell = a.sm_ncell, rowb = ncell * 16, pieceb = a.sm_pieceb;
@@ -528,7 +530,8 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         if (j == 0)  // output cell: the pooled pixel, or (no pool) the top-left of its four conv pixels
             ldsCell[g * 32 + l] = !valid ? -1L
                                   : POOL ? (long)a.pool_lead + ((long)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol
-                                         : (long)a.out_lead + ((long)b * (a.H + 1) + (2 * prow + 1)) * W1 + 2 * pcol;
+                                  : MODE == 2 ? (long)a.out_lead + ((long)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol
+                                              : (long)a.out_lead + ((long)b * (a.H + 1) + (2 * prow + 1)) * W1 + 2 * pcol;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // image, parameters, pixel tables
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         for (int grp = 0; grp < 4; ++grp) {
             const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + chw + 8 * grp + 4 * kh);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 acc[j][grp * 4 + 0] = c4.x; acc[j][grp * 4 + 1] = c4.y;
                 acc[j][grp * 4 + 2] = c4.z; acc[j][grp * 4 + 3] = c4.w;
             }
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         for (int s = 0; s < KST; ++s) {
             const int soff = ((s >> 1) / 3) * rowb + (s & 1) * 2 * pieceb;  // scalar
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const v4i bf = *reinterpret_cast<const v4i *>(X + base[j] + soff + ((s >> 1) % 3) * 16);
                 acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s], bf, acc[j], 0, 0, 0);
             }
@@ -604,11 +607,25 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
             for (int r = 0; r < 4; ++r) {
                 mp[r] = ldsMP[ch0 + r];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) accb[r][j] = acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
+                for (int j = 0; j < 4; ++j) accb[r][j] = j >= NJ ? 0 : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
             }
             if constexpr (POOL) {
                 const uint32_t packed = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
                 if (pcell >= 0) *reinterpret_cast<uint32_t *>(a.ypool + (size_t)pcell * a.pool_cs + ch0) = packed;
+            } else if constexpr (MODE == 2) {  // stride 2: window position 0 is the output pixel
+                int32_t a1[4][1], v1[4][1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a1[r][0] = accb[r][0];
+                if (pow2) {
+                    requant_values<ACT, SAT, 1>(a1, mp, a.zp_act, v1);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v1[r][0] = (int32_t)requant_u8(a1[r][0], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
+                                                       SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+                }
+                if (pcell >= 0)
+                    *reinterpret_cast<uint32_t *>(a.y + (size_t)pcell * a.out_cs + ch0) = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
             } else {  // no pool: four output pixels per lane, sixteen requantisations
                 int32_t v[4][4];
                 if (pow2) {
@@ -642,8 +659,9 @@ static int mid_launch_sat(ConvArgs &a, hipStream_t st, int grid, int threads, si
         return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
     };
     const bool sat = a.store_mode == MI355_STORE_SATURATE;
-    if (a.ypool) return sat ? go(conv_mid_pool_kernel<ACT, true, true>) : go(conv_mid_pool_kernel<ACT, false, true>);
-    return sat ? go(conv_mid_pool_kernel<ACT, true, false>) : go(conv_mid_pool_kernel<ACT, false, false>);
+    if (a.ypool) return sat ? go(conv_mid_pool_kernel<ACT, true, 0>) : go(conv_mid_pool_kernel<ACT, false, 0>);
+    if (a.stride == 2) return sat ? go(conv_mid_pool_kernel<ACT, true, 2>) : go(conv_mid_pool_kernel<ACT, false, 2>);
+    return sat ? go(conv_mid_pool_kernel<ACT, true, 1>) : go(conv_mid_pool_kernel<ACT, false, 1>);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -692,7 +710,7 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
     const int c = a.cb * a.nchunks;
     // conv + maxpool (ypool, no y), or the same kernels without the pool (y, no ypool): four output pixels per lane
     if (!conv_small_eligible(a.n, c, a.ksize) || a.acc_out || a.y_f32 || !a.ws) return MI355_EINVAL;
-    if (a.ypool ? (a.y != nullptr || a.stride != 1) : (a.y == nullptr || a.out_w < a.n || a.up != 1 || (a.stride == 2 && c == 64))) return MI355_EINVAL;
+    if (a.ypool ? (a.y != nullptr || a.stride != 1) : (a.y == nullptr || a.out_w < a.n || a.up != 1)) return MI355_EINVAL;
     if ((a.H & 1) || (a.W & 1) || a.in_cs != c) return MI355_EINVAL;
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     const int OH = a.H / 2, OW = a.W / 2;
