@@ -230,6 +230,33 @@ def test_conv_random_shapes_vs_oracle(case):
     assert np.array_equal(fast["f32"], got["f32"])
 
 
+@pytest.mark.parametrize("B,c,n,H,W,act", [(16, 128, 256, 76, 76, "leaky"),   # one tile per workgroup
+                                           (8, 256, 512, 76, 76, "leaky"),    # two K parts, persistent workgroups (YOLOv3's 256->512 s2)
+                                           (40, 128, 128, 52, 36, "relu6"),   # non-square, ragged tiles, two wave sets
+                                           (6, 128, 256, 152, 152, "linear")])       # 154-cell rows: tiles of whole output rows
+def test_conv_ws3_stride2(B, c, n, H, W, act):
+    """Stride-2 3x3 convolutions with 128 / 256 input channels in the weights-stationary kernel (output pixel (y, x) reads
+    the input around (2y, 2x): only the pixel -> image-cell tables differ from stride 1): oracle on two images, every
+    byte against the generic implicit GEMM (debug flag 16384)."""
+    rng = np.random.default_rng(B + c + n + H + W)
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3, 2.0 ** -13, 2.0 ** -9)
+    xt = binding.DevTensor.from_nchw(x, 23)
+    args = (xt, wq, zp_w, 3, bias, mv, sv, 23, 23, 1.0, binding.ACT[act], binding.STORE_WRAP, binding.ACC_EXACT)
+    got = binding.conv_forward(*args, want_acc=False, stride=2)
+    assert binding.shim().mi355_last_conv_kernel() == 4, "the call should be served by conv_ws3.hip"
+    sel = [0, B - 1]
+    _, u8 = _oracle_layer(x[sel], wq, zp_w, 3, 23, bias, mv, sv, 23, oracle.ACT[act], oracle.STORE_WRAP, oracle.ACC_EXACT, stride=2)
+    assert np.array_equal(got["u8"][sel].reshape(2, n, (H // 2) * (W // 2)), u8)
+    binding.shim().mi355_debug_flags(16384)
+    try:
+        gen = binding.conv_forward(*args, want_acc=False, stride=2)
+        assert binding.shim().mi355_last_conv_kernel() == 5
+    finally:
+        binding.shim().mi355_debug_flags(0)
+    assert np.array_equal(got["u8"], gen["u8"])
+
+
 @pytest.mark.parametrize("bm,bn,nt", [(128, 256, 0), (128, 128, 0), (64, 256, 0), (64, 128, 0), (32, 256, 0), (32, 128, 0),
                                       (128, 384, 0), (128, 384, 3), (128, 384, 7), (128, 256, 5), (64, 128, 13)])
 def test_conv_every_tile_config(bm, bn, nt):

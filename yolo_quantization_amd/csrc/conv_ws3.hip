@@ -89,7 +89,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     // the tiles wg, wg + nwg, .. (one tile per workgroup when the whole layer is a single round: the yolov3-tiny layers)
     const int mt = blockIdx.x % a.mtiles, wg = blockIdx.x / a.mtiles, nwg = gridDim.x / a.mtiles;
     const int f0 = mt * NF;                      // first filter of the workgroup
-    const int W1 = a.W + 1, hw = a.H * a.W;
+    // a.H x a.W is the INPUT map; pixels (tiles, groups, lanes) enumerate the OUTPUT map OHd x OWd = the input map for
+    // stride 1, its even positions for stride 2 (3x3, pad 1): output (y, x) reads input rows S y - 1 .. S y + 1, columns
+    // S x - 1 .. S x + 1, so only the pixel -> image-cell tables know about the stride
+    const int W1 = a.W + 1, S = a.stride, OHd = a.OH, OWd = a.OW, hw = OHd * OWd;
     const bool pow2 = a.hdr->pow2 == 1;
     v4i wf[KST];
     WP3_DECL;
@@ -101,10 +104,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
         const int p0 = tile * TP, p1 = min(p0 + TP, a.total_n);  // this tile's pixels [p0, p1)
 
         // ---- tile geometry: image rows [first - 1, last + 1] of the flattened (b, y) row space, columns -1 .. W
-        const int b0 = p0 / hw, r0 = (p0 - b0 * hw) / a.W;
-        const int b1 = (p1 - 1) / hw, r1 = ((p1 - 1) - b1 * hw) / a.W;
-        const int gr_first = b0 * (a.H + 1) + r0 + 1;
-        const int nrows = b1 * (a.H + 1) + r1 + 1 - gr_first + 3;
+        const int b0 = p0 / hw, r0 = (p0 - b0 * hw) / OWd;
+        const int b1 = (p1 - 1) / hw, r1 = ((p1 - 1) - b1 * hw) / OWd;
+        const int gr_first = b0 * (a.H + 1) + S * r0 + 1;
+        const int nrows = b1 * (a.H + 1) + S * r1 + 1 - gr_first + 3;
         const long org = (long)a.in_lead + (long)(gr_first - 1) * W1 - 1;
         // LDS image: cell-major, row R (0 = the row above the tile's first pixel row) at cells [(R % RS) ncell, +ncell), cell
         // c = column c - 1; a cell is its C channels followed by 16 B of skew (CELLB / 16 is odd: the 16 lanes of a
@@ -160,10 +163,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     const int p0 = tile * TP, p1 = min(p0 + TP, a.total_n);  // this tile's pixels [p0, p1)
 
     // ---- tile geometry: image rows [first - 1, last + 1] of the flattened (b, y) row space, columns -1 .. W
-    const int b0 = p0 / hw, r0 = (p0 - b0 * hw) / a.W;
-    const int b1 = (p1 - 1) / hw, r1 = ((p1 - 1) - b1 * hw) / a.W;
-    const int gr_first = b0 * (a.H + 1) + r0 + 1;
-    const int nrows = b1 * (a.H + 1) + r1 + 1 - gr_first + 3;
+    const int b0 = p0 / hw, r0 = (p0 - b0 * hw) / OWd;
+    const int b1 = (p1 - 1) / hw, r1 = ((p1 - 1) - b1 * hw) / OWd;
+    const int gr_first = b0 * (a.H + 1) + S * r0 + 1;
+    const int nrows = b1 * (a.H + 1) + S * r1 + 1 - gr_first + 3;
     const long org = (long)a.in_lead + (long)(gr_first - 1) * W1 - 1;
     // LDS image: cell-major, row R (0 = the row above the tile's first pixel row) at cells [(R % RS) ncell, +ncell), cell
     // c = column c - 1; a cell is its C channels followed by 16 B of skew (CELLB / 16 is odd: the 16 lanes of a
@@ -185,9 +188,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
         const bool valid = p < p1;
         const int pc = valid ? p : p1 - 1;  // idle lanes shadow the tile's last pixel
         const int b = pc / hw, rem = pc - b * hw;
-        const int y = rem / a.W, x = rem - y * a.W;
-        ldsBase[idx] = (b * (a.H + 1) + y + 1 - gr_first) | (x << 16);
-        ldsCell[idx] = valid ? a.out_lead + (b * (a.H + 1) + (y + 1)) * W1 + x : -1;
+        const int y = rem / OWd, x = rem - y * OWd;
+        ldsBase[idx] = (b * (a.H + 1) + S * y + 1 - gr_first) | ((S * x) << 16);
+        ldsCell[idx] = valid ? a.out_lead + (b * (OHd + 1) + (y + 1)) * (OWd + 1) + x : -1;
     }
     __syncthreads();
     TS3(2);
@@ -411,11 +414,12 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
 {
     const int c = a.cb * a.nchunks;
     if (!conv_ws3_eligible(a.n, c, a.ksize) || !a.ws || !a.y || a.acc_out || a.ypool || a.y_f32 || a.yolo_out) return MI355_EINVAL;
-    if (a.stride != 1 || a.up != 1 || a.out_w < a.n) return MI355_EINVAL;
+    if ((a.stride != 1 && a.stride != 2) || a.up != 1 || a.out_w < a.n) return MI355_EINVAL;
+    if (a.stride == 2 && ((a.H & 1) || (a.W & 1))) return MI355_EINVAL;  // even maps: output = the even positions
     const int kp = c / 128, nq = ws3_quads(a.n, c), pieces = 8 * kp;
     const int mtiles = a.n / (32 * nq), nset = 8 / (nq * kp);
     const long total = a.total_n;
-    const int hw = a.H * a.W;
+    const int S = a.stride, OHd = a.OH, OWd = a.OW, hw = OHd * OWd;  // pixels enumerate the output map (see the kernel)
     const int want = 256 / mtiles > 0 ? 256 / mtiles : 1;  // workgroups per filter tile: one round of the chip
     // LDS need of a plan with tiles of tp pixels (0: does not fit); fills the geometry fields of `a`
     auto plan = [&](int tp, size_t &lds_out) {
@@ -424,12 +428,12 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
         int rows_cap = 0;
         for (int t = 0; t < ntiles; ++t) {
             const long p0 = (long)t * tp, p1 = (p0 + tp < total ? p0 + tp : total) - 1;
-            const int b0 = (int)(p0 / hw), r0 = (int)((p0 - (long)b0 * hw) / a.W);
-            const int b1 = (int)(p1 / hw), r1 = (int)((p1 - (long)b1 * hw) / a.W);
-            const int nrows = b1 * (a.H + 1) + r1 - b0 * (a.H + 1) - r0 + 3;
+            const int b0 = (int)(p0 / hw), r0 = (int)((p0 - (long)b0 * hw) / OWd);
+            const int b1 = (int)(p1 / hw), r1 = (int)((p1 - (long)b1 * hw) / OWd);
+            const int nrows = b1 * (a.H + 1) + S * r1 - b0 * (a.H + 1) - S * r0 + 3;
             if (nrows > rows_cap) rows_cap = nrows;
         }
-        if (tp == hw && total % hw == 0 && rows_cap == a.H + 2) rows_cap = a.H + 1;  // whole-image tiles: the two pad rows alias
+        if (S == 1 && tp == hw && total % hw == 0 && rows_cap == a.H + 2) rows_cap = a.H + 1;  // whole-image tiles: the two pad rows alias
         const int cells = rows_cap * (a.W + 2);
         size_t lds = (size_t)cells * (pieces + 1) * 16;
         const size_t imgb = lds;
@@ -462,7 +466,7 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
         // cannot tile the map well (128->256 @76x76: wider than its 62-pixel row image; 256->512 @38x38: 40 cells in
         // a 64-slot row).  Only those maps take this path.
         const int rs = a.W + 2 <= 16 ? 16 : (a.W + 2 <= 32 ? 32 : 64);
-        if (a.W <= 62 && (a.W + 2) >= 0.7 * rs) return MI355_EINVAL;
+        if (S == 1 && a.W <= 62 && (a.W + 2) >= 0.7 * rs) return MI355_EINVAL;  // (stride 2 has no row-image kernel)
         // several tiles per (persistent) workgroup: the largest tile that fits LDS, the tile count rounded up to whole
         // rounds of the `want` workgroups and the tile size shrunk to match, so that every workgroup walks as many tiles
         bool ok = false;
@@ -471,6 +475,10 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
             const int tp = (int)((total + per * want - 1) / (per * want));
             ok = tp >= 48 && plan(tp, lds);
         }
+        // wide rows (stride 2 reads two input rows per output row): tiles of whole output rows that never straddle an
+        // image need the fewest LDS rows
+        for (int k = (WS3_GMAX * 32) / OWd; k >= 1 && !ok; --k)
+            if (OHd % k == 0 && k * OWd >= 32) ok = plan(k * OWd, lds);
         if (!ok) return MI355_EINVAL;
         nwg = a.ntiles_n < want ? a.ntiles_n : want;
     }
