@@ -199,7 +199,10 @@ int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     // tiles of equal size, as few rounds of 256 workgroups as the 256-pixel tile limit allows
     const long total = a.total_n;
-    const long rounds = (total + 256L * P1_GMAX * 32 - 1) / (256L * P1_GMAX * 32);
+    // few input channels: a pixel costs little LDS, and layers with millions of pixels (64 -> 32 at 304 x 304) are bound
+    // by the per-workgroup latencies unless a workgroup streams a long tile
+    const int gmax = c <= 64 ? 32 : (c == 128 ? 16 : P1_GMAX);
+    const long rounds = (total + 256L * gmax * 32 - 1) / (256L * gmax * 32);
     int tp = (int)((total + 256 * rounds - 1) / (256 * rounds));
     if (tp < 16) tp = 16;
     const int ntiles = (int)((total + tp - 1) / tp);
