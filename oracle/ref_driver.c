@@ -251,3 +251,29 @@ int refdrv_yolo_params(void *h, int i, float *biases, int *mask, int *total)
     *total = l.total;
     return l.n;
 }
+
+/* The quantised 0.1 the reference derives for LEAKY layers (src/blas.c:318-323: M0_lut0, M0_right_shift_lut0); only the
+ * MKL forward reads it (src/convolutional_layer.c:583), but the default build computes it too. */
+void refdrv_leaky_lut(void *h, int i, int32_t *M0_lut0, int *shift_lut0)
+{
+    layer *l = &((refnet *)h)->net->layers[i];
+    *M0_lut0 = l->M0_lut0;
+    *shift_lut0 = l->M0_right_shift_lut0;
+}
+
+/* One layer of a prepared network on a caller-supplied uint8 input (function-level known-answer vectors: the layer's own
+ * forward pointer, src/convolutional_layer.c:258-273, with net.input_uint8 pointing at `input`). */
+int refdrv_forward_layer(void *h, int i, uint8_t *input)
+{
+    refnet *r = h;
+    if (!r->prepared || i < 0 || i >= r->net->n) return -1;
+    network net = *r->net;
+    net.train = 0;
+    net.index = i;
+    net.input_uint8 = input;
+    layer l = net.layers[i];
+    hush();
+    l.forward(l, net);
+    unhush();
+    return 0;
+}

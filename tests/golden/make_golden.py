@@ -26,8 +26,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from yolo_quantization_amd import synth  # noqa: E402
 import refdrv  # noqa: E402
+import oracle  # noqa: E402  (only for the fp32-exact-regime mask: pass-1 sums of the reference's own layer inputs)
 
 WEIGHT_SEED, IMAGE_SEED = 1234, 7
+LOWRANGE_SEED, LOWRANGE_SHIFT = 500, 5   # function-level vectors of the deep layers: input bytes in 0..7
 
 
 DET_CALLS = [(640, 480, 1, 0.5), (300, 500, 0, 0.3), (416, 416, 1, 0.6)]  # (image w, h, relative, thresh)
@@ -137,6 +139,7 @@ def yolov3_tiny(tag, cfgname):
     wts = f"/tmp/golden_{tag}.weights"
     meta = synth.synth_weights(cfg, wts, seed=WEIGHT_SEED)
     net, layers, x = run_ref(cfg, wts, img_seed=IMAGE_SEED)
+    wrec = oracle.read_weights(wts, layers)
     out = {"cfg": cfgname, "weight_seed": WEIGHT_SEED, "image_seed": IMAGE_SEED, "weights_sha256": meta["sha256"],
            "input_sha256": sha(x), "oracle": "reference default build (GPU=0 QUANTIZATION=1 -Ofast)", "layers": []}
     for i, L in enumerate(layers):
@@ -148,6 +151,24 @@ def yolov3_tiny(tag, cfgname):
             p = net.prep(i)
             e["prep_sha256"] = sha(np.concatenate([p["biases_int32"].view(np.uint8), p["M_value"].view(np.uint8),
                                                    p["shift_value"].view(np.uint8)]))
+            # the "fp32-exact regime" of the reference's accumulators.  With the reference's OWN input to
+            # this layer (teacher forcing), an element is provably exact in src/gemm.c:279-299 when its pass-1 sum
+            # sum_k w_u8*x_u8 (all terms >= 0, so the final sum bounds every prefix) and its result stay within 2^24.
+            # Committed: the mask's hash and size, the reference's int32 / uint8 tensors with the elements outside the
+            # mask zeroed (hashes), and how many elements of the exact-integer result differ from the reference at all.
+            xin = x if i == 0 else net.layer_u8(i - 1).reshape(L.c, L.h, L.w)
+            d = wrec[i]
+            ex, s1 = oracle.conv_acc(xin, d["wq"], d["zp_w"], L.size, L.stride, L.pad, p["zp_in"], oracle.ACC_EXACT, want_s1=True)
+            mask = (s1 <= 2 ** 24) & (np.abs(ex.astype(np.int64)) <= 2 ** 24)
+            ref = a.reshape(ex.shape)
+            assert not ((ex != ref) & mask).any(), f"layer {i}: exact != reference inside the fp32-exact regime"
+            e["exact_mask_count"] = int(mask.sum())
+            e["exact_mask_sha256"] = sha(np.packbits(mask.ravel()))
+            e["ref_int32_masked_sha256"] = sha(np.where(mask, ref, 0).astype(np.int32))
+            e["ref_u8_masked_sha256"] = sha(np.where(mask, net.layer_u8(i).reshape(ex.shape), 0).astype(np.uint8))
+            e["exact_vs_ref_mismatch"] = int((ex != ref).sum())
+            e["exact_vs_ref_max_abs_diff"] = int(np.abs(ex.astype(np.int64) - ref).max())
+            e["M0_lut0"], e["M0_right_shift_lut0"] = net.leaky_lut(i)   # src/blas.c:318-323 (the MKL path's LEAKY multiplier)
         if L.type != "yolo":
             u = net.layer_u8(i)
             e["u8_sha256"] = sha(u)
@@ -157,16 +178,41 @@ def yolov3_tiny(tag, cfgname):
         if L.type == "conv" and L.quant_stop:
             e["u8_hex"] = net.layer_u8(i).tobytes().hex()
         out["layers"].append(e)
+    # Function-level known answers for the deep layers (K >= 2304), whose accumulators the fp32 GEMM rounds on the net's own
+    # activations: the same layers on a LOW-RANGE input (seeded bytes >> LOWRANGE_SHIFT), where every pass-1 sum stays
+    # below 2^24, so the reference's tensors are exact integers and can pin the exact-integer kernels on every element.
+    # Run after the whole-net hashes above (a conv's forward only overwrites that layer's own outputs).
+    for i, L in enumerate(layers):
+        if L.type != "conv" or L.c * L.size * L.size < 2304:
+            continue
+        xl = (synth.synth_image_u8(L.c, L.h, L.w, seed=LOWRANGE_SEED + i) >> LOWRANGE_SHIFT).astype(np.uint8)
+        net.forward_layer(i, xl)
+        a = net.layer_int32(i); u = net.layer_u8(i)
+        p = net.prep(i); d = wrec[i]
+        ex, s1 = oracle.conv_acc(xl, d["wq"], d["zp_w"], L.size, L.stride, L.pad, p["zp_in"], oracle.ACC_EXACT, want_s1=True)
+        mask = (s1 <= 2 ** 24) & (np.abs(ex.astype(np.int64)) <= 2 ** 24)
+        assert mask.all() and np.array_equal(ex.ravel(), a), f"layer {i}: low-range input is meant to keep the fp32 GEMM exact"
+        out["layers"][i]["lowrange"] = {"seed": LOWRANGE_SEED + i, "shift": LOWRANGE_SHIFT, "input_sha256": sha(xl),
+                                        "int32_sha256": sha(a), "u8_sha256": sha(u), "int32_min": int(a.min()),
+                                        "int32_max": int(a.max()), "s1_max": int(s1.max())}
     json.dump(out, open(os.path.join(HERE, f"yolov3_tiny_{tag}.json"), "w"), indent=1)
     print(f"yolov3_tiny_{tag}: wrote {len(out['layers'])} layers")
 
 
 if __name__ == "__main__":
     assert refdrv.available(), "run oracle/build_ref.sh first (needs /root/reference)"
-    tiny_unit(1, 1.0)
-    tiny_unit(2, 8.0)
-    tiny_unit(1, 1.0, "s2_unit")
-    tiny_unit(2, 8.0, "s2_unit")
-    funcs()
-    yolov3_tiny("leaky", "yolov3-tiny_quant.cfg")
-    yolov3_tiny("relu6", "yolov3-tiny_quant_relu6.cfg")
+    only = sys.argv[1:]   # e.g. `make_golden.py yolov3_tiny` rewrites the two JSON files only
+
+    def want(name):
+        return not only or name in only
+    if want("tiny_unit"):
+        tiny_unit(1, 1.0)
+        tiny_unit(2, 8.0)
+    if want("s2_unit"):
+        tiny_unit(1, 1.0, "s2_unit")
+        tiny_unit(2, 8.0, "s2_unit")
+    if want("funcs"):
+        funcs()
+    if want("yolov3_tiny"):
+        yolov3_tiny("leaky", "yolov3-tiny_quant.cfg")
+        yolov3_tiny("relu6", "yolov3-tiny_quant_relu6.cfg")

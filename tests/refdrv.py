@@ -41,6 +41,10 @@ def lib(omp=False):
         L.refdrv_quantize_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.refdrv_yolo_detections.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int]
         L.refdrv_yolo_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(L, "refdrv_forward_layer"):
+            L.refdrv_forward_layer.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        if hasattr(L, "refdrv_leaky_lut"):
+            L.refdrv_leaky_lut.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _libs[omp] = L
     return _libs[omp]
 
@@ -104,6 +108,18 @@ class RefNet:
         cnt = self.L.refdrv_yolo_detections(self.h, i, imw, imh, C.c_float(thresh), int(relative), recs.ctypes.data, cap)
         assert cnt >= 0
         return cnt, recs[:min(cnt, cap)]
+
+    def forward_layer(self, i, x_u8):
+        """Layer i alone on the given uint8 input (its own forward pointer); outputs via layer_int32 / layer_u8 / layer_f32."""
+        x = np.ascontiguousarray(x_u8, dtype=np.uint8)
+        assert x.size == self.info[i]["c"] * self.info[i]["h"] * self.info[i]["w"]
+        assert self.L.refdrv_forward_layer(self.h, i, x.ctypes.data) == 0
+
+    def leaky_lut(self, i):
+        """(M0_lut0, M0_right_shift_lut0) of conv layer i: the quantised 0.1 of the MKL path's LEAKY (src/blas.c:318-323)."""
+        a = C.c_int32(); b = C.c_int()
+        self.L.refdrv_leaky_lut(self.h, i, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def prep(self, i):
         n = max(self.info[i]["n"], 1)

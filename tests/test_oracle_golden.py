@@ -154,10 +154,42 @@ def test_exact_mode_equals_ref_where_fp32_is_exact(golden_dir, cfg_dir, tmp_path
         neq = acc != ref[i]["int32"]
         assert not (neq & safe).any(), f"layer {i}: exact != reference inside the fp32-exact regime"
         differs[i] = int(neq.sum())
+        # the committed, reference-produced description of that regime (what tests/test_gpu_refpin.py holds the HIP kernels to)
+        e = g["layers"][i]
+        assert int(safe.sum()) == e["exact_mask_count"] and sha(np.packbits(safe.ravel())) == e["exact_mask_sha256"], f"layer {i} mask"
+        assert sha(np.where(safe, acc, 0).astype(np.int32)) == e["ref_int32_masked_sha256"], f"layer {i} masked int32"
+        assert differs[i] == e["exact_vs_ref_mismatch"], f"layer {i} mismatch count"
         K = L.c * L.size * L.size
         if K * 255 * 255 < 2 ** 24:
             assert safe.all() and differs[i] == 0
     assert differs[12] > 0, "L12 (K=4608) is expected to show the reference's fp32 rounding"
+
+
+@pytest.mark.parametrize("tag", ["leaky", "relu6"])
+def test_deep_layers_low_range_vectors(golden_dir, cfg_dir, tmp_path, tag):
+    """The K >= 2304 layers on input bytes 0..7 (function-level vectors the reference produced with each layer's own forward
+    pointer): the fp32 GEMM is exact there, so BOTH accumulate modes of the restatement must give the reference's hashes."""
+    g = json.load(open(os.path.join(golden_dir, f"yolov3_tiny_{tag}.json")))
+    cfg = os.path.join(cfg_dir, g["cfg"])
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=g["weight_seed"])
+    net = oracle.OracleNet(cfg, wts)
+    net.prepare(np.float32(1.0 / 255.0), 0)
+    n = 0
+    for e in g["layers"]:
+        lr = e.get("lowrange")
+        if not lr:
+            continue
+        i = e["i"]; L = net.layers[i]; d = net.w[i]; p = net.p[i]
+        xl = (synth.synth_image_u8(L.c, L.h, L.w, seed=lr["seed"]) >> lr["shift"]).astype(np.uint8)
+        assert sha(xl) == lr["input_sha256"]
+        for accum in (oracle.ACC_EXACT, oracle.ACC_REF_F32):
+            acc = oracle.conv_acc(xl, d["wq"], d["zp_w"], L.size, L.stride, L.pad, p["zp_in"], accum)
+            assert sha(acc) == lr["int32_sha256"], (i, accum)
+            u8 = oracle.requant(acc, p["biases_int32"], p["M_value"], p["shift_value"], d["zp_act"], oracle.ACT[L.activation])
+            assert sha(u8) == lr["u8_sha256"], (i, accum)
+        n += 1
+    assert n == 4
 
 
 DET_CALLS = [(640, 480, 1, 0.5), (300, 500, 0, 0.3), (416, 416, 1, 0.6)]  # as in tests/golden/make_golden.py
