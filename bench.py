@@ -35,7 +35,12 @@ def parse_args():
     ap.add_argument("--cpu-images", type=int, default=8, help="bounded CPU-baseline sample (images through the reference)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
     ap.add_argument("--cpu-omp", action="store_true", help="also time the reference's OpenMP build on all host cores (extra JSON key)")
+    ap.add_argument("--no-ref-f32", action="store_true", help="skip the extra leg that times the bit-faithful MI355_ACC_REF_F32 mode")
+    ap.add_argument("--ref-f32-steps", type=int, default=2)
     return ap.parse_args()
+
+
+METRICS = {"yolov3-tiny_quant.cfg": "images/sec yolov3-tiny INT8 416x416", "yolov3_quant.cfg": "images/sec yolov3 (full, 75 conv + 23 quantized shortcut) INT8 608x608"}
 
 
 def conv_layer_work(info, batch):
@@ -48,19 +53,20 @@ def conv_layer_work(info, batch):
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
-    produced by tools/gpu_session.sh pmc + tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950
-    FETCH_SIZE x2 correction).  None when no profile is committed."""
+    """HBM bytes per launch of the dominant kernel from the newest COMMITTED rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json, produced by tools/gpu_session.sh pmc + tools/pmc_traffic.py: separate FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 FETCH_SIZE x2 correction) -- NOT measured in this run (PMC collection needs rocprofv3
+    around the process).  Returns (bytes or None, source file or None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
     if not files:
-        return None
+        return None, None
     rows = [r for r in json.load(open(files[-1])) if "conv_rows_i8_kernel" in r["kernel"]]
     n = sum(r["launches"] for r in rows)
     if not n:
-        return None
+        return None, None
     tot = sum(((r["hbm_read_bytes_per_launch"] or 0) + (r["hbm_write_bytes_per_launch"] or 0)) * r["launches"] for r in rows)
-    return tot / n
+    return tot / n, os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(cfg, wts, nimg, omp=False):
@@ -70,7 +76,20 @@ def cpu_baseline(cfg, wts, nimg, omp=False):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     from yolo_quantization_amd import synth
-    x = synth.synth_image_u8(3, 416, 416, seed=7)
+    _, shapes = synth.layer_shapes(synth.read_cfg(cfg))
+    x = synth.synth_image_u8(shapes[0].c, shapes[0].h, shapes[0].w, seed=7)
+    if any(L.type == "shortcut" for L in shapes):
+        # `[shortcut] quantized=1` is this build's own op: the reference cannot run the net.  Bounded sample: ONE image through
+        # the CPU restatement in exact-integer mode, OpenMP over output channels (thread count stated).
+        import oracle
+        onet = oracle.OracleNet(cfg, wts)
+        onet.prepare(np.float32(1.0 / 255.0), 0)
+        t0 = time.time()
+        onet.forward(x, accum=oracle.ACC_EXACT)
+        dt = time.time() - t0
+        return {"value": 1 / dt, "unit": "images/s", "cores": int(oracle.lib().orc_omp_threads()), "kind": "port",
+                "sample": f"1 x {os.path.basename(cfg)} {shapes[0].h}x{shapes[0].w} image, whole net, batch 1, exact-integer mode "
+                          f"(the reference has no quantized [shortcut]), {os.cpu_count()} host cores present"}
     try:
         import refdrv
         if not refdrv.available(omp):
@@ -94,7 +113,7 @@ def cpu_baseline(cfg, wts, nimg, omp=False):
         dt = time.time() - t0
         kind = "port"
     return {"value": nimg / dt, "unit": "images/s", "cores": (os.cpu_count() if omp and kind == "reference" else 1), "kind": kind,
-            "sample": f"{nimg} x yolov3-tiny 416x416 image, whole net, batch 1, {os.cpu_count()} host cores present"}
+            "sample": f"{nimg} x {os.path.basename(cfg)} {shapes[0].h}x{shapes[0].w} image, whole net, batch 1, {os.cpu_count()} host cores present"}
 
 
 def flush_c_stdio():
@@ -129,7 +148,7 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getppid() % 2000))  # the launcher sets it; this default only serves BENCH_FORCE_DIST
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from yolo_quantization_amd import binding, synth
@@ -239,20 +258,51 @@ def main():
                     mf_ms += t_ms
             all_ms += t_ms
             layers.append(row)
+        # the north-star target is quoted on the 3x3 stride-1 layers: their aggregate MFMA rate, whichever kernel serves them
+        s33_ops = sum(conv_layer_work(inf, B)[0] for i, inf in enumerate(net.info)
+                      if inf["type"] == binding.T_CONV and inf["size"] == 3 and inf["stride"] == 1 and inf["c"] > 3)
+        s33_ms = sum(layers[i]["ms"] for i, inf in enumerate(net.info)
+                     if inf["type"] == binding.T_CONV and inf["size"] == 3 and inf["stride"] == 1 and inf["c"] > 3)
         nlaunch = sum(1 for i, inf in enumerate(net.info) if on_rows_kernel(i, inf))
         nconv = sum(1 for inf in net.info if inf["type"] == binding.T_CONV)
-        achieved = mf_ops / (mf_ms * 1e-3) / 1e12
+        achieved = mf_ops / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
+        traffic, traffic_src = pmc_traffic_per_launch()
         roof = {"bound": "mfma", "kernel": f"conv_rows_i8_kernel (MFMA implicit GEMM on 64-channel chunks: {nlaunch} of the step's {nconv} conv launches, "
                           f"{100 * mf_ms / all_ms:.0f}% of its time and {100 * mf_ops / all_ops:.0f}% of its operations)",
                 "achieved": round(achieved, 2), "peak": round(PEAK_INT8_TOPS, 1), "unit": "TOP/s",
-                "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": pmc_traffic_per_launch(),
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/*_pmc_traffic.json)",
-                "ops_per_launch_avg": mf_ops / nlaunch, "ms_per_launch_avg": round(mf_ms / nlaunch, 5),
+                "frac": round(achieved / PEAK_INT8_TOPS, 4),
+                "traffic": traffic if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg" else None,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                "traffic_source": f"committed profile {traffic_src} -- not measured in this run" if traffic_src else None,
+                "ops_per_launch_avg": mf_ops / max(nlaunch, 1), "ms_per_launch_avg": round(mf_ms / max(nlaunch, 1), 5),
+                "conv3x3_s1_aggregate": {"tops": round(s33_ops / (s33_ms * 1e-3) / 1e12, 1) if s33_ms else None,
+                                         "frac": round(s33_ops / (s33_ms * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4) if s33_ms else None,
+                                         "ms": round(s33_ms, 5), "layers": "every 3x3 stride-1 conv with c > 3"},
                 "input_layout_ms": round(max(float(ms[0]) / nprof - ev_cost, 0.0), 5),
                 "event_overhead_ms": round(ev_cost, 5)}
         if args.layers:
             for r in layers:
                 print("[layer]", json.dumps(r), file=sys.stderr)
+
+    # ---- extra leg: what full-tensor bit-exactness against the Makefile-default reference costs.
+    # MI355_ACC_REF_F32 = the verification kernel that emulates the reference's sequential fp32 accumulation (one thread per
+    # output); same net, same batch, separate instance, never part of `value`.
+    ref_f32 = None
+    if rank == 0 and world == 1 and not force_dist and not args.no_ref_f32 and os.path.basename(args.cfg).startswith("yolov3-tiny"):
+        rnet = binding.Net(args.cfg, wts, batch=B, gpu=local_rank, accum=binding.ACC_REF_F32)
+        rnet.prepare_fixed(1.0 / 255.0, 0)
+        rnet.push_input(x)
+        rnet.forward(); rnet.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.ref_f32_steps):
+            rnet.forward()
+        rnet.sync()
+        rdt = time.perf_counter() - t0
+        rnet.close()
+        ref_f32 = {"images_per_s": round(B * args.ref_f32_steps / rdt, 1), "ms_per_step": round(rdt / args.ref_f32_steps * 1e3, 3),
+                   "steps": args.ref_f32_steps, "batch": B,
+                   "note": "MI355_ACC_REF_F32: bit-identical to the Makefile-default reference on every tensor (fp32-accumulate emulation, "
+                           "tests/test_gpu_parity.py::test_yolov3_tiny_416_ref_f32_equals_reference_hashes); verification mode, not the product path"}
 
     cpu = cpu_omp = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -261,7 +311,7 @@ def main():
             cpu_omp = cpu_baseline(args.cfg, wts, args.cpu_images * 4, omp=True)
 
     if rank == 0:
-        out = {"metric": "images/sec yolov3-tiny INT8 416x416", "value": round(value, 1), "unit": "images/s",
+        out = {"metric": METRICS.get(os.path.basename(args.cfg), f"images/sec {os.path.basename(args.cfg)} INT8"), "value": round(value, 1), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x s8 -> int32 (f64 requant)",
                "data": "synthetic",
@@ -272,7 +322,7 @@ def main():
                           "global_batch": world * B, "parallelism": f"image-sharded x{world}, RCCL weight broadcast once",
                           "launch": "hipGraph replay" if args.graph else f"eager; per-layer HIP events on every {prof_stride}th step of the timed region",
                           "weight_broadcast_ms": round(bcast_ms, 3)},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu, "accum_ref_f32_mode": ref_f32}
         if cpu_omp:
             out["cpu_baseline_allcores"] = cpu_omp
         if layers:

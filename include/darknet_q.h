@@ -33,7 +33,7 @@ extern "C" {
 
 /* same enumerator values as the reference (include/darknet.h:87-89, 99-130) */
 typedef enum { LOGISTIC = 0, RELU = 1, LINEAR = 3, RELU6 = 8, LEAKY = 9 } ACTIVATION;
-typedef enum { CONVOLUTIONAL = 0, MAXPOOL = 3, ROUTE = 8, YOLO = 23, UPSAMPLE = 26 } LAYER_TYPE;
+typedef enum { CONVOLUTIONAL = 0, MAXPOOL = 3, ROUTE = 8, SHORTCUT = 13, YOLO = 23, UPSAMPLE = 26 } LAYER_TYPE;
 
 #define QUANT_POSITIVE_LIMIT 255
 #define QUANT_NEGATIVE_LIMIT 0
@@ -70,6 +70,10 @@ struct layer {
 
     /* route */
     int *input_layers, *input_sizes;
+    /* shortcut (quantized residual add, builder-specified: mi355_shortcut_forward): `index` = the layer added to the
+     * previous layer's output (ref field name, src/shortcut_layer.c:28), the two 16.16 multipliers of the prep */
+    int index;
+    int32_t shortcut_Ka, shortcut_Kb;
     /* yolo */
     int classes, total;
     int *mask;
@@ -134,6 +138,8 @@ struct network {
     const mi355_tensor *fused_pool_t; /* executor -> conv forward_gpu: pooled output tensor of the fused pair */
     int verbose;
     int prepared;
+    int has_host_weights; /* load_weights ran: raw weights_uint8 / biases / scales of every layer are on the host */
+    int has_l0_weights;   /* imported from a packed exchange: blobs only, plus layer 0's raw record (re-prep on a new input scale) */
     void *graph; /* hipGraph of the layer loop, built lazily when use_graph */
     int use_graph;
     /* per-layer HIP-event timing on net->stream (replaces the commented what_time_is_it_now() probes of
@@ -197,6 +203,9 @@ void network_import_packed(network *net, const void *buf, size_t bytes);
 void network_import_packed_host(network *net, const void *buf, size_t bytes); /* host half only (no device) */
 /* same exchange with the buffer already on the device (what bench.py hands over after torch.distributed.broadcast) */
 void network_import_packed_gpu(network *net, const void *dev_buf, size_t bytes);
+/* the same bytes as a file: written once after load_weights + prep, read back with one fread */
+void network_save_packed(network *net, char *filename);
+void network_load_packed(network *net, char *filename);
 
 /* misc */
 void error(const char *s);

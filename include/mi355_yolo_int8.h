@@ -165,6 +165,22 @@ int mi355_maxpool_forward(const mi355_tensor *x, const mi355_tensor *y, int size
 int mi355_upsample_forward(const mi355_tensor *x, const mi355_tensor *y, int stride, void *stream);
 /* forward_route_layer_quant (ref: src/route_layer.c:107-130): channel concat of n inputs, no rescale */
 int mi355_route_forward(const mi355_tensor *const *xs, int n, const mi355_tensor *y, void *stream);
+/* quant_stop tail of a glue layer (ref: src/maxpool_layer.c:163-171, src/upsample_layer.c:104-112, src/route_layer.c:121-129):
+ * out_f32[b][out_c0 + c][pix] = (int)(x[b][pix][c0 + c] - zero_point) * scale for c < nc; out_f32 is the reference's
+ * `l.output` layout [B][out_C][H*W].  A route with quant_stop calls it once per input with that input's own scale / zero
+ * point (ref :125: `net.layers[index].activ_data_uint8_*`). */
+int mi355_dequant_forward(const mi355_tensor *x, int c0, int nc, uint8_t zero_point, float scale, float *out_f32, int out_C,
+                          int out_c0, void *stream);
+/* Quantized residual add, `[shortcut] quantized=1`.  The reference has NO integer shortcut (src/shortcut_layer.c:62-75 and
+ * src/blas.c:490-514 are float only), so this op is builder-specified (parity status: unpinned, the
+ * oracle is oracle.c:orc_shortcut_u8):
+ *     K = round((float)(s_in / s_out) * 2^16)                          mi355_shortcut_multiplier, 1 <= K < 2^21
+ *     q = zp_out + ((Ka*(a - zp_a) + Kb*(b - zp_b) + 2^15) >> 16)      arithmetic shift: round half up
+ *     y = clamp(q, 0, 255)                                             linear activation only
+ * a = the previous layer's tensor, b = the tensor of layer `from`; same batch / map / channels (YOLOv3's residual blocks). */
+int mi355_shortcut_multiplier(float s_in, float s_out, int32_t *K);
+int mi355_shortcut_forward(const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *y, int32_t Ka, int32_t Kb,
+                           uint8_t zp_a, uint8_t zp_b, uint8_t zp_out, void *stream);
 /* letterbox_image (ref: src/image.c:812-831; bilinear resize_image :1199-1242, embed_image :428-439, fill 0.5): planar
  * float image [c][imh][imw] in device memory -> [c][h][w], aspect ratio kept, centred.  Bit-identical floats. */
 int mi355_letterbox_forward(const float *im_f32, int imw, int imh, int c, float *out_f32, int w, int h, void *stream);

@@ -4,6 +4,9 @@
  * (no -ffast-math, -ffp-contract=off) so that every float/double step is the one written here.
  */
 #include "oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -60,6 +63,16 @@ void orc_gemm_nn_u8_i32_te(int M, int N, int K, float ALPHA, const uint8_t *A, i
     }
 }
 
+/* threads the OpenMP-parallel parts (exact-mode accumulators) use; bench.py states it next to a `port` CPU baseline */
+int orc_omp_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* ------------------------------------------------------------------ conv accumulators
  * src/convolutional_layer.c:699-723 for one image, groups == 1. */
 void orc_conv_acc(const uint8_t *x, int c, int h, int w, const uint8_t *wq, const uint8_t *zp_w, int n, int ksize,
@@ -96,25 +109,31 @@ void orc_conv_acc(const uint8_t *x, int c, int h, int w, const uint8_t *wq, cons
                 }
         }
     } else {
-        int64_t *row = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)N);
-        int64_t *rs1 = row + N;
-        for (int oc = 0; oc < n; ++oc) {
-            memset(row, 0, sizeof(int64_t) * 2 * (size_t)N);
-            int zw = zp_w[oc];
-            for (int k = 0; k < K; ++k) {
-                int wv = wq[(size_t)oc * K + k];
-                const uint8_t *bk = b + (size_t)k * N;
+        /* exact integers: output channels are independent -> OpenMP over oc (test speed only; the bit-faithful
+         * ref-f32 branch above stays sequential like the Makefile-default reference) */
+#pragma omp parallel
+        {
+            int64_t *row = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)N);
+            int64_t *rs1 = row + N;
+#pragma omp for schedule(dynamic, 1)
+            for (int oc = 0; oc < n; ++oc) {
+                memset(row, 0, sizeof(int64_t) * 2 * (size_t)N);
+                int zw = zp_w[oc];
+                for (int k = 0; k < K; ++k) {
+                    int wv = wq[(size_t)oc * K + k];
+                    const uint8_t *bk = b + (size_t)k * N;
+                    for (int j = 0; j < N; ++j) {
+                        row[j] += (int64_t)(wv - zw) * bk[j];
+                        rs1[j] += (int64_t)wv * bk[j];
+                    }
+                }
                 for (int j = 0; j < N; ++j) {
-                    row[j] += (int64_t)(wv - zw) * bk[j];
-                    rs1[j] += (int64_t)wv * bk[j];
+                    acc[(size_t)oc * N + j] = (int32_t)row[j];
+                    if (s1) s1[(size_t)oc * N + j] = rs1[j];
                 }
             }
-            for (int j = 0; j < N; ++j) {
-                acc[(size_t)oc * N + j] = (int32_t)row[j];
-                if (s1) s1[(size_t)oc * N + j] = rs1[j];
-            }
+            free(row);
         }
-        free(row);
     }
     free(col);
 }
@@ -157,6 +176,90 @@ void orc_requant(const int32_t *acc, int n, int spatial, const int32_t *biases_i
             }
             out_u8[idx] = (uint8_t)v; /* modular */
         }
+    }
+}
+
+/* ------------------------------------------------------ MKL-path epilogue: src/convolutional_layer.c:572-596
+ * PARITY STATUS OF THIS FUNCTION: UNPINNED.  forward_convolutional_layer_quant_inputi_outputi_mkl cannot be built in this
+ * image (needs mkl.h / cblas_gemm_s16s16s32; stand-in headers are not allowed), so no output of it exists to check against.
+ * What IS pinned: its inputs M0_lut0 / M0_right_shift_lut0 are computed by the default build too (src/blas.c:318-323) and
+ * are committed in tests/golden/yolov3_tiny_leaky.json (1717986944, 3 == the float 0.1f).  The restatement follows the
+ * source line by line:
+ *   :578-579  same two double multiplies / truncations as the default path
+ *   :583      LEAKY: q <= 0 ? round(q * 2^-31 * M0_lut0 * 2^-shift_lut0) + zp : q + zp      (evaluated left to right in double)
+ *   :586      LINEAR: q + zp      :589  RELU6: q <= 0 ? zp : q + zp      :591  default (RELU included): q unchanged, NO zero point
+ *   :594      clamp(q, 0, 255) and only then the uint8 store. */
+void orc_requant_mkl(const int32_t *acc, int n, int spatial, const int32_t *biases_int32, const double *M_value,
+                     const double *shift_value, uint8_t zp_act, int activation, int32_t M0_lut0, int shift_lut0,
+                     uint8_t *out_u8)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < spatial; ++j) {
+            size_t idx = (size_t)i * spatial + j;
+            int32_t q = acc[idx];
+            int64_t t = (int64_t)((double)(q + biases_int32[i]) * M_value[i]);
+            q = (int32_t)((double)t * shift_value[i]);
+            switch (activation) {
+            case ORC_LEAKY: {
+                double d = q <= 0 ? (round((double)q * pow(2, -31) * (double)M0_lut0 * pow(2, -shift_lut0)) + (double)zp_act)
+                                  : (double)(q + (int)zp_act);
+                q = (int32_t)d;
+                break;
+            }
+            case ORC_LINEAR: q = q + (int)zp_act; break;
+            case ORC_RELU6: q = q <= 0 ? (int)zp_act : q + (int)zp_act; break;
+            default: break;
+            }
+            out_u8[idx] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+        }
+}
+
+/* Exhaustive comparison of the two LEAKY formulas after the clamp, over every requantised value q in [lo, hi]:
+ *   default path (:737) + clamp  = what MI355_STORE_SATURATE / ORC_STORE_SATURATE computes
+ *   MKL path (:583) + clamp (:594)
+ * Returns the number of q for which the stored bytes differ for ANY zero point 0..255 (the byte is
+ * clamp(r(q) + zp) with r the rounded negative branch, so the two agree for every zp iff r agrees wherever
+ * r + 255 >= 0 and both are < -255 otherwise). */
+long orc_mkl_leaky_mismatches(int64_t lo, int64_t hi, int32_t M0_lut0, int shift_lut0)
+{
+    long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (int64_t qq = lo; qq <= hi; ++qq) {
+        const int32_t q = (int32_t)qq;
+        const double a = q < 0 ? round((double)q * 0.1) : (double)q;                                                  /* default */
+        const double b = q <= 0 ? round((double)q * pow(2, -31) * (double)M0_lut0 * pow(2, -shift_lut0)) : (double)q; /* MKL */
+        if (a == b) continue;
+        if (a < -255.0 && b < -255.0) continue; /* both clamp to 0 for every zero point */
+        ++bad;
+    }
+    return bad;
+}
+
+/* -------------------------------------------------------------- quantized residual add ([shortcut] quantized=1)
+ * BUILDER-SPECIFIED, parity unpinned: the reference's shortcut is float only (forward_shortcut_layer,
+ * src/shortcut_layer.c:62-75: copy_cpu(input) then shortcut_cpu, src/blas.c:490-514: out += add; activation).  The
+ * integer form quantises that sum of two differently-scaled uint8 tensors:
+ *     K  = round((float)(s_in / s_out) * 2^16), 1 <= K < 2^21       (float division as in src/blas.c:313)
+ *     q  = zp_out + ((Ka*(a - zp_a) + Kb*(b - zp_b) + 2^15) >> 16)   (arithmetic shift == floor: round half up)
+ *     y  = clamp(q, 0, 255)
+ * This function is the normative statement of the op; the HIP kernel (glue.hip: shortcut_u8_kernel) is tested against it. */
+int orc_shortcut_multiplier(float s_in, float s_out, int32_t *K)
+{
+    if (!(s_in > 0.0f) || !(s_out > 0.0f)) return -1;
+    const float ratio = s_in / s_out;
+    const double k = round((double)ratio * 65536.0);
+    if (!(k >= 1.0) || !(k < 2097152.0)) return -1;
+    *K = (int32_t)k;
+    return 0;
+}
+
+void orc_shortcut_u8(const uint8_t *a, const uint8_t *b, long count, int32_t Ka, int32_t Kb, uint8_t zp_a, uint8_t zp_b,
+                     uint8_t zp_out, uint8_t *out)
+{
+    for (long i = 0; i < count; ++i) {
+        const int64_t t = (int64_t)Ka * ((int)a[i] - (int)zp_a) + (int64_t)Kb * ((int)b[i] - (int)zp_b) + 32768;
+        int64_t q = (int64_t)zp_out + (t >> 16); /* arithmetic shift (gcc: sign-propagating) */
+        out[i] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
     }
 }
 

@@ -37,6 +37,11 @@ def lib():
         L.orc_conv_acc.argtypes = [vp, ci, ci, ci, vp, vp, ci, ci, ci, ci, u8, ci, vp, vp]
         L.orc_requant.argtypes = [vp, ci, ci, vp, vp, vp, u8, ci, ci, vp]
         L.orc_dequant.argtypes = [vp, ci, u8, cf, vp]
+        L.orc_requant_mkl.argtypes = [vp, ci, ci, vp, vp, vp, u8, ci, C.c_int32, ci, vp]
+        L.orc_mkl_leaky_mismatches.restype = C.c_long
+        L.orc_mkl_leaky_mismatches.argtypes = [C.c_int64, C.c_int64, C.c_int32, ci]
+        L.orc_shortcut_multiplier.argtypes = [cf, cf, vp]
+        L.orc_shortcut_u8.argtypes = [vp, vp, C.c_long, C.c_int32, C.c_int32, u8, u8, u8, vp]
         L.orc_maxpool_u8.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp]
         L.orc_upsample_u8.argtypes = [vp, ci, ci, ci, ci, vp]
         L.orc_quant_multiplier.argtypes = [cf, vp, vp]
@@ -96,6 +101,32 @@ def requant(acc, biases_int32, M_value, shift_value, zp_act, activation, store=S
     b = np.ascontiguousarray(biases_int32, np.int32)
     mv = np.ascontiguousarray(M_value, np.float64); sv = np.ascontiguousarray(shift_value, np.float64)
     lib().orc_requant(_p(acc), n, spatial, _p(b), _p(mv), _p(sv), zp_act, activation, store, _p(out))
+    return out
+
+
+def requant_mkl(acc, biases_int32, M_value, shift_value, zp_act, activation, M0_lut0, shift_lut0):
+    """The MKL flavour's epilogue (src/convolutional_layer.c:572-596) -- unpinned restatement."""
+    n, spatial = acc.shape
+    out = np.zeros((n, spatial), np.uint8)
+    acc = np.ascontiguousarray(acc, np.int32)
+    b = np.ascontiguousarray(biases_int32, np.int32)
+    mv = np.ascontiguousarray(M_value, np.float64); sv = np.ascontiguousarray(shift_value, np.float64)
+    lib().orc_requant_mkl(_p(acc), n, spatial, _p(b), _p(mv), _p(sv), zp_act, activation, M0_lut0, shift_lut0, _p(out))
+    return out
+
+
+def shortcut_multiplier(s_in, s_out):
+    k = C.c_int32()
+    rc = lib().orc_shortcut_multiplier(float(s_in), float(s_out), C.byref(k))
+    assert rc == 0, "shortcut multiplier outside [2^-16, 32)"
+    return k.value
+
+
+def shortcut_u8(a, b, Ka, Kb, zp_a, zp_b, zp_out):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    assert a.shape == b.shape
+    out = np.empty(a.shape, np.uint8)
+    lib().orc_shortcut_u8(_p(a), _p(b), a.size, Ka, Kb, zp_a, zp_b, zp_out, _p(out))
     return out
 
 
@@ -200,7 +231,7 @@ def read_weights(path, layers):
             d["s_w"] = take("<f4", L.n); d["zp_w"] = take("u1", L.n)
             d["wq"] = take("u1", L.n * K).reshape(L.n, K)
             off += 4 * L.n * K  # float weights: unused by the integer path
-        elif L.type == "maxpool" or (L.type == "upsample" and L.quantized) or \
+        elif L.type in ("maxpool", "shortcut") or (L.type == "upsample" and L.quantized) or \
                 (L.type == "route" and L.quantized and len(L.inputs) > 1):
             d["s_act"] = take("<f4", 1)[0]; d["zp_act"] = int(take("u1", 1)[0])
         out.append(d)
@@ -272,6 +303,12 @@ class OracleNet:
                 o["u8"] = upsample_u8(cur, L.stride)
             elif L.type == "route":
                 o["u8"] = np.concatenate([outs[j]["u8"] for j in L.inputs], axis=0)
+                if L.quant_stop:  # src/route_layer.c:121-129: every input with its own scale / zero point
+                    o["f32"] = np.concatenate([dequant(outs[j]["u8"], self.act[j][1], self.act[j][0]) for j in L.inputs], axis=0)
+            elif L.type == "shortcut":  # builder-specified quantized residual add (orc_shortcut_u8)
+                ja, jb = i - 1, L.inputs[1]
+                Ka = shortcut_multiplier(self.act[ja][0], self.act[i][0]); Kb = shortcut_multiplier(self.act[jb][0], self.act[i][0])
+                o["u8"] = shortcut_u8(cur, outs[jb]["u8"], Ka, Kb, self.act[ja][1], self.act[jb][1], self.act[i][1])
             elif L.type == "yolo":
                 classes = int(self.sections[i].get("classes", 20))
                 f = np.ascontiguousarray(cur_f, np.float32)
@@ -279,6 +316,8 @@ class OracleNet:
                 lib().orc_yolo_forward(_p(f), L.n, classes, L.h, L.w, _p(out))
                 o["f32"] = out
                 o["u8"] = cur  # yolo is not a quantized layer; uint8 hand-off is unchanged (network.c:248)
+            if L.quant_stop and L.type in ("maxpool", "upsample", "shortcut"):  # src/maxpool_layer.c:163-171, upsample :104-112
+                o["f32"] = dequant(o["u8"], self.act[i][1], self.act[i][0])
             outs.append(o)
             if L.type != "yolo":
                 cur = o["u8"]

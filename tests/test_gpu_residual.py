@@ -1,0 +1,259 @@
+"""GPU suite, part 3 (`-m gpu`): the quantized residual add and BASELINE config[4] as a real net (full YOLOv3: 75
+convolutions, 23 `[shortcut] quantized=1`, routes, upsamples, 3 heads), the quant_stop tails of the glue layers, and the
+packed-weights import paths (in-memory, RCCL-style device buffer, on-disk file).
+
+Parity status of the shortcut: the reference has no integer shortcut (src/shortcut_layer.c:62-75 is float only), so the
+op is builder-specified; oracle.c:orc_shortcut_u8 is its normative statement and what the kernel is compared with."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from yolo_quantization_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+C = binding.C
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    binding.init(0)
+
+
+@pytest.mark.parametrize("B,Cc,H,W", [(1, 32, 16, 16), (3, 64, 7, 5), (2, 48, 9, 11), (1, 256, 76, 76), (2, 1024, 19, 19)])
+def test_shortcut_kernel_vs_oracle(B, Cc, H, W):
+    rng = np.random.default_rng(B + Cc + H)
+    a = rng.integers(0, 256, (B, Cc, H, W), dtype=np.uint8)
+    b = rng.integers(0, 256, (B, Cc, H, W), dtype=np.uint8)
+    for (sa, za, sb, zb, so, zo) in ((6.6 / 255, 23, 6.6 / 255, 23, 9.0 / 255, 23), (6 / 255, 0, 16 / 255, 128, 7.5 / 255, 60),
+                                     (0.2, 255, 0.3, 0, 0.0097, 10)):
+        Ka = oracle.shortcut_multiplier(np.float32(sa), np.float32(so)); Kb = oracle.shortcut_multiplier(np.float32(sb), np.float32(so))
+        ta = binding.DevTensor.from_nchw(a, za); tb = binding.DevTensor.from_nchw(b, zb)
+        ty = binding.DevTensor(B, H, W, Cc, zo)
+        binding.check(binding.shim().mi355_shortcut_forward(ta.ref(), tb.ref(), ty.ref(), Ka, Kb, za, zb, zo, None), "shortcut")
+        want = oracle.shortcut_u8(a, b, Ka, Kb, za, zb, zo)
+        got = ty.to_nchw()
+        assert np.array_equal(got, want)
+        assert (want == 0).any() or (want == 255).any() or so > 0.03
+    # shape mismatch and out-of-range multipliers are refused, not clamped
+    t2 = binding.DevTensor(B, H, W + 1, Cc, 0)
+    assert binding.shim().mi355_shortcut_forward(ta.ref(), tb.ref(), t2.ref(), Ka, Kb, 0, 0, 0, None) == -22
+    assert binding.shim().mi355_shortcut_forward(ta.ref(), tb.ref(), ty.ref(), 0, Kb, 0, 0, 0, None) == -22
+    assert binding.shim().mi355_shortcut_forward(ta.ref(), tb.ref(), ty.ref(), 1 << 21, Kb, 0, 0, 0, None) == -22
+
+
+def test_dequant_entry_point():
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, (2, 48, 5, 7), dtype=np.uint8)
+    t = binding.DevTensor.from_nchw(x, 9)
+    out = binding.DevBuf(2 * 64 * 35 * 4)
+    binding.check(binding.shim().mi355_memset(out.ptr, 0, out.nbytes, None), "memset")
+    binding.check(binding.shim().mi355_dequant_forward(t.ref(), 16, 32, 77, 0.125, out.ptr, 64, 8, None), "dequant")
+    got = out.to_numpy(np.float32, 2 * 64 * 35).reshape(2, 64, 35)
+    want = np.zeros((2, 64, 35), np.float32)
+    want[:, 8:40] = oracle.dequant(x[:, 16:48].reshape(2, 32, 35), 77, np.float32(0.125))
+    assert np.array_equal(got, want)
+    assert binding.shim().mi355_dequant_forward(t.ref(), 40, 16, 0, 1.0, out.ptr, 64, 0, None) == -22
+
+
+def _run(cfg, wts, x, dump, **kw):
+    B = x.shape[0]
+    net = binding.Net(cfg, wts, batch=B, dump_int32=dump, **kw)
+    xq = net.prepare_from_float(synth.image_u8_to_float(x))
+    assert np.array_equal(xq, x.ravel())
+    net.forward()
+    net.sync()
+    outs = [net.pull(i) for i in range(net.n)]
+    info = [dict(inf, fused=net.is_fused(i), kernel=net.conv_kernel(i)) for i, inf in enumerate(net.info)]
+    net.close()
+    return outs, info
+
+
+def _compare_with_oracle(cfg, wts, x, outs, info, dump, store=oracle.STORE_WRAP):
+    onet = oracle.OracleNet(cfg, wts)
+    onet.prepare(np.float32(1.0 / 255.0), 0)
+    for b in range(x.shape[0]):
+        want = onet.forward(x[b], store=store)
+        for i, inf in enumerate(info):
+            per = inf["outputs"]
+            sl = slice(b * per, (b + 1) * per)
+            if inf["type"] != binding.T_YOLO and not inf["fused"]:
+                assert np.array_equal(outs[i]["u8"][sl], want[i]["u8"].ravel()), f"image {b} layer {i} u8"
+            if inf["type"] == binding.T_CONV and dump:
+                assert np.array_equal(outs[i]["int32"][sl], want[i]["int32"].ravel()), f"image {b} layer {i} int32"
+            if inf["quant_stop"]:
+                assert np.array_equal(outs[i]["f32"][sl], want[i]["f32"].ravel()), f"image {b} layer {i} f32 (quant_stop tail)"
+            if inf["type"] == binding.T_YOLO:
+                np.testing.assert_allclose(outs[i]["f32"][sl], want[i]["f32"].ravel(), rtol=0, atol=2e-7)
+    return onet
+
+
+@pytest.mark.parametrize("dump", [True, False], ids=["dump", "production"])
+@pytest.mark.parametrize("seed,gain", [(1, 1.0), (2, 6.0)])
+def test_res_unit_net_vs_oracle(cfg_dir, tmp_path, dump, seed, gain):
+    """cfg/res_unit.cfg: two residual blocks (equal and different operand scales), a route that concatenates a shortcut's
+    output, quant_stop tails on a maxpool and on a two-input route (each input dequantised with its own scale / zero
+    point, ref: src/route_layer.c:121-129), batch 3, through the plain-C host; gain 6: saturating sums and wrapping convs."""
+    cfg = os.path.join(cfg_dir, "res_unit.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=seed, act_gain=gain)
+    x = synth.synth_image_u8(3, 16, 16, seed=40 + seed, batch=3)
+    outs, info = _run(cfg, wts, x, dump)
+    _compare_with_oracle(cfg, wts, x, outs, info, dump)
+    assert sum(inf["type"] == binding.T_SHORTCUT for inf in info) == 2
+    assert info[11]["quant_stop"] and info[12]["quant_stop"] and "f32" in outs[11] and "f32" in outs[12]
+
+
+def _small_yolov3_cfg(cfg_dir, tmp_path, size, classes_line=None):
+    txt = open(os.path.join(cfg_dir, "yolov3_quant.cfg")).read()
+    txt = txt.replace("width=608", f"width={size}").replace("height=608", f"height={size}")
+    p = str(tmp_path / f"yolov3_{size}.cfg")
+    open(p, "w").write(txt)
+    return p
+
+
+@pytest.mark.parametrize("dump", [True, False], ids=["dump", "production"])
+def test_yolov3_full_topology_small_input_vs_oracle(cfg_dir, tmp_path, dump):
+    """The real 107-layer YOLOv3 topology (75 convs, 23 quantized shortcuts, 4 routes, 2 upsamples, 3 heads) at 96x96,
+    batch 2: EVERY tensor of every layer against the oracle (dump mode adds the int32 accumulators of all 75 convs)."""
+    cfg = _small_yolov3_cfg(cfg_dir, tmp_path, 96)
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=11)
+    x = synth.synth_image_u8(3, 96, 96, seed=12, batch=2)
+    outs, info = _run(cfg, wts, x, dump)
+    _compare_with_oracle(cfg, wts, x, outs, info, dump)
+    assert len(info) == 107 and sum(inf["type"] == binding.T_CONV for inf in info) == 75
+
+
+def test_yolov3_608_batch32_properties_and_per_shape_oracle(cfg_dir, tmp_path):
+    """BASELINE config[4] at full size: full YOLOv3, 608x608, batch 32 on one MI355X.
+    Size-independent properties: identical images give identical bytes in every batch slot of every layer's tensor
+    (checksum of checksums over the three head tensors + spot layers), image 0 equals the batch-1 run, hipGraph replay
+    equals eager launches.  Then, at batch 1, every DISTINCT conv shape of the net is checked against the oracle on the
+    device's own input to that layer (teacher forcing from the device tensors), and every shortcut likewise."""
+    cfg = os.path.join(cfg_dir, "yolov3_quant.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=21)
+    x1 = synth.synth_image_u8(3, 608, 608, seed=22)
+    B = 32
+    xb = np.broadcast_to(x1[None], (B,) + x1.shape)
+    heads = None
+    for graph in (False, True):
+        net = binding.Net(cfg, wts, batch=B, use_graph=graph)
+        net.prepare_fixed(1.0 / 255.0, 0)
+        net.push_input(np.ascontiguousarray(xb))
+        net.forward()
+        if graph:
+            net.forward()
+        net.sync()
+        cur = {}
+        for i, inf in enumerate(net.info):
+            if inf["type"] == binding.T_YOLO or (inf["type"] == binding.T_CONV and inf["quant_stop"]) or i in (4, 36, 61, 74, 86, 98):
+                if net.is_fused(i):
+                    continue
+                o = net.pull(i)
+                key = "f32" if inf["type"] == binding.T_YOLO else "u8"
+                t = o[key].reshape(B, -1)
+                assert all(np.array_equal(t[b], t[0]) for b in range(1, B)), f"layer {i}: batch slots differ (graph={graph})"
+                cur[i] = t[0].copy()
+        net.close()
+        if heads is None:
+            heads = cur
+        else:
+            assert heads.keys() == cur.keys() and all(np.array_equal(heads[k], cur[k]) for k in cur), "hipGraph replay != eager"
+    # batch 1, every tensor kept (dump mode): teacher-forced oracle check per distinct conv shape + every shortcut
+    net = binding.Net(cfg, wts, batch=1, dump_int32=True)
+    net.prepare_fixed(1.0 / 255.0, 0)
+    net.push_input(x1)
+    net.forward()
+    net.sync()
+    onet = oracle.OracleNet(cfg, wts)
+    onet.prepare(np.float32(1.0 / 255.0), 0)
+    outs = {}
+
+    def out(i):
+        if i not in outs:
+            outs[i] = net.pull(i)
+        return outs[i]
+    for k in heads:   # image 0 of the batch-32 production run == the batch-1 dump run (different kernels / fusions)
+        key = "f32" if net.info[k]["type"] == binding.T_YOLO else "u8"
+        if key == "f32":
+            np.testing.assert_allclose(out(k)[key], heads[k], rtol=0, atol=0)
+        else:
+            assert np.array_equal(out(k)[key], heads[k]), f"layer {k}: batch-32 slot != batch-1 run"
+    seen = set()
+    nshapes = nshort = 0
+    for i, L in enumerate(onet.layers):
+        if L.type == "conv":
+            shape = (L.c, L.n, L.h, L.w, L.size, L.stride, L.activation)
+            if shape in seen:
+                continue
+            seen.add(shape)
+            xin = x1 if i == 0 else out(i - 1)["u8"].reshape(L.c, L.h, L.w)
+            d, p = onet.w[i], onet.p[i]
+            acc = oracle.conv_acc(xin, d["wq"], d["zp_w"], L.size, L.stride, L.pad, p["zp_in"], oracle.ACC_EXACT)
+            u8 = oracle.requant(acc, p["biases_int32"], p["M_value"], p["shift_value"], d["zp_act"], oracle.ACT[L.activation])
+            assert np.array_equal(out(i)["int32"], acc.ravel()), f"conv {i} {shape}: int32"
+            assert np.array_equal(out(i)["u8"], u8.ravel()), f"conv {i} {shape}: u8"
+            nshapes += 1
+        elif L.type == "shortcut":
+            ja, jb = i - 1, L.inputs[1]
+            Ka = oracle.shortcut_multiplier(onet.act[ja][0], onet.act[i][0]); Kb = oracle.shortcut_multiplier(onet.act[jb][0], onet.act[i][0])
+            assert (Ka, Kb) == net.shortcut_multipliers(i)
+            want = oracle.shortcut_u8(out(ja)["u8"], out(jb)["u8"], Ka, Kb, onet.act[ja][1], onet.act[jb][1], onet.act[i][1])
+            assert np.array_equal(out(i)["u8"], want), f"shortcut {i}"
+            nshort += 1
+            outs.pop(ja, None)
+    net.close()
+    assert nshapes >= 25 and nshort == 23, (nshapes, nshort)
+
+
+def test_packed_import_paths_equal_weights_file_net(cfg_dir, tmp_path):
+    """SURVEY 8(f) row 3 / the rank != 0 start-up path: a network built from (a) network_import_packed (host bytes), (b)
+    network_import_packed_gpu (the bytes already in HBM, what an RCCL broadcast leaves behind) and (c) the on-disk packed
+    file gives the same bytes on every layer as the network that read the .weights file; and an imported network can
+    re-derive layer 0 when an image's dynamic input scale differs (it carries layer 0's raw record)."""
+    for name, size in (("tiny_unit", 12), ("res_unit", 16)):
+        cfg = os.path.join(cfg_dir, f"{name}.cfg")
+        wts = str(tmp_path / f"{name}.weights")
+        synth.synth_weights(cfg, wts, seed=5)
+        x = synth.synth_image_u8(3, size, size, seed=77, batch=4)
+        ref = binding.Net(cfg, wts, batch=4)
+        ref.prepare_fixed(1.0 / 255.0, 0)
+        ref.push_input(x); ref.forward(); ref.sync()
+        want = [ref.pull(i) for i in range(ref.n)]
+        packed = ref.export_packed()
+        pfile = str(tmp_path / f"{name}.packed")
+        ref.save_packed(pfile)
+        for how in ("host", "gpu", "file"):
+            net = binding.Net(cfg, None, batch=4)
+            if how == "host":
+                net.import_packed(packed)
+            elif how == "gpu":
+                dev = binding.DevBuf.from_numpy(packed)
+                net.import_packed_gpu(dev.ptr, packed.nbytes)
+            else:
+                net.load_packed(pfile)
+            net.push_input(x); net.forward(); net.sync()
+            for i in range(net.n):
+                got = net.pull(i)
+                for k in want[i]:
+                    if k != "int32":
+                        assert np.array_equal(got[k], want[i][k]), (name, how, i, k)
+            if how == "gpu":   # dynamic input scale on an imported net: float image with another range -> layer 0 re-derived
+                xf = (synth.image_u8_to_float(x) * np.float32(0.5)).astype(np.float32)
+                xq = net.prepare_from_float_gpu(xf)
+                net.forward(); net.sync()
+                full = binding.Net(cfg, wts, batch=4)
+                xq2 = full.prepare_from_float(xf)
+                assert np.array_equal(xq, xq2)
+                full.forward(); full.sync()
+                for i in range(net.n):
+                    a, b = net.pull(i), full.pull(i)
+                    for k in b:
+                        if k != "int32":
+                            assert np.array_equal(a[k], b[k]), (name, "re-prep", i, k)
+                full.close()
+            net.close()
+        ref.close()

@@ -148,3 +148,121 @@ def test_pack_blob_reconstructs_exact_accumulators(n, c, k):
     got = mf + dzp[:n].astype(np.int64) * sx + cw[:n].astype(np.int64)
     assert np.array_equal(got, want)
     assert np.abs(got).max() < 2 ** 31
+
+
+# ------------------------------------------------------------------------------------------ round 2 additions
+def test_saturate_mode_equals_mkl_epilogue_for_every_requantised_value(golden_dir):
+    """`saturate` is builder-defined: the default path's formulas with the clamp moved before the uint8 store.  The MKL
+    flavour (src/convolutional_layer.c:572-596) cannot be built here, but its epilogue is plain C and restated in
+    orc_requant_mkl; its LEAKY multiplier (M0_lut0, shift) is pinned from the default build of the reference.  Exhaustive
+    over all 2^31 + 1 non-positive int32 q: default-LEAKY + clamp and MKL-LEAKY + clamp store the same byte for every zero
+    point, so `saturate` == the MKL epilogue for LEAKY (LINEAR / RELU6 are the same expressions; RELU differs: :591)."""
+    g = json.load(open(os.path.join(golden_dir, "yolov3_tiny_leaky.json")))
+    luts = {(e["M0_lut0"], e["M0_right_shift_lut0"]) for e in g["layers"] if e["type"] == "conv" and e["M0_lut0"]}
+    assert luts == {(1717986944, 3)}          # == (float)0.1 exactly: 1717986944 * 2^-31 * 2^-3
+    assert 1717986944 * 2.0 ** -34 == float(np.float32(0.1))
+    L = oracle.lib()
+    assert L.orc_mkl_leaky_mismatches(-2 ** 31, 0, 1717986944, 3) == 0
+    assert L.orc_mkl_leaky_mismatches(1, 2 ** 20, 1717986944, 3) == 0
+    # and through the two epilogue functions on random accumulators, every activation
+    rng = np.random.default_rng(5)
+    acc = rng.integers(-3_000_000, 3_000_000, (8, 4096)).astype(np.int32)
+    acc[0, :64] = np.arange(-32, 32)
+    bias = rng.integers(-1000, 1000, 8).astype(np.int32)
+    mv = rng.uniform(0.5, 1.0, 8); sv = 2.0 ** -rng.integers(6, 14, 8).astype(np.float64)
+    for act in (oracle.LEAKY, oracle.LINEAR, oracle.RELU6):
+        a = oracle.requant(acc, bias, mv, sv, 23, act, oracle.STORE_SATURATE)
+        b = oracle.requant_mkl(acc, bias, mv, sv, 23, act, 1717986944, 3)
+        assert np.array_equal(a, b), act
+    a = oracle.requant(acc, bias, mv, sv, 23, oracle.RELU, oracle.STORE_SATURATE)
+    b = oracle.requant_mkl(acc, bias, mv, sv, 23, oracle.RELU, 1717986944, 3)
+    assert not np.array_equal(a, b)           # documented difference: the MKL flavour adds no zero point for RELU
+
+
+def test_shortcut_spec_properties():
+    """The builder-specified quantized residual add (oracle.c:orc_shortcut_u8 is the normative statement): agrees with the
+    real-valued sum to half an output step, saturates, is symmetric in its operands, and K follows the float ratio."""
+    rng = np.random.default_rng(9)
+    sa, sb, so = np.float32(6.6 / 255), np.float32(6.0 / 255), np.float32(9.5 / 255)
+    za, zb, zo = 23, 0, 10
+    Ka, Kb = oracle.shortcut_multiplier(sa, so), oracle.shortcut_multiplier(sb, so)
+    assert Ka == int(np.floor(np.float64(np.float32(sa / so)) * 65536 + 0.5))
+    a = rng.integers(0, 256, 100_000, dtype=np.uint8); b = rng.integers(0, 256, 100_000, dtype=np.uint8)
+    y = oracle.shortcut_u8(a, b, Ka, Kb, za, zb, zo)
+    real = (np.float64(sa) * (a.astype(np.int64) - za) + np.float64(sb) * (b.astype(np.int64) - zb)) / np.float64(so) + zo
+    ideal = np.clip(np.floor(real + 0.5), 0, 255)
+    assert np.abs(y.astype(np.int64) - ideal).max() <= 1 and (y != ideal).mean() < 0.02   # 16.16 multipliers: rare off-by-one at ties
+    assert (y == 255).any() and (y == 0).any()
+    assert np.array_equal(y, oracle.shortcut_u8(b, a, Kb, Ka, zb, za, zo))
+    # exact integer restatement in numpy
+    t = Ka * (a.astype(np.int64) - za) + Kb * (b.astype(np.int64) - zb) + 32768
+    assert np.array_equal(y, np.clip(zo + (t >> 16), 0, 255).astype(np.uint8))
+    K = C.c_int32()
+    S = binding.shim()
+    S.mi355_shortcut_multiplier.argtypes = [C.c_float, C.c_float, C.c_void_p]
+    for s_in, s_out in ((sa, so), (sb, so), (so, sa), (np.float32(1.0), np.float32(0.05))):
+        assert S.mi355_shortcut_multiplier(float(s_in), float(s_out), C.byref(K)) == 0
+        assert K.value == oracle.shortcut_multiplier(s_in, s_out)
+    assert S.mi355_shortcut_multiplier(1.0, 0.01, C.byref(K)) < 0       # ratio >= 32
+    assert S.mi355_shortcut_multiplier(0.0, 0.01, C.byref(K)) < 0
+
+
+@pytest.mark.parametrize("name,nconv,nshort", [("yolov3_quant", 75, 23), ("res_unit", 8, 2)])
+def test_host_parses_residual_nets(cfg_dir, tmp_path, name, nconv, nshort):
+    """cfg parser + weights reader + host prep of the nets with `[shortcut] quantized=1` (BASELINE config[4] is the real
+    107-layer YOLOv3 topology): shapes equal the independent shape inference of synth.py, the shortcut multipliers equal
+    the oracle's, a packed export / import round-trips (blobs + layer-0 record + shortcut records)."""
+    cfg = os.path.join(cfg_dir, f"{name}.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=3)
+    _, shapes = synth.layer_shapes(synth.read_cfg(cfg))
+    net = binding.Net(cfg, wts)
+    net.prepare_host_only(1.0 / 255.0, 0)
+    assert net.n == len(shapes)
+    assert sum(i["type"] == binding.T_CONV for i in net.info) == nconv
+    assert sum(i["type"] == binding.T_SHORTCUT for i in net.info) == nshort
+    onet = oracle.OracleNet(cfg, wts)
+    onet.prepare(np.float32(1.0 / 255.0), 0)
+    for i, (L, inf) in enumerate(zip(shapes, net.info)):
+        assert (inf["out_c"], inf["out_h"], inf["out_w"]) == (L.out_c, L.out_h, L.out_w), i
+        if L.type == "shortcut":
+            ka, kb = net.shortcut_multipliers(i)
+            assert ka == oracle.shortcut_multiplier(onet.act[i - 1][0], onet.act[i][0])
+            assert kb == oracle.shortcut_multiplier(onet.act[L.inputs[1]][0], onet.act[i][0])
+        if L.type == "conv":
+            assert np.array_equal(net.prep(i)["biases_int32"], onet.p[i]["biases_int32"]), i
+    packed = net.export_packed()
+    f = str(tmp_path / "net.packed")
+    net.save_packed(f)
+    assert open(f, "rb").read() == packed.tobytes()
+    net2 = binding.Net(cfg, None)
+    net2.import_packed_host(packed)
+    assert np.array_equal(net2.export_packed(), packed)
+    for i, L in enumerate(shapes):
+        if L.type == "shortcut":
+            assert net2.shortcut_multipliers(i) == net.shortcut_multipliers(i)
+    net.close(); net2.close()
+
+
+def test_oracle_restatement_is_clean_under_asan_ubsan(tmp_path, cfg_dir):
+    """SURVEY.md 5 (race detection / sanitizers row): the reference RELIES on undefined behaviour (out-of-range
+    double -> uint8 conversions, src/convolutional_layer.c:737, src/maxpool_layer.c:143); the restatement must not.
+    oracle.c is compiled with -fsanitize=address,undefined (-fno-sanitize-recover) together with a small driver that runs
+    every entry point on wrap-on-store data, and must finish without a sanitizer report."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    drv = os.path.join(ROOT, "tests", "sanitize_driver.c")
+    exe = str(tmp_path / "orc_san")
+    cmd = ["gcc", "-O1", "-g", "-std=c11", "-fno-fast-math", "-ffp-contract=off", "-fopenmp", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=all", "-I" + os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "oracle.c"), drv,
+           "-o", exe, "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and ("asan" in r.stderr.lower() or "cannot find" in r.stderr.lower()):
+        pytest.skip("sanitizer runtime not installed: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1", OMP_NUM_THREADS="2")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "sanitize_driver: OK" in r.stdout

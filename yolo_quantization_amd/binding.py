@@ -85,6 +85,10 @@ def shim():
         L.mi355_upsample_forward.argtypes = [C.POINTER(Tensor), C.POINTER(Tensor), ci, vp]
         L.mi355_route_forward.argtypes = [C.POINTER(C.POINTER(Tensor)), ci, C.POINTER(Tensor), vp]
         L.mi355_yolo_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+        L.mi355_dequant_forward.argtypes = [C.POINTER(Tensor), ci, ci, C.c_uint8, C.c_float, vp, ci, ci, vp]
+        L.mi355_shortcut_multiplier.argtypes = [C.c_float, C.c_float, vp]
+        L.mi355_shortcut_forward.argtypes = [C.POINTER(Tensor), C.POINTER(Tensor), C.POINTER(Tensor), C.c_int32, C.c_int32,
+                                             C.c_uint8, C.c_uint8, C.c_uint8, vp]
         L.mi355_image_minmax.argtypes = [vp, C.c_long, vp, vp]
         L.mi355_letterbox_forward.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp]
         L.mi355_image_quantize.argtypes = [vp, C.c_long, C.c_float, ci, vp, vp]
@@ -263,6 +267,9 @@ def host():
             getattr(L, n).argtypes = [vp, ci]
         L.dnq_layer_prep.argtypes = [vp, ci] + [vp] * 6
         L.dnq_layer_is_fused.argtypes = [vp, ci]
+        L.dnq_layer_shortcut.argtypes = [vp, ci, vp]
+        L.network_save_packed.argtypes = [vp, C.c_char_p]
+        L.network_load_packed.argtypes = [vp, C.c_char_p]
         L.dnq_layer_conv_kernel.argtypes = [vp, ci]
         L.dnq_layer_conv_kernel.restype = ci
         _host = L
@@ -271,7 +278,7 @@ def host():
 
 INFO_KEYS = ["type", "out_c", "out_h", "out_w", "c", "h", "w", "n", "size", "stride", "pad", "activation",
              "batch_normalize", "quantized", "quant_stop", "outputs"]
-T_CONV, T_MAXPOOL, T_ROUTE, T_YOLO, T_UPSAMPLE = 0, 3, 8, 23, 26
+T_CONV, T_MAXPOOL, T_ROUTE, T_SHORTCUT, T_YOLO, T_UPSAMPLE = 0, 3, 8, 13, 23, 26
 
 
 def _as(ptr, n, dt):
@@ -425,6 +432,23 @@ class Net:
         buf = np.zeros(self.packed_size(), np.uint8)
         self.H.network_export_packed(self.h, buf.ctypes.data)
         return buf
+
+    def save_packed(self, path):
+        self.H.network_save_packed(self.h, path.encode())
+
+    def load_packed(self, path):
+        """Packed file -> host blobs -> device (the on-disk twin of import_packed)."""
+        self.H.network_load_packed(self.h, path.encode())
+
+    def shortcut_multipliers(self, i):
+        k = (C.c_int32 * 3)()
+        assert self.H.dnq_layer_shortcut(self.h, i, k) == 0
+        return int(k[0]), int(k[1])
+
+    def shortcut_from(self, i):
+        k = (C.c_int32 * 3)()
+        assert self.H.dnq_layer_shortcut(self.h, i, k) == 0
+        return int(k[2])
 
     def import_packed(self, buf):
         buf = np.ascontiguousarray(buf, np.uint8)

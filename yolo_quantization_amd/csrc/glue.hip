@@ -119,6 +119,70 @@ __global__ __launch_bounds__(256) void phwc_to_nchw_kernel(const LayoutArgs a)
     a.nchw[idx] = a.t[cell * a.cs + c] ^ bias;
 }
 
+// quant_stop tail of the glue layers (ref: src/maxpool_layer.c:163-171, src/upsample_layer.c:104-112, src/route_layer.c:121-129):
+// out[b][c0_out + c][pix] = (int)(u8[b][pix][c0 + c] - zp) * scale for c < nc, reference layout [B][C_out][H*W] float.
+__global__ __launch_bounds__(256) void dequant_cells_kernel(const DequantArgs a)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long hw = (long)a.H * a.W;
+    const long total = (long)a.B * a.nc * hw;
+    if (idx >= total) return;
+    const long pix = idx % hw;
+    const int c = (int)((idx / hw) % a.nc);
+    const int b = (int)(idx / (hw * a.nc));
+    const int y = (int)(pix / a.W), x = (int)(pix % a.W);
+    const long cell = a.lead + ((long)b * (a.H + 1) + (y + 1)) * (a.W + 1) + x;
+    const int u = a.t[cell * a.cs + a.c0 + c] ^ 0x80;
+    a.out[((long)b * a.out_C + a.out_c0 + c) * hw + pix] = (float)(u - a.zp) * a.scale;
+}
+
+// Quantized residual add ([shortcut] quantized=1; builder-specified, DESIGN.md section 7 -- the reference's shortcut is
+// float only, src/shortcut_layer.c:62-75): q = zo + ((Ka*(a - za) + Kb*(b - zb) + 2^15) >> 16), saturated to 0..255.
+// k0 = 2^15 + (zo << 16) - Ka*za - Kb*zb is folded on the host.  One thread per (cell, 16-channel group).
+__global__ __launch_bounds__(256) void shortcut_u8_kernel(const ShortcutArgs s)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)s.B * s.H * s.W * s.groups;
+    if (idx >= total) return;
+    const int g = (int)(idx % s.groups);
+    const long p = idx / s.groups;
+    const int x = (int)(p % s.W);
+    const int y = (int)((p / s.W) % s.H);
+    const int b = (int)(p / ((long)s.W * s.H));
+    const long cell = ((long)b * (s.H + 1) + (y + 1)) * (s.W + 1) + x;
+    const uint4 va = *reinterpret_cast<const uint4 *>(s.a + (cell + s.a_lead) * s.a_cs + g * 16);
+    const uint4 vb = *reinterpret_cast<const uint4 *>(s.b + (cell + s.b_lead) * s.b_cs + g * 16);
+    const uint32_t wa[4] = {va.x ^ 0x80808080u, va.y ^ 0x80808080u, va.z ^ 0x80808080u, va.w ^ 0x80808080u};
+    const uint32_t wb[4] = {vb.x ^ 0x80808080u, vb.y ^ 0x80808080u, vb.z ^ 0x80808080u, vb.w ^ 0x80808080u};
+    uint32_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int av = (int)((wa[d] >> (8 * e)) & 0xFFu), bv = (int)((wb[d] >> (8 * e)) & 0xFFu);
+            int q = (s.ka * av + s.kb * bv + s.k0) >> 16;
+            q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            w |= (uint32_t)q << (8 * e);
+        }
+        o[d] = w ^ 0x80808080u;
+    }
+    *reinterpret_cast<uint4 *>(s.y + (cell + s.y_lead) * s.y_cs + g * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+int dequant_cells_launch(const DequantArgs &a, hipStream_t st)
+{
+    const long total = (long)a.B * a.nc * a.H * a.W;
+    hipLaunchKernelGGL(dequant_cells_kernel, dim3(nblk(total)), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+int shortcut_launch(const ShortcutArgs &a, hipStream_t st)
+{
+    const long total = (long)a.B * a.H * a.W * a.groups;
+    hipLaunchKernelGGL(shortcut_u8_kernel, dim3(nblk(total)), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
 // fill a cs==4 image tensor with (zp,zp,zp,0) cells
 __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *p, uint32_t v, long n)
 {

@@ -78,6 +78,21 @@ struct CopyArgs {
     int B, H, W, OH, OW, cs_in, cs_out, in_lead, out_lead, groups, stride, coff;  // coff: channel offset in y
 };
 
+struct DequantArgs {
+    const uint8_t *t;
+    float *out;
+    int B, H, W, cs, lead, c0, nc, out_C, out_c0, zp;
+    float scale;
+};
+
+struct ShortcutArgs {
+    const uint8_t *a, *b;
+    uint8_t *y;
+    int B, H, W, groups;
+    int a_cs, b_cs, y_cs, a_lead, b_lead, y_lead;
+    int ka, kb, k0;
+};
+
 struct LayoutArgs {
     uint8_t *nchw;
     uint8_t *t;
@@ -105,6 +120,8 @@ int maxpool_launch(const PoolArgs &a, hipStream_t st);
 int copy_cells_launch(const CopyArgs &a, hipStream_t st);
 int nchw_to_phwc_launch(const LayoutArgs &a, hipStream_t st);
 int phwc_to_nchw_launch(const LayoutArgs &a, hipStream_t st);
+int dequant_cells_launch(const DequantArgs &a, hipStream_t st);
+int shortcut_launch(const ShortcutArgs &a, hipStream_t st);
 int fill_u32_launch(uint32_t *p, uint32_t v, long n, hipStream_t st);
 int letterbox_launch(const float *im, int imw, int imh, int c, float *out, int w, int h, hipStream_t st);
 int image_minmax_launch(const float *x, long count, uint32_t *mm, hipStream_t st);

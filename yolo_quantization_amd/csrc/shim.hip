@@ -553,6 +553,39 @@ int mi355_route_forward(const mi355_tensor *const *xs, int n, const mi355_tensor
     return MI355_OK;
 }
 
+int mi355_dequant_forward(const mi355_tensor *x, int c0, int nc, uint8_t zero_point, float scale, float *out_f32, int out_C,
+                          int out_c0, void *stream)
+{
+    if (!x || !x->data || !out_f32 || x->cs % 16) return einval("dequant: null / layout");
+    if (c0 < 0 || nc <= 0 || c0 + nc > x->C || out_c0 < 0 || out_c0 + nc > out_C) return einval("dequant: channel range");
+    DequantArgs a{(const uint8_t *)x->data, out_f32, x->B, x->H, x->W, x->cs, x->lead, c0, nc, out_C, out_c0, (int)zero_point, scale};
+    return dequant_cells_launch(a, (hipStream_t)stream);
+}
+
+int mi355_shortcut_multiplier(float s_in, float s_out, int32_t *K)
+{
+    if (!K || !(s_in > 0.0f) || !(s_out > 0.0f)) return einval("shortcut_multiplier: scales must be positive");
+    const float ratio = s_in / s_out;  // float, like M in the reference's prep (src/blas.c:313)
+    const double k = round((double)ratio * 65536.0);
+    if (!(k >= 1.0) || !(k < 2097152.0)) return einval("shortcut_multiplier: need 2^-16 <= s_in / s_out < 32");
+    *K = (int32_t)k;
+    return MI355_OK;
+}
+
+int mi355_shortcut_forward(const mi355_tensor *a, const mi355_tensor *b, const mi355_tensor *y, int32_t Ka, int32_t Kb,
+                           uint8_t zp_a, uint8_t zp_b, uint8_t zp_out, void *stream)
+{
+    if (!a || !b || !y || !a->data || !b->data || !y->data) return einval("shortcut: null");
+    if (a->cs % 16 || b->cs % 16 || y->cs % 16) return einval("shortcut: layout");
+    if (a->B != y->B || b->B != y->B || a->H != y->H || b->H != y->H || a->W != y->W || b->W != y->W || a->C != y->C || b->C != y->C)
+        return einval("shortcut: both inputs and the output must share batch, map size and channels");
+    if (Ka < 1 || Kb < 1 || Ka >= (1 << 21) || Kb >= (1 << 21)) return einval("shortcut: multipliers must be in [1, 2^21)");
+    ShortcutArgs s{(const uint8_t *)a->data, (const uint8_t *)b->data, (uint8_t *)y->data, y->B, y->H, y->W, (y->C + 15) / 16,
+                   a->cs, b->cs, y->cs, a->lead, b->lead, y->lead, Ka, Kb,
+                   32768 + ((int)zp_out << 16) - Ka * (int)zp_a - Kb * (int)zp_b};
+    return shortcut_launch(s, (hipStream_t)stream);
+}
+
 int mi355_letterbox_forward(const float *im_f32, int imw, int imh, int c, float *out_f32, int w, int h, void *stream)
 {
     if (!im_f32 || !out_f32 || imw < 1 || imh < 1 || c < 1 || w < 2 || h < 2) return einval("letterbox: null / bad size");

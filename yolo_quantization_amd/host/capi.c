@@ -77,3 +77,11 @@ int dnq_layer_is_fused(network *net, int i)
     return (net->layers[i].fuse_next_pool || net->layers[i].fuse_next_upsample) && net->fuse_maxpool && !net->dump_int32 &&
            net->accum_mode == MI355_ACC_EXACT;
 }
+
+/* k[0..2] = Ka, Kb, `from` index of shortcut layer i */
+int dnq_layer_shortcut(network *net, int i, int32_t *k)
+{
+    if (i < 0 || i >= net->n || net->layers[i].type != SHORTCUT) return -1;
+    k[0] = net->layers[i].shortcut_Ka; k[1] = net->layers[i].shortcut_Kb; k[2] = net->layers[i].index;
+    return 0;
+}

@@ -14,6 +14,8 @@ layer make_upsample_layer(int batch, int w, int h, int c, int stride, int layer_
                           int close_quantization, int count);
 layer make_route_layer(int batch, int n, int *input_layers, int *input_sizes, int layer_quant_flag,
                        int quant_stop_flag, int close_quantization, int count);
+layer make_shortcut_layer(int batch, int index, int w, int h, int c, int w2, int h2, int c2, int layer_quant_flag,
+                          int quant_stop_flag, int close_quantization, int count);
 layer make_yolo_layer(int batch, int w, int h, int n, int total, int *mask, int classes, int count);
 
 void free_layer_device(layer *l);

@@ -42,20 +42,26 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
     d.zp_in = l.input_data_uint8_zero_point[0];
     d.zp_act = l.activ_data_uint8_zero_point[0];
     d.s_act = l.activ_data_uint8_scales[0];
+    /* Fused forms: the executor's plan marks candidates by shape, the launchers decide.  MI355_EINVAL from a fused entry
+     * point means "no kernel fuses this shape" (nothing was launched): the flag is cleared in the network's layer array
+     * (net.layers points at it; `l` is a by-value copy) and the convolution runs unfused below, the layer after it on its
+     * own. */
+    layer *self = &net.layers[l.count];
     if (net.fused_pool_t) { /* this conv + the 2x2/2 maxpool after it as one kernel; the pre-pool tensor is not stored */
-        check_mi355(mi355_conv_pool_forward(&d, net.cur_t, l.blob_gpu, NULL, net.fused_pool_t, net.stream),
-                    "mi355_conv_pool_forward");
-        return;
+        const int rc = mi355_conv_pool_forward(&d, net.cur_t, l.blob_gpu, NULL, net.fused_pool_t, net.stream);
+        if (rc != MI355_EINVAL) { check_mi355(rc, "mi355_conv_pool_forward"); return; }
+        self->fuse_next_pool = 0;
     }
     if (net.fused_up_t) { /* this conv + the nearest-neighbour upsample after it; the conv's own tensor is not stored */
-        check_mi355(mi355_conv_upsample_forward(&d, net.cur_t, l.blob_gpu, net.fused_up_t, net.fused_up_stride, net.stream),
-                    "mi355_conv_upsample_forward");
-        return;
+        const int rc = mi355_conv_upsample_forward(&d, net.cur_t, l.blob_gpu, net.fused_up_t, net.fused_up_stride, net.stream);
+        if (rc != MI355_EINVAL) { check_mi355(rc, "mi355_conv_upsample_forward"); return; }
+        self->fuse_next_upsample = 0;
     }
     if (net.fused_yolo_out) { /* quant_stop head + the yolo layer after it (ref: src/yolo_layer.c:132-146) in one kernel */
-        check_mi355(mi355_conv_yolo_forward(&d, net.cur_t, l.blob_gpu, &l.out_t, l.output_gpu, net.fused_yolo_out,
-                                            net.fused_yolo_classes, net.stream), "mi355_conv_yolo_forward");
-        return;
+        const int rc = mi355_conv_yolo_forward(&d, net.cur_t, l.blob_gpu, &l.out_t, l.output_gpu, net.fused_yolo_out,
+                                               net.fused_yolo_classes, net.stream);
+        if (rc != MI355_EINVAL) { check_mi355(rc, "mi355_conv_yolo_forward"); return; }
+        self->fuse_next_yolo = 0;
     }
     check_mi355(mi355_conv_forward(&d, net.cur_t, l.blob_gpu, l.weights_uint8_gpu, l.weight_zero_point_gpu, &l.out_t,
                                    net.dump_int32 ? l.output_int32_gpu : NULL,
@@ -63,26 +69,60 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
                 "mi355_conv_forward");
 }
 
+/* quant_stop tail shared by the glue layers: l.output = (u8 - zp) * scale (ref: src/maxpool_layer.c:163-171,
+ * src/upsample_layer.c:104-112) */
+static void dequant_tail(layer l, network net)
+{
+    check_mi355(mi355_dequant_forward(&l.out_t, 0, l.out_c, l.activ_data_uint8_zero_point[0], l.activ_data_uint8_scales[0],
+                                      l.output_gpu, l.out_c, 0, net.stream), "mi355_dequant_forward");
+}
+
 /* ref: forward_maxpool_layer_quant, src/maxpool_layer.c:109-172 */
 static void forward_maxpool_layer_quant_gpu(layer l, network net)
 {
     check_mi355(mi355_maxpool_forward(net.cur_t, &l.out_t, l.size, l.stride, l.pad, net.stream), "mi355_maxpool_forward");
+    if (l.quant_stop_flag) dequant_tail(l, net);
 }
 
 /* ref: forward_upsample_layer_quant, src/upsample_layer.c:96-113 */
 static void forward_upsample_layer_quant_gpu(layer l, network net)
 {
     check_mi355(mi355_upsample_forward(net.cur_t, &l.out_t, l.stride, net.stream), "mi355_upsample_forward");
+    if (l.quant_stop_flag) dequant_tail(l, net);
 }
 
 /* ref: forward_route_layer_quant, src/route_layer.c:107-130 */
 static void forward_route_layer_quant_gpu(layer l, network net)
 {
     const mi355_tensor *xs[16];
-    if (l.route_elided) return; /* the producers wrote straight into this layer's buffer */
     if (l.n > 16) error("route: more than 16 inputs");
-    for (int i = 0; i < l.n; ++i) xs[i] = &net.layers[l.input_layers[i]].out_t;
-    check_mi355(mi355_route_forward(xs, l.n, &l.out_t, net.stream), "mi355_route_forward");
+    if (!l.route_elided) { /* else the producers wrote straight into this layer's buffer */
+        for (int i = 0; i < l.n; ++i) xs[i] = &net.layers[l.input_layers[i]].out_t;
+        check_mi355(mi355_route_forward(xs, l.n, &l.out_t, net.stream), "mi355_route_forward");
+    }
+    if (l.quant_stop_flag) { /* ref :121-129: every input's channels with THAT input's scale / zero point */
+        int coff = 0;
+        for (int i = 0; i < l.n; ++i) {
+            const layer *in = &net.layers[l.input_layers[i]];
+            check_mi355(mi355_dequant_forward(&l.out_t, coff, in->out_c, in->activ_data_uint8_zero_point[0],
+                                              in->activ_data_uint8_scales[0], l.output_gpu, l.out_c, coff, net.stream),
+                        "mi355_dequant_forward");
+            coff += in->out_c;
+        }
+    }
+}
+
+/* Quantized residual add.  The reference's [shortcut] is float only (forward_shortcut_layer, src/shortcut_layer.c:62-75 ->
+ * shortcut_cpu, src/blas.c:490-514: out = input + layers[index].output, then the activation): no integer forward exists
+ * to be bit-exact against, so the integer form is this build's own specification. */
+static void forward_shortcut_layer_quant_gpu(layer l, network net)
+{
+    const layer *from = &net.layers[l.index];
+    const layer *prev = &net.layers[net.index - 1];
+    check_mi355(mi355_shortcut_forward(net.cur_t, &from->out_t, &l.out_t, l.shortcut_Ka, l.shortcut_Kb,
+                                       prev->activ_data_uint8_zero_point[0], from->activ_data_uint8_zero_point[0],
+                                       l.activ_data_uint8_zero_point[0], net.stream), "mi355_shortcut_forward");
+    if (l.quant_stop_flag) dequant_tail(l, net);
 }
 
 /* ref: forward_yolo_layer (inference part), src/yolo_layer.c:132-146 */
@@ -159,7 +199,6 @@ layer make_maxpool_layer(int batch, int h, int w, int c, int size, int stride, i
     l.layer_quant_flag = layer_quant_flag; l.quant_stop_flag = quant_stop_flag;
     l.close_quantization = close_quantization;
     if (!layer_quant_flag) error("[maxpool] without quantized=1 is the reference's float path; not built");
-    if (quant_stop_flag) error("quant_stop on a maxpool layer is not supported on the device path");
     alloc_act_record(&l);
     l.forward = forward_cpu_not_built;
     l.forward_gpu = forward_maxpool_layer_quant_gpu;
@@ -180,7 +219,6 @@ layer make_upsample_layer(int batch, int w, int h, int c, int stride, int layer_
     l.layer_quant_flag = layer_quant_flag; l.quant_stop_flag = quant_stop_flag;
     l.close_quantization = close_quantization;
     if (!layer_quant_flag) error("[upsample] without quantized=1 is the reference's float path; not built");
-    if (quant_stop_flag) error("quant_stop on an upsample layer is not supported on the device path");
     alloc_act_record(&l);
     l.forward = forward_cpu_not_built;
     l.forward_gpu = forward_upsample_layer_quant_gpu;
@@ -201,10 +239,33 @@ layer make_route_layer(int batch, int n, int *input_layers, int *input_sizes, in
     l.layer_quant_flag = layer_quant_flag; l.quant_stop_flag = quant_stop_flag;
     l.close_quantization = close_quantization;
     if (!layer_quant_flag) error("[route] without quantized=1 is the reference's float path; not built");
-    if (quant_stop_flag) error("quant_stop on a route layer is not supported on the device path");
     alloc_act_record(&l);
     l.forward = forward_cpu_not_built;
     l.forward_gpu = forward_route_layer_quant_gpu;
+    return l;
+}
+
+/* ref: make_shortcut_layer, src/shortcut_layer.c:9-40 (same dims only: the reference's strided / sampled variants of
+ * shortcut_cpu have no use in the quantized nets) */
+layer make_shortcut_layer(int batch, int index, int w, int h, int c, int w2, int h2, int c2, int layer_quant_flag,
+                          int quant_stop_flag, int close_quantization, int count)
+{
+    layer l;
+    memset(&l, 0, sizeof(l));
+    l.type = SHORTCUT;
+    l.batch = batch; l.w = w2; l.h = h2; l.c = c2; l.count = count;
+    l.out_w = w; l.out_h = h; l.out_c = c;
+    l.outputs = w * h * c;
+    l.inputs = l.outputs;
+    l.index = index;
+    l.activation = LINEAR;
+    l.layer_quant_flag = layer_quant_flag; l.quant_stop_flag = quant_stop_flag;
+    l.close_quantization = close_quantization;
+    if (!layer_quant_flag) error("[shortcut] without quantized=1 is the reference's float path (src/shortcut_layer.c:62-75); not built");
+    if (w != w2 || h != h2 || c != c2) error("[shortcut] quantized=1 needs both inputs to share width, height and channels");
+    alloc_act_record(&l);
+    l.forward = forward_cpu_not_built;
+    l.forward_gpu = forward_shortcut_layer_quant_gpu;
     return l;
 }
 

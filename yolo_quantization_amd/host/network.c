@@ -48,6 +48,7 @@ const char *get_layer_string(LAYER_TYPE t)
     case MAXPOOL: return "MAX";
     case ROUTE: return "ROUTE";
     case UPSAMPLE: return "UPSAMPLE";
+    case SHORTCUT: return "SHORTCUT";
     case YOLO: return "YOLO";
     }
     return "?";
@@ -192,10 +193,18 @@ static int view_producer_ok(network *net, int j, int r)
     if (p->type != CONVOLUTIONAL && p->type != UPSAMPLE && p->type != MAXPOOL) return 0;
     if (p->type == CONVOLUTIONAL && (p->fuse_next_pool && net->fuse_maxpool)) return 0;
     if (j > 0 && net->layers[j - 1].fuse_next_pool && net->fuse_maxpool && p->type == MAXPOOL) return 0; /* written by the fused conv */
+    const int zp_differs = p->activ_data_uint8_zero_point[0] != net->layers[r].activ_data_uint8_zero_point[0];
     if (j + 1 < net->n) {
         layer *c = &net->layers[j + 1];
-        if (c->type == CONVOLUTIONAL && c->size != 1 &&
-            p->activ_data_uint8_zero_point[0] != net->layers[r].activ_data_uint8_zero_point[0]) return 0;
+        if (c->type == CONVOLUTIONAL && c->size != 1 && zp_differs) return 0;
+    }
+    /* a one-input route that plan_views elides shares the producer's tensor: the layer after THAT route reads the same
+     * pad cells */
+    for (int r2 = 0; r2 + 1 < net->n; ++r2) {
+        layer *q = &net->layers[r2];
+        if (q->type != ROUTE || q->n != 1 || q->input_layers[0] != j) continue;
+        layer *c = &net->layers[r2 + 1];
+        if (c->type == CONVOLUTIONAL && c->size != 1 && zp_differs) return 0;
     }
     return 1;
 }
@@ -252,10 +261,39 @@ static void alloc_network_device(network *net)
     if (net->graph) { mi355_graph_destroy(net->graph); net->graph = NULL; }
 }
 
+/* 16.16 multipliers of the two addends of every quantized [shortcut] (mi355_shortcut_multiplier) */
+static void prep_shortcut_layers(network *net)
+{
+    for (int i = 1; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        if (l->type != SHORTCUT) continue;
+        const layer *a = &net->layers[i - 1], *b = &net->layers[l->index];
+        if (a->type == YOLO || b->type == YOLO) error("shortcut: inputs must be quantized layers");
+        check_mi355(mi355_shortcut_multiplier(a->activ_data_uint8_scales[0], l->activ_data_uint8_scales[0], &l->shortcut_Ka),
+                    "mi355_shortcut_multiplier (previous layer)");
+        check_mi355(mi355_shortcut_multiplier(b->activ_data_uint8_scales[0], l->activ_data_uint8_scales[0], &l->shortcut_Kb),
+                    "mi355_shortcut_multiplier (`from` layer)");
+    }
+}
+
+/* does any layer other than i + 1 read layer i's own tensor? (a route input, the `from` of a shortcut) */
+static int output_read_elsewhere(const network *net, int i)
+{
+    for (int j = 0; j < net->n; ++j) {
+        const layer *q = &net->layers[j];
+        if (q->type == ROUTE)
+            for (int k = 0; k < q->n; ++k)
+                if (q->input_layers[k] == i) return 1;
+        if (q->type == SHORTCUT && q->index == i) return 1;
+    }
+    return 0;
+}
+
 void quantization_prep_host(network *net, float in_scale, uint8_t in_zp)
 {
     layer *l0 = &net->layers[0];
     if (l0->type != CONVOLUTIONAL) error("first layer must be convolutional");
+    prep_shortcut_layers(net);
     l0->input_data_uint8_scales[0] = in_scale;
     l0->input_data_uint8_zero_point[0] = in_zp;
     for (int i = 0; i < net->n; ++i) {
@@ -285,31 +323,23 @@ static void plan_fusion(network *net)
     for (int i = 0; i < net->n; ++i) net->layers[i].fuse_next_upsample = 0;
     for (int i = 0; i + 1 < net->n; ++i) { /* conv + nearest upsample: the conv stores every pixel stride x stride times */
         layer *c = &net->layers[i], *u = &net->layers[i + 1];
-        if (c->type != CONVOLUTIONAL || u->type != UPSAMPLE || c->quant_stop_flag || c->c % 64 || u->stride > 4) continue;
-        int used = 0;
-        for (int j = 0; j < net->n; ++j)
-            if (net->layers[j].type == ROUTE)
-                for (int k = 0; k < net->layers[j].n; ++k) used |= net->layers[j].input_layers[k] == i;
-        if (!used) c->fuse_next_upsample = 1;
+        if (c->type != CONVOLUTIONAL || u->type != UPSAMPLE || c->quant_stop_flag || c->c % 64 || u->stride > 4 || c->stride != 1) continue;
+        if (!output_read_elsewhere(net, i)) c->fuse_next_upsample = 1;
     }
     for (int i = 0; i + 1 < net->n; ++i) { /* quant_stop head conv + yolo: one kernel writes both float tensors */
         layer *c = &net->layers[i], *y = &net->layers[i + 1];
-        if (c->type == CONVOLUTIONAL && c->quant_stop_flag && y->type == YOLO && c->c % 16 == 0 &&
+        if (c->type == CONVOLUTIONAL && c->quant_stop_flag && y->type == YOLO && c->c % 16 == 0 && c->stride == 1 &&
             c->n == y->n * (y->classes + 5))
             c->fuse_next_yolo = 1;
     }
     for (int i = 0; i + 1 < net->n; ++i) {
         layer *c = &net->layers[i], *p = &net->layers[i + 1];
         if (c->type != CONVOLUTIONAL || p->type != MAXPOOL) continue;
-        if (c->size != 3 || c->quant_stop_flag || p->size != 2 || p->stride != 2 || p->pad / 2 != 0) continue;
+        if (c->size != 3 || c->stride != 1 || c->quant_stop_flag || p->size != 2 || p->stride != 2 || p->pad / 2 != 0) continue;
         if ((c->out_h & 1) || (c->out_w & 1) || (c->c != 3 && c->c % 16)) continue;
         /* 64-byte-chunk layers use the row-image kernel, which has no fused form; 64 -> 64..128 has its own fused kernel */
         if (c->c % 64 == 0 && !(c->c == 64 && c->n % 32 == 0 && c->n >= 64 && c->n <= 128)) continue;
-        int used = 0;
-        for (int j = 0; j < net->n; ++j)
-            if (net->layers[j].type == ROUTE)
-                for (int k = 0; k < net->layers[j].n; ++k) used |= net->layers[j].input_layers[k] == i;
-        if (!used) c->fuse_next_pool = 1;
+        if (!output_read_elsewhere(net, i)) c->fuse_next_pool = 1;
     }
 }
 
@@ -319,7 +349,7 @@ void quantization_weights_and_activations_fixed_input(network *net, float in_sca
     plan_fusion(net);
     alloc_network_device(net);
     for (int i = 0; i < net->n; ++i)
-        if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, 1);
+        if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, net->has_host_weights);
     check_mi355(mi355_stream_sync(net->stream), "sync");
     net->prepared = 1;
 }
@@ -363,6 +393,8 @@ void quantization_weights_and_activations_gpu(network *net, const float *input_g
     if (!net->prepared) {
         quantization_weights_and_activations_fixed_input(net, s, zp);
     } else if (l0->input_data_uint8_scales[0] != s || l0->input_data_uint8_zero_point[0] != zp) {
+        if (!net->has_host_weights && !net->has_l0_weights)
+            error("the input scale changed but this network holds no raw layer-0 weights to re-derive layer 0 from");
         const int zp_changed = l0->input_data_uint8_zero_point[0] != zp;
         l0->input_data_uint8_scales[0] = s;
         l0->input_data_uint8_zero_point[0] = zp;
@@ -403,10 +435,14 @@ void set_batch_network(network *net, int b)
     net->input = calloc((size_t)net->inputs * b, sizeof(float));
     net->input_uint8 = calloc((size_t)net->inputs * b, sizeof(uint8_t));
     for (int i = 0; i < net->n; ++i) net->layers[i].batch = b;
+    if (net->input_gpu) { /* batch x inputs floats of the device input path: re-allocated lazily at the new size */
+        mi355_free(net->input_gpu);
+        net->input_gpu = NULL;
+    }
     if (net->prepared) { /* re-size the device buffers, keep the packed weights */
         alloc_network_device(net);
         for (int i = 0; i < net->n; ++i)
-            if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, net->layers[i].weights_uint8 != NULL);
+            if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, net->has_host_weights);
         check_mi355(mi355_stream_sync(net->stream), "sync");
     }
 }
@@ -464,16 +500,22 @@ static void run_layers(network *netp)
     for (int i = 0; i < net.n; ++i) {
         net.index = i;
         layer l = net.layers[i];
-        const int fuse = l.fuse_next_pool && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
-        const int fuse_yolo = l.fuse_next_yolo && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
-        net.fused_pool_t = fuse ? &netp->layers[i + 1].out_t : NULL;
-        net.fused_yolo_out = fuse_yolo ? netp->layers[i + 1].output_gpu : NULL;
-        net.fused_yolo_classes = fuse_yolo ? netp->layers[i + 1].classes : 0;
-        const int fuse_up = l.fuse_next_upsample && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
-        net.fused_up_t = fuse_up ? &netp->layers[i + 1].out_t : NULL;
-        net.fused_up_stride = fuse_up ? netp->layers[i + 1].stride : 1;
+        const int fuse0 = l.fuse_next_pool && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
+        const int fuse_yolo0 = l.fuse_next_yolo && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
+        net.fused_pool_t = fuse0 ? &netp->layers[i + 1].out_t : NULL;
+        net.fused_yolo_out = fuse_yolo0 ? netp->layers[i + 1].output_gpu : NULL;
+        net.fused_yolo_classes = fuse_yolo0 ? netp->layers[i + 1].classes : 0;
+        const int fuse_up0 = l.fuse_next_upsample && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
+        net.fused_up_t = fuse_up0 ? &netp->layers[i + 1].out_t : NULL;
+        net.fused_up_stride = fuse_up0 ? netp->layers[i + 1].stride : 1;
         l.forward_gpu(l, net);
         if (l.type == CONVOLUTIONAL) netp->layers[i].conv_kernel = mi355_last_conv_kernel();
+        /* plan_fusion marks candidates by shape; the launchers have the last word.  A fused call they refuse
+         * (MI355_EINVAL) was re-run unfused by the conv's forward_gpu, which also cleared the flag for good: the layer
+         * after it then runs on its own like any other. */
+        const int fuse = fuse0 && netp->layers[i].fuse_next_pool;
+        const int fuse_yolo = fuse_yolo0 && netp->layers[i].fuse_next_yolo;
+        const int fuse_up = fuse_up0 && netp->layers[i].fuse_next_upsample;
         if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
         if (fuse_up) { /* the upsample layer's tensor was written by the conv kernel: hand it on and skip the layer */
             ++i;
@@ -509,6 +551,8 @@ static void run_layers(network *netp)
 void forward_network_gpu(network *netp)
 {
     if (!netp->prepared) error("forward_network_gpu before quantization_weights_and_activations");
+    if (netp->accum_mode == MI355_ACC_REF_F32 && !netp->has_host_weights)
+        error("-accum ref-f32 reads the raw weights_uint8 of every layer; a network imported from packed blobs does not hold them");
     if (netp->use_graph) {
         if (!netp->graph) {
             run_layers(netp); /* warm-up outside capture (module load, attribute calls) */
@@ -596,23 +640,41 @@ void network_yolo_detections_gpu(network *net, int i, int imw, int imh, float th
 }
 
 /* ------------------------------------------------------------------------------------ packed-weight exchange */
-typedef struct { uint32_t magic; int32_t nlayers; float in_scale; int32_t in_zp; uint64_t total; } pack_head;
+/* Layout (little endian, position independent): pack_head | pack_rec[nlayers] | blobs (16-byte aligned, conv layers in
+ * order) | layer-0 raw record.  The last part carries what prep_conv_layer needs to RE-DERIVE layer 0 when an image's
+ * dynamic input scale / zero point differs from the exporter's (ref: src/blas.c:279 recomputes them per image): biases,
+ * batch-norm statistics, weight scales / zero points and the 3-channel layer's few raw weights.  No other layer depends on
+ * the input scale, so the other layers travel as packed blobs only (an imported network therefore cannot serve the
+ * MI355_ACC_REF_F32 verification mode, which reads raw weights: has_host_weights == 0 refuses it). */
+typedef struct { uint32_t magic; int32_t nlayers; float in_scale; int32_t in_zp; uint64_t total; uint64_t l0_bytes; } pack_head;
 typedef struct { float s_act, s_in; int32_t zp_act, zp_in; uint64_t blob_bytes; } pack_rec;
-#define PACK_MAGIC 0x51444B4Eu
+typedef struct { int32_t n, c, size, batch_normalize; } pack_l0;
+#define PACK_MAGIC 0x32444B4Eu /* "NKD2" */
+
+static size_t l0_record_bytes(const layer *l)
+{
+    size_t sz = sizeof(pack_l0) + (size_t)l->n * sizeof(float) * (l->batch_normalize ? 4 : 1) /* biases (+ scales, mean, var) */
+                + (size_t)l->n * sizeof(float) + (size_t)l->n + (size_t)l->nweights;            /* w scales, w zp, weights */
+    return (sz + 15) & ~(size_t)15;
+}
 
 size_t network_packed_size(network *net)
 {
     if (!net->layers[0].blob_host) error("network_packed_size before prep");
     size_t sz = sizeof(pack_head) + (size_t)net->n * sizeof(pack_rec);
+    sz = (sz + 15) & ~(size_t)15;
     for (int i = 0; i < net->n; ++i) sz += (net->layers[i].blob_bytes + 15) & ~(size_t)15;
-    return sz;
+    return sz + l0_record_bytes(&net->layers[0]);
 }
 
 void network_export_packed(network *net, void *buf)
 {
     char *p = buf;
-    pack_head h = {PACK_MAGIC, net->n, net->layers[0].input_data_uint8_scales[0],
-                   net->layers[0].input_data_uint8_zero_point[0], network_packed_size(net)};
+    const size_t total = network_packed_size(net);
+    memset(buf, 0, total);
+    layer *l0 = &net->layers[0];
+    pack_head h = {PACK_MAGIC, net->n, l0->input_data_uint8_scales[0], l0->input_data_uint8_zero_point[0], total,
+                   l0_record_bytes(l0)};
     memcpy(p, &h, sizeof(h)); p += sizeof(h);
     for (int i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];
@@ -623,22 +685,35 @@ void network_export_packed(network *net, void *buf)
         r.blob_bytes = l->blob_bytes;
         memcpy(p, &r, sizeof(r)); p += sizeof(r);
     }
+    p = (char *)buf + ((sizeof(pack_head) + (size_t)net->n * sizeof(pack_rec) + 15) & ~(size_t)15);
     for (int i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];
         if (!l->blob_bytes) continue;
         memcpy(p, l->blob_host, l->blob_bytes);
         p += (l->blob_bytes + 15) & ~(size_t)15;
     }
+    pack_l0 r0 = {l0->n, l0->c, l0->size, l0->batch_normalize};
+    memcpy(p, &r0, sizeof(r0)); p += sizeof(r0);
+    memcpy(p, l0->biases, (size_t)l0->n * sizeof(float)); p += (size_t)l0->n * sizeof(float);
+    if (l0->batch_normalize) {
+        memcpy(p, l0->scales, (size_t)l0->n * sizeof(float)); p += (size_t)l0->n * sizeof(float);
+        memcpy(p, l0->rolling_mean, (size_t)l0->n * sizeof(float)); p += (size_t)l0->n * sizeof(float);
+        memcpy(p, l0->rolling_variance, (size_t)l0->n * sizeof(float)); p += (size_t)l0->n * sizeof(float);
+    }
+    memcpy(p, l0->weight_data_uint8_scales, (size_t)l0->n * sizeof(float)); p += (size_t)l0->n * sizeof(float);
+    memcpy(p, l0->weight_data_uint8_zero_point, (size_t)l0->n); p += l0->n;
+    memcpy(p, l0->weights_uint8, (size_t)l0->nweights);
 }
 
 void network_import_packed_host(network *net, const void *buf, size_t bytes)
 {
     const char *p = buf;
     pack_head h;
+    if (bytes < sizeof(h)) error("network_import_packed: truncated");
     memcpy(&h, p, sizeof(h)); p += sizeof(h);
-    if (h.magic != PACK_MAGIC || h.nlayers != net->n || h.total != bytes) error("network_import_packed: header mismatch (different cfg?)");
+    if (h.magic != PACK_MAGIC || h.nlayers != net->n || h.total != bytes) error("network_import_packed: header mismatch (different cfg or format version?)");
     const pack_rec *recs = (const pack_rec *)p;
-    p += (size_t)net->n * sizeof(pack_rec);
+    p = (const char *)buf + ((sizeof(pack_head) + (size_t)net->n * sizeof(pack_rec) + 15) & ~(size_t)15);
     for (int i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];
         pack_rec r;
@@ -654,6 +729,61 @@ void network_import_packed_host(network *net, const void *buf, size_t bytes)
             p += (r.blob_bytes + 15) & ~(size_t)15;
         }
     }
+    layer *l0 = &net->layers[0];
+    pack_l0 r0;
+    memcpy(&r0, p, sizeof(r0)); p += sizeof(r0);
+    if (r0.n != l0->n || r0.c != l0->c || r0.size != l0->size || r0.batch_normalize != l0->batch_normalize ||
+        h.l0_bytes != l0_record_bytes(l0)) error("network_import_packed: layer-0 record mismatch");
+    memcpy(l0->biases, p, (size_t)l0->n * sizeof(float)); p += (size_t)l0->n * sizeof(float);
+    if (l0->batch_normalize) {
+        memcpy(l0->scales, p, (size_t)l0->n * sizeof(float)); p += (size_t)l0->n * sizeof(float);
+        memcpy(l0->rolling_mean, p, (size_t)l0->n * sizeof(float)); p += (size_t)l0->n * sizeof(float);
+        memcpy(l0->rolling_variance, p, (size_t)l0->n * sizeof(float)); p += (size_t)l0->n * sizeof(float);
+    }
+    memcpy(l0->weight_data_uint8_scales, p, (size_t)l0->n * sizeof(float)); p += (size_t)l0->n * sizeof(float);
+    memcpy(l0->weight_data_uint8_zero_point, p, (size_t)l0->n); p += l0->n;
+    memcpy(l0->weights_uint8, p, (size_t)l0->nweights);
+    prep_shortcut_layers(net);
+    net->has_host_weights = 0; /* blobs only (plus layer 0's raw record) */
+    net->has_l0_weights = 1;
+}
+
+/* On-disk form of the same bytes: what `load_weights` + the host prep + packing produce, written once
+ * and read back with one fread -- replaces, for a deployed model, the per-layer reader ref: src/parser.c:1124-1159, the
+ * per-channel prep ref: src/blas.c:285-334 and the MFMA-order packing at every start-up. */
+void network_save_packed(network *net, char *filename)
+{
+    const size_t sz = network_packed_size(net);
+    void *buf = malloc(sz);
+    network_export_packed(net, buf);
+    FILE *fp = fopen(filename, "wb");
+    if (!fp) file_error(filename);
+    if (fwrite(buf, 1, sz, fp) != sz) error("network_save_packed: short write");
+    fclose(fp);
+    free(buf);
+}
+
+static void *read_packed_file(const char *filename, size_t *bytes)
+{
+    FILE *fp = fopen(filename, "rb");
+    if (!fp) file_error(filename);
+    fseek(fp, 0, SEEK_END);
+    const long sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    if (sz < (long)sizeof(pack_head)) error("network_load_packed: file too small");
+    void *buf = malloc((size_t)sz);
+    if (fread(buf, 1, (size_t)sz, fp) != (size_t)sz) error("network_load_packed: short read");
+    fclose(fp);
+    *bytes = (size_t)sz;
+    return buf;
+}
+
+void network_load_packed(network *net, char *filename)
+{
+    size_t sz = 0;
+    void *buf = read_packed_file(filename, &sz);
+    network_import_packed(net, buf, sz);
+    free(buf);
 }
 
 void network_import_packed(network *net, const void *buf, size_t bytes)
@@ -695,6 +825,8 @@ void free_network(network *net)
     if (net->graph) mi355_graph_destroy(net->graph);
     if (net->input_uint8_gpu) mi355_free(net->input_uint8_gpu);
     if (net->input_t.data) mi355_free(net->input_t.data);
+    if (net->input_gpu) mi355_free(net->input_gpu);
+    if (net->quant_mm_gpu) mi355_free(net->quant_mm_gpu);
     if (net->stream) mi355_stream_destroy(net->stream);
     free(net->layers); free(net->input); free(net->input_uint8); free(net->seen);
     free(net);

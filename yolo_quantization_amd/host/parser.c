@@ -123,6 +123,9 @@ static layer parse_convolutional(section *o, size_params p, int count)
     int groups = option_find_int(o, "groups", 1);
     if (pad) padding = size / 2; /* ref :178 */
     ACTIVATION act = get_activation(option_find_str(o, "activation", "logistic"));
+    if (act == LOGISTIC) /* also the default when the key is missing (ref: src/parser.c:180) */
+        error("[convolutional] activation=logistic (or no activation key): the reference's quantized forward stores nothing for it "
+              "(`default: break`, src/convolutional_layer.c:746); use leaky, relu6, relu or linear");
     if (!(p.h && p.w && p.c)) error("Layer before convolutional layer must output image.");
     int bn = option_find_int(o, "batch_normalize", 0);
     int q = option_find_int(o, "quantized", 0);
@@ -186,6 +189,25 @@ static layer parse_route(section *o, size_params p, network *net, int count)
     }
     r.fisrt_time_train_fag = option_find_int(o, "first_time", 0);
     return r;
+}
+
+/* ref: parse_shortcut, src/parser.c:566-590 (`from`, `activation`; the fork adds no quant keys there -- `quantized` /
+ * `quant_stop` / `first_time` follow its other glue layers) */
+static layer parse_shortcut(section *o, size_params p, network *net, int count)
+{
+    char *l = option_find(o, "from");
+    if (!l) error("Shortcut layer must specify `from`");
+    int index = atoi(l);
+    if (index < 0) index = p.index + index;
+    if (index < 0 || index >= p.index || p.index == 0) error("shortcut: bad layer index");
+    layer from = net->layers[index];
+    ACTIVATION act = get_activation(option_find_str(o, "activation", "linear"));
+    if (act != LINEAR) error("[shortcut] quantized=1 supports activation=linear only (YOLOv3's residual blocks)");
+    int q = option_find_int(o, "quantized", 0), qs = option_find_int(o, "quant_stop", 0);
+    layer s = make_shortcut_layer(p.batch, index, p.w, p.h, p.c, from.out_w, from.out_h, from.out_c, q, qs,
+                                  p.close_quantization, count);
+    s.fisrt_time_train_fag = option_find_int(o, "first_time", 0);
+    return s;
 }
 
 static layer parse_yolo(section *o, size_params p, int count)
@@ -253,6 +275,7 @@ network *parse_network_cfg(char *filename, int close_quantization)
         else if (!strcmp(s->type, "[maxpool]") || !strcmp(s->type, "[max]")) l = parse_maxpool(s, p, i);
         else if (!strcmp(s->type, "[upsample]")) l = parse_upsample(s, p, i);
         else if (!strcmp(s->type, "[route]")) l = parse_route(s, p, net, i);
+        else if (!strcmp(s->type, "[shortcut]")) l = parse_shortcut(s, p, net, i);
         else if (!strcmp(s->type, "[yolo]")) l = parse_yolo(s, p, i);
         else {
             fprintf(stderr, "Layer type %s has no quantized forward in the reference (SURVEY.md 2 row 20); not built.\n", s->type);
@@ -340,12 +363,14 @@ void load_weights(network *net, char *filename)
         if (l.type == UPSAMPLE && l.layer_quant_flag) { /* ref :1185-1199 */
             if (!l.fisrt_time_train_fag) load_act_record(l, fp);
         }
+        if (l.type == SHORTCUT) load_act_record(l, fp); /* builder-specified: the sum's own (scale, zero point), like a maxpool's record */
     }
     long here = ftell(fp);
     fseek(fp, 0, SEEK_END);
     if (ftell(fp) != here) fprintf(stderr, "warning: %ld trailing bytes in %s\n", ftell(fp) - here, filename);
     fclose(fp);
     net->prepared = 0;
+    net->has_host_weights = 1;
 }
 
 network *load_network(char *cfg, char *weights, int clear)

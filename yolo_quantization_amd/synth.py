@@ -9,6 +9,7 @@ benchmark synthesise a seeded model and write it in the reference's `.weights` l
                          f32 in_scale; u8 in_zp; f32 act_scale; u8 act_zp; f32 w_scale[n]; u8 w_zp[n];
                          u8 weights_uint8[n*c*k*k]; f32 weights[n*c*k*k]
     per [maxpool] (always), per quantized [route] with >1 input, per quantized [upsample]: f32 act_scale; u8 act_zp
+    per [shortcut] (quantized residual add -- this build's own op, the reference has none): f32 act_scale; u8 act_zp
 
 Recipe: He-normal float weights, BN scale U[.8,1.2], mean U[-.05,.05], var U[.5,1.5], bias
 U[-.1,.1]; per-channel min/max (incl. 0) uint8 quantisation of the BN-folded weights; activation (scale, zp) =
@@ -102,6 +103,11 @@ def layer_shapes(sections: list[dict]) -> tuple[dict, list[LayerShape]]:
             f = layers[srcs[0]]
             oc = sum(layers[i].out_c for i in srcs)
             L = LayerShape("route", 0, 0, 0, oc, f.out_h, f.out_w, len(srcs), 0, 1, 0, "", 0, q, qs, srcs)
+        elif t == "[shortcut]":
+            frm = int(s["from"])
+            frm = frm if frm >= 0 else idx + frm
+            L = LayerShape("shortcut", c, h, w, c, h, w, 0, 0, 1, 0, s.get("activation", "linear"), 0, q, qs, [idx - 1, frm])
+            assert (layers[frm].out_c, layers[frm].out_h, layers[frm].out_w) == (c, h, w), "shortcut inputs must share dims"
         elif t == "[yolo]":
             L = LayerShape("yolo", c, h, w, c, h, w)
             L.n = len(s.get("mask", "0").split(","))
@@ -171,6 +177,16 @@ def synth_weights(cfg_path: str, out_path: str, seed: int = 1234, act_gain: floa
             a = act_q[L.inputs[0]]
             if L.quantized and len(L.inputs) > 1:
                 blob += struct.pack("<fB", float(a[0]), int(a[1]))
+            act_q.append(a)
+        elif L.type == "shortcut":
+            # the sum's own record: zero point of the full real range of a + b, scale = 0.6 of that range / 255 (a calibrated
+            # scale is tighter than the worst case; this also makes both ends saturate in the tests)
+            (sa, za), (sb, zb) = act_q[L.inputs[0]], act_q[L.inputs[1]]
+            lo = -(np.float64(sa) * za + np.float64(sb) * zb)
+            hi = np.float64(sa) * (255 - za) + np.float64(sb) * (255 - zb)
+            zp = int(min(255, max(0, np.floor(-lo / ((hi - lo) / 255.0) + 0.5))))
+            a = (np.float32((hi - lo) * 0.6 / 255.0), zp)
+            blob += struct.pack("<fB", float(a[0]), int(a[1]))
             act_q.append(a)
         else:  # yolo
             act_q.append(act_q[i - 1])
