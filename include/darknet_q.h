@@ -189,6 +189,26 @@ void pull_layer_output(network *net, int i);
 void network_yolo_detections_gpu(network *net, int i, int imw, int imh, float thresh, int relative, float *recs,
                                  int max_recs, int *counts);
 
+/* ---- detections (what `detector test` does after network_predict; ref: include/darknet.h:658-669) -------------------- */
+typedef struct { float x, y, w, h; } box;
+typedef struct detection {
+    box bbox;
+    int classes;
+    float *prob;
+    float *mask;
+    float objectness;
+    int sort_class;
+} detection;
+/* ref: src/network.c:583-640 -- yolo layers in network order, image 0 of the batch (get_network_boxes_batch: image b) */
+detection *get_network_boxes(network *net, int w, int h, float thresh, float hier, int *map, int relative, int *num);
+detection *get_network_boxes_batch(network *net, int b, int w, int h, float thresh, float hier, int *map, int relative, int *num);
+void free_detections(detection *dets, int n);
+void do_nms_sort(detection *dets, int total, int classes, float thresh); /* ref: src/box.c:58-89 */
+void do_nms_sort_arrays(const float *boxes, float *probs, const float *objectness, int n, int classes, float thresh);
+float box_iou(box a, box b);
+char *data_cfg_find(const char *datacfg, const char *key); /* `key = value` of a .data file, or NULL */
+char **get_labels(char *filename, int *count);
+
 /* per-layer profiling: record HIP events around every layer for the next `max_steps` forward passes (eager
  * launches only), then read the per-layer sums in ms: out[0] = input layout conversion, out[1+i] = layer i. */
 void network_profile_begin(network *net, int max_steps);
@@ -203,6 +223,9 @@ void network_import_packed(network *net, const void *buf, size_t bytes);
 void network_import_packed_host(network *net, const void *buf, size_t bytes); /* host half only (no device) */
 /* same exchange with the buffer already on the device (what bench.py hands over after torch.distributed.broadcast) */
 void network_import_packed_gpu(network *net, const void *dev_buf, size_t bytes);
+/* the whole start-up exchange behind the C ABI: root exports + uploads, one mi355_bcast_blob (RCCL over xGMI), the other
+ * ranks import from HBM.  comm: mi355_comm_init handle of the calling rank. */
+void network_bcast_packed(network *net, void *comm, int rank, int root);
 /* the same bytes as a file: written once after load_weights + prep, read back with one fread */
 void network_save_packed(network *net, char *filename);
 void network_load_packed(network *net, char *filename);

@@ -76,6 +76,18 @@ int mi355_graph_end(void *stream, void **graph_exec);
 int mi355_graph_launch(void *graph_exec, void *stream);
 int mi355_graph_destroy(void *graph_exec);
 
+/* ---- the path's one collective: one-shot RCCL broadcast of the packed weights over xGMI -----------------
+ * The reference has no inference-time communication (its multi-GPU code is host-staged weight averaging for training,
+ * ref: src/network.c:1100-1194); images shard by rank and every device holds a replica of the packed blobs.  librccl is
+ * bound with dlopen at the first call (MI355_ENODEV when absent).  One communicator rank per device: call mi355_init(dev)
+ * on the thread first.  id128: the 128-byte ncclUniqueId, created on one rank and handed to the others by the launcher
+ * (a shared variable between host threads, the process launcher's store between processes). */
+int mi355_comm_unique_id(void *id128);
+int mi355_comm_init(void **comm, int nranks, const void *id128, int rank);
+int mi355_bcast_blob(void *comm, void *dev_buf, size_t bytes, int root, void *stream); /* in place, asynchronous on `stream` */
+int mi355_comm_destroy(void *comm);
+const char *mi355_comm_last_error(void);
+
 /* ---- tensors ----------------------------------------------------------------------------------------------- */
 typedef struct mi355_tensor {
     void *data;   /* device pointer to cell 0 */

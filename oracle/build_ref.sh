@@ -37,4 +37,16 @@ build_flavour() {   # $1 = obj dir suffix, $2 = extra cflags, $3 = output .so, $
 }
 build_flavour ""     ""         libdarknet_ref.so     ""
 build_flavour "_omp" "-fopenmp" libdarknet_ref_omp.so "-lgomp"
+# The reference bound to the MI355X kernels: the SAME unmodified reference objects + integration/mi355_glue.c (the file a
+# maintainer adds as src/mi355_glue.c, compiled against the reference's own include/darknet.h) + the driver's -DMI355 hooks,
+# linked against the product's C-ABI library.  Proves the drop-in boundary: tests/test_gpu_refbind.py runs it on the GPU box.
+SHIM="$HERE/../yolo_quantization_amd/lib"
+if [ -f "$SHIM/libmi355yolo.so" ]; then
+  od="$OUT/obj"
+  gcc $COMMON -DMI355 -I"$HERE/../include" -I"$HERE/../integration" -c "$HERE/../integration/mi355_glue.c" -o "$OUT/mi355_glue.o"
+  gcc $COMMON -DMI355 -I"$HERE/../include" -I"$HERE/../integration" -c "$HERE/ref_driver.c" -o "$OUT/ref_driver_mi355.o"
+  objs=$(ls "$od"/*.o | grep -v ref_driver.o)
+  gcc -shared -o "$OUT/libdarknet_ref_mi355.so" $objs "$OUT/mi355_glue.o" "$OUT/ref_driver_mi355.o" -lm -pthread \
+      -L"$SHIM" -lmi355yolo -Wl,-rpath,'$ORIGIN/../../yolo_quantization_amd/lib'
+fi
 echo "build_ref: OK -> $OUT"

@@ -277,3 +277,46 @@ int refdrv_forward_layer(void *h, int i, uint8_t *input)
     unhush();
     return 0;
 }
+
+#ifdef MI355
+/* ---- the reference with its layer.forward_gpu pointers bound to libmi355yolo.so (integration/mi355_glue.c) ----------
+ * The network is the REFERENCE's: its parser, weights loader, host prep and `struct layer`; only the forward_gpu function
+ * pointers (include/darknet.h:161) are ours.  After refdrv_forward_mi355 the layers' output_uint8_final / output_int32 /
+ * output hold what the device computed, so the same accessors serve both paths. */
+#include "mi355_glue.h"
+int refdrv_mi355_bind(void *h, int gpu, int accum_mode, int store_mode)
+{
+    refnet *r = h;
+    if (!r->prepared) return -1;
+    mi355_bind_network(r->net, gpu, accum_mode, store_mode);
+    return 0;
+}
+int refdrv_forward_mi355(void *h, int pull_all)
+{
+    refnet *r = h;
+    forward_network_mi355(r->net, pull_all);
+    return 0;
+}
+void refdrv_mi355_unbind(void *h) { mi355_unbind_network(((refnet *)h)->net); }
+#endif
+
+/* do_nms_sort of the reference itself (src/box.c:58-89) on flat arrays: boxes [n][4], probs [n][classes] (in/out),
+ * objectness [n].  qsort reorders the detections; each carries its row id (in the unused `classes` field) so the
+ * result lands back in its own row. */
+void refdrv_nms_sort(const float *boxes, float *probs, const float *objectness, int n, int classes, float thresh)
+{
+    detection *dets = calloc(n > 0 ? n : 1, sizeof(detection));
+    for (int i = 0; i < n; ++i) {
+        dets[i].bbox.x = boxes[4 * i]; dets[i].bbox.y = boxes[4 * i + 1]; dets[i].bbox.w = boxes[4 * i + 2]; dets[i].bbox.h = boxes[4 * i + 3];
+        dets[i].objectness = objectness[i];
+        dets[i].classes = i;
+        dets[i].prob = calloc(classes, sizeof(float));
+        memcpy(dets[i].prob, probs + (size_t)i * classes, sizeof(float) * classes);
+    }
+    do_nms_sort(dets, n, classes, thresh);
+    for (int i = 0; i < n; ++i) {
+        memcpy(probs + (size_t)dets[i].classes * classes, dets[i].prob, sizeof(float) * classes);
+        free(dets[i].prob);
+    }
+    free(dets);
+}

@@ -9,6 +9,7 @@ Fixtures are data only (inputs + the reference's outputs):
   s2_unit_seed{1,2}.npz     the same for cfg/s2_unit.cfg (stride-2 3x3 convolutions)
   funcs.npz                 known-answer vectors for gemm_nn_uint8_int32_te / im2col_cpu_uint8 /
                             quant_multi_smaller_than_one_to_scale_and_shift / quant_weights_with_min_max_channel
+  nms.npz                   do_nms_sort (src/box.c:58-89) on clustered random detections
   yolov3_tiny_{leaky,relu6}.json   per-layer SHA-256 of output_int32 / output_uint8_final / output (f32) of the
                             24-layer net @416x416 on the seeded synthetic model + seeded uint8 image, the host-prep
                             arrays' SHA-256, and the full head tensors' uint8 bytes (L15, L22) as hex.
@@ -134,6 +135,30 @@ def funcs():
     print("funcs: wrote", len(d), "arrays")
 
 
+def nms():
+    """do_nms_sort (src/box.c:58-89) known answers: clustered random boxes (many overlaps), a few zero-objectness rows."""
+    import ctypes as C
+    L = refdrv.lib()
+    L.refdrv_nms_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    rng = np.random.default_rng(77)
+    d = {}
+    for name, (n, classes, thresh) in {"a": (60, 5, 0.45), "b": (200, 3, 0.3), "c": (7, 80, 0.45), "empty": (0, 4, 0.45)}.items():
+        centres = rng.uniform(0.2, 0.8, (max(n // 6, 1), 2))
+        idx = rng.integers(0, len(centres), n)
+        boxes = np.concatenate([centres[idx] + rng.normal(0, 0.03, (n, 2)), rng.uniform(0.05, 0.3, (n, 2))], axis=1).astype(np.float32)
+        obj = rng.uniform(0.3, 1.0, n).astype(np.float32)
+        if n > 10:
+            obj[rng.integers(0, n, n // 10)] = 0
+        probs = (obj[:, None] * rng.uniform(0, 1, (n, classes))).astype(np.float32)
+        probs[probs < 0.25] = 0
+        out = probs.copy()
+        L.refdrv_nms_sort(boxes.ctypes.data, out.ctypes.data, obj.ctypes.data, n, classes, thresh)
+        d[f"{name}_boxes"] = boxes; d[f"{name}_obj"] = obj; d[f"{name}_probs"] = probs; d[f"{name}_out"] = out
+        d[f"{name}_thresh"] = np.float32(thresh)
+        print(f"nms {name}: {int((probs > 0).sum())} scores in, {int((out > 0).sum())} kept")
+    np.savez_compressed(os.path.join(HERE, "nms.npz"), **d)
+
+
 def yolov3_tiny(tag, cfgname):
     cfg = os.path.join(ROOT, "cfg", cfgname)
     wts = f"/tmp/golden_{tag}.weights"
@@ -213,6 +238,8 @@ if __name__ == "__main__":
         tiny_unit(2, 8.0, "s2_unit")
     if want("funcs"):
         funcs()
+    if want("nms"):
+        nms()
     if want("yolov3_tiny"):
         yolov3_tiny("leaky", "yolov3-tiny_quant.cfg")
         yolov3_tiny("relu6", "yolov3-tiny_quant_relu6.cfg")

@@ -8,8 +8,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REF_DIR = os.path.join(_HERE, "..", "oracle", "_ref")
 
 
+_NAMES = {False: "libdarknet_ref.so", True: "libdarknet_ref_omp.so", "mi355": "libdarknet_ref_mi355.so"}
+
+
 def available(omp=False):
-    return os.path.exists(os.path.join(REF_DIR, "libdarknet_ref_omp.so" if omp else "libdarknet_ref.so"))
+    return os.path.exists(os.path.join(REF_DIR, _NAMES[omp]))
 
 
 _libs = {}
@@ -17,7 +20,11 @@ _libs = {}
 
 def lib(omp=False):
     if omp not in _libs:
-        L = C.CDLL(os.path.join(REF_DIR, "libdarknet_ref_omp.so" if omp else "libdarknet_ref.so"))
+        L = C.CDLL(os.path.join(REF_DIR, _NAMES[omp]))
+        if omp == "mi355":
+            L.refdrv_mi355_bind.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+            L.refdrv_forward_mi355.argtypes = [C.c_void_p, C.c_int]
+            L.refdrv_mi355_unbind.argtypes = [C.c_void_p]
         L.refdrv_load.restype = C.c_void_p
         L.refdrv_load.argtypes = [C.c_char_p, C.c_char_p]
         L.refdrv_nlayers.argtypes = [C.c_void_p]
@@ -108,6 +115,16 @@ class RefNet:
         cnt = self.L.refdrv_yolo_detections(self.h, i, imw, imh, C.c_float(thresh), int(relative), recs.ctypes.data, cap)
         assert cnt >= 0
         return cnt, recs[:min(cnt, cap)]
+
+    def mi355_bind(self, gpu=0, accum=0, store=0):
+        """Point the reference's layer.forward_gpu pointers at libmi355yolo.so (integration/mi355_glue.c)."""
+        assert self.L.refdrv_mi355_bind(self.h, gpu, accum, store) == 0
+
+    def forward_mi355(self, pull_all=True):
+        assert self.L.refdrv_forward_mi355(self.h, int(pull_all)) == 0
+
+    def mi355_unbind(self):
+        self.L.refdrv_mi355_unbind(self.h)
 
     def forward_layer(self, i, x_u8):
         """Layer i alone on the given uint8 input (its own forward pointer); outputs via layer_int32 / layer_u8 / layer_f32."""

@@ -785,7 +785,12 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     lds += (size_t)BM * 40 + 1024;
     if (lds > 160 * 1024) return MI355_EINVAL;
     auto kern = conv_rows_i8_kernel<BM, BN, WMW, WNW, RS, KS>;
-    static size_t lds_attr = 0;  // per kernel instantiation: raise the dynamic-LDS limit once, not per launch
+    // per kernel instantiation AND per device (function attributes are per device; `darknet -gpus` drives several devices
+    // from one process): raise the dynamic-LDS limit once, not per launch
+    static size_t lds_attr_dev[64] = {0};
+    int dev_ix = 0;
+    (void)hipGetDevice(&dev_ix);
+    size_t &lds_attr = lds_attr_dev[dev_ix & 63];
     if (lds > 64 * 1024 && lds > lds_attr) {
         lds_attr = lds;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

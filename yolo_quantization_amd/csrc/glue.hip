@@ -162,6 +162,10 @@ __global__ __launch_bounds__(256) void shortcut_u8_kernel(const ShortcutArgs s)
         for (int e = 0; e < 4; ++e) {
             const int av = (int)((wa[d] >> (8 * e)) & 0xFFu), bv = (int)((wb[d] >> (8 * e)) & 0xFFu);
             int q = (s.ka * av + s.kb * bv + s.k0) >> 16;
+            // Keep shift and clamp apart: fused, hipcc (ROCm 7.2) emits V_ASHR_PK_U8_I32 for pairs of them and ORs bytes 2, 3
+            // into its result assuming bits 31:16 are zero -- on gfx950 the instruction leaves the destination's old upper
+            // half there (measured: byte 2 came back OR'ed with the first lane value; tools/dbg/shortcut_dbg.py).
+            asm volatile("" : "+v"(q));
             q = q < 0 ? 0 : (q > 255 ? 255 : q);
             w |= (uint32_t)q << (8 * e);
         }

@@ -2,15 +2,28 @@
  * darknet.c -- `./darknet detector test <data> <cfg> <weights> <image> [flags]`, the drop-in entry point
  * (ref: examples/darknet.c:220 main -> examples/detector.c:952 run_detector -> :878 test_detector), INT8 path only.
  *
- * Flags of the reference kept: -i <gpu>, -thresh <t>, -close_quantization (rejected: float path not built).
- * Added: -batch <B> (replicates the image), -accum exact|ref-f32, -parity wrap|saturate, -dump <dir> (per-layer
- * tensors in the reference layout), -graph (hipGraph replay), -n <iters> (timing loop).
+ * The flow is test_detector's (examples/detector.c:878-950):
+ *   read_data_cfg(<data>) `names=`, get_labels            :880-882
+ *   load_network, set_batch_network                        :885-886
+ *   load image -> letterbox_image(net->w, net->h)          :903-904   (here: on the device, mi355_letterbox_forward)
+ *   quantization_weights_and_activations (layer-0 quantiser on the float image) :918   (here: on the device)
+ *   network_predict, "Predicted in"                        :922-924
+ *   get_network_boxes(im.w, im.h, thresh, hier, 0, 1)      :926       (here: box decode on the device)
+ *   do_nms_sort(nms = .45)                                 :930
+ *   draw_detections -> prints "<name>: <p>%"               :931 (src/image.c:255); drawing / saving the image is not built
  *
- * Image input: binary PPM (P6) of the network size, a raw `.u8` file holding [c][h][w] bytes, or
- * `synthetic:<seed>`.  JPEG/PNG decoding (stb_image in the reference, third-party) and letterboxing are outside
- * the INT8 hot path and not built; detections are printed as raw (objectness*class) maxima,
- * box decode / NMS / drawing are SURVEY.md 8(f) rank 1 "next" work.
+ * Flags of the reference kept: -i <gpu>, -thresh <t>, -hier <t>, -gpus a,b,c (ref :954-986), -close_quantization
+ * (rejected: float path not built).  Added: -batch <B> (replicates the image), -accum exact|ref-f32,
+ * -parity wrap|saturate, -dump <dir> (per-layer tensors in the reference layout), -graph (hipGraph replay), -n <iters>,
+ * -save_packed <file> / -packed <file>, -boxes (one machine-readable line per kept box), -bcast (with
+ * -gpus: replica 0 reads the weights file, the others receive the packed blobs by one RCCL broadcast over xGMI).
+ *
+ * Image input: binary PPM (P6) of ANY size (letterboxed like the reference does), a raw `.u8` file holding [c][h][w] bytes at
+ * network size, or `synthetic:<seed>`.  JPEG/PNG decoding is third-party code in the reference (stb_image, SURVEY.md 2
+ * row 21) and not built.
  */
+#include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,37 +42,50 @@ static const char *find_char_arg(int argc, char **argv, const char *arg, const c
     return def;
 }
 
-static void load_image_u8(const char *path, int c, int h, int w, uint8_t *out)
+typedef struct { int w, h, c; float *data; } image; /* planar float [c][h][w] in 0..1, like the reference's `image` */
+
+/* load_image_color's contract (ref: src/image.c:1361-1395: bytes / 255., planar) for PPM / raw / synthetic sources */
+static image load_image_any(const char *path, int netc, int neth, int netw)
 {
-    const size_t n = (size_t)c * h * w;
-    if (0 == strncmp(path, "synthetic", 9)) {
-        unsigned long long s = 88172645463325252ULL;
-        const char *colon = strchr(path, ':');
-        if (colon) s ^= strtoull(colon + 1, NULL, 10) * 0x9E3779B97F4A7C15ULL;
-        for (size_t i = 0; i < n; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; out[i] = (uint8_t)(s >> 32); }
-        out[0] = 0; out[1] = 255; /* full range: the reference's dynamic quantiser is then the identity */
-        return;
+    image im = {0, 0, 0, NULL};
+    if (0 == strncmp(path, "synthetic", 9) || (strlen(path) > 3 && 0 == strcmp(path + strlen(path) - 3, ".u8"))) {
+        const size_t n = (size_t)netc * neth * netw;
+        uint8_t *raw = malloc(n);
+        if (0 == strncmp(path, "synthetic", 9)) {
+            unsigned long long s = 88172645463325252ULL;
+            const char *colon = strchr(path, ':');
+            if (colon) s ^= strtoull(colon + 1, NULL, 10) * 0x9E3779B97F4A7C15ULL;
+            for (size_t i = 0; i < n; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; raw[i] = (uint8_t)(s >> 32); }
+            raw[0] = 0; raw[1] = 255; /* full range: the reference's dynamic quantiser is then the identity */
+        } else {
+            FILE *f = fopen(path, "rb");
+            if (!f) { fprintf(stderr, "Cannot load image \"%s\"\n", path); exit(0); }
+            if (fread(raw, 1, n, f) != n) error("raw .u8 image has the wrong size");
+            fclose(f);
+        }
+        im.w = netw; im.h = neth; im.c = netc;
+        im.data = malloc(n * sizeof(float));
+        for (size_t i = 0; i < n; ++i) im.data[i] = (float)raw[i] / 255.0f;
+        free(raw);
+        return im;
     }
     FILE *f = fopen(path, "rb");
     if (!f) { fprintf(stderr, "Cannot load image \"%s\"\n", path); exit(0); }
-    size_t len = strlen(path);
-    if (len > 3 && 0 == strcmp(path + len - 3, ".u8")) {
-        if (fread(out, 1, n, f) != n) error("raw .u8 image has the wrong size");
-        fclose(f);
-        return;
-    }
     char magic[3] = {0};
     int iw = 0, ih = 0, maxv = 0;
-    if (fscanf(f, "%2s %d %d %d", magic, &iw, &ih, &maxv) != 4 || strcmp(magic, "P6") || maxv != 255)
+    if (fscanf(f, "%2s %d %d %d", magic, &iw, &ih, &maxv) != 4 || strcmp(magic, "P6") || maxv != 255 || iw < 1 || ih < 1)
         error("image must be a binary PPM (P6, maxval 255), a raw .u8 file or synthetic:<seed>; JPEG/PNG decoding is not built");
     fgetc(f);
-    if (iw != w || ih != h || c != 3) error("PPM size must equal the network input (letterbox resize is not built)");
-    uint8_t *rgb = malloc((size_t)3 * w * h);
-    if (fread(rgb, 1, (size_t)3 * w * h, f) != (size_t)3 * w * h) error("PPM truncated");
-    for (int k = 0; k < 3; ++k)
-        for (int i = 0; i < w * h; ++i) out[(size_t)k * w * h + i] = rgb[3 * i + k];
-    free(rgb);
+    if (netc != 3) error("PPM input needs a 3-channel network");
+    uint8_t *rgb = malloc((size_t)3 * iw * ih);
+    if (fread(rgb, 1, (size_t)3 * iw * ih, f) != (size_t)3 * iw * ih) error("PPM truncated");
     fclose(f);
+    im.w = iw; im.h = ih; im.c = 3;
+    im.data = malloc((size_t)3 * iw * ih * sizeof(float));
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < iw * ih; ++i) im.data[(size_t)k * iw * ih + i] = (float)rgb[3 * i + k] / 255.f; /* ref :1386 */
+    free(rgb);
+    return im;
 }
 
 static void dump_layer(const char *dir, network *net, int i)
@@ -85,81 +111,179 @@ static void dump_layer(const char *dir, network *net, int i)
     }
 }
 
-static void test_detector(const char *cfgfile, const char *weightfile, const char *filename, float thresh, int batch,
-                          int accum, int store, const char *dumpdir, int use_graph, int iters, int gpu)
+typedef struct {
+    const char *datacfg, *cfgfile, *weightfile, *filename, *dumpdir, *packed_in, *packed_out;
+    float thresh, hier_thresh;
+    int batch, accum, store, use_graph, iters, gpu, boxes, quiet;
+    int rank, nranks;      /* -gpus with -bcast: this replica's rank; rank 0 reads the weights file, the others receive blobs */
+    const void *comm_id;   /* shared 128-byte RCCL unique id (NULL: every replica reads the file) */
+    double seconds; /* out: per forward pass */
+} detect_job;
+
+/* one network on one device: load, input path, predict, boxes, NMS, print */
+static void test_detector(detect_job *job)
 {
-    network *net = load_network((char *)cfgfile, (char *)weightfile, 0);
-    net->gpu_index = gpu;
-    net->accum_mode = accum;
-    net->store_mode = store;
-    net->dump_int32 = dumpdir != NULL;
-    net->use_graph = use_graph;
-    set_batch_network(net, batch);
-    uint8_t *img = malloc((size_t)net->inputs);
-    load_image_u8(filename, net->c, net->h, net->w, img);
-    /* float image as the reference sees it (X = u8/255), so that its dynamic layer-0 quantiser runs (src/blas.c:279) */
-    for (int b = 0; b < batch; ++b)
-        for (int k = 0; k < net->inputs; ++k) net->input[(size_t)b * net->inputs + k] = (float)img[k] / 255.0f;
-    quantization_weights_and_activations(net);
-    double t0 = what_time_is_it_now();
-    for (int it = 0; it < iters; ++it) network_predict(net, net->input);
-    double dt = (what_time_is_it_now() - t0) / iters;
-    printf("%s: Predicted in %f seconds. (batch %d, %.1f images/s, accum=%s, parity=%s)\n", filename, dt, batch,
-           batch / dt, accum == MI355_ACC_EXACT ? "exact" : "ref-f32", store == MI355_STORE_WRAP ? "wrap" : "saturate");
-    /* ref: get_network_boxes (src/network.c:583-640) -> get_yolo_detections, here decoded on the device; NMS / drawing are
-     * host-side post-processing outside the INT8 path: the boxes above thresh are printed instead */
-    for (int i = 0; i < net->n; ++i) {
-        layer *l = &net->layers[i];
-        if (l->type != YOLO) continue;
-        const int cap = l->n * l->h * l->w, rl = 6 + l->classes;
-        float *recs = calloc((size_t)batch * cap * rl, sizeof(float));
-        int *counts = calloc((size_t)batch, sizeof(int));
-        /* the image is handed over at network size (no letterbox resize built), so the box correction is the identity */
-        network_yolo_detections_gpu(net, i, net->w, net->h, thresh, 1, recs, cap, counts);
-        printf("yolo layer %d (%dx%d): %d boxes with objectness above %.2f in image 0\n", i, l->w, l->h, counts[0], thresh);
-        for (int k = 0; k < counts[0] && k < 5; ++k) {
-            const float *r = recs + (size_t)k * rl;
-            int best = 0;
-            for (int c = 1; c < l->classes; ++c)
-                if (r[6 + c] > r[6 + best]) best = c;
-            printf("  cell %d anchor %d: class %d %.0f%%  box x %.4f y %.4f w %.4f h %.4f\n", (int)r[0] / l->n, (int)r[0] % l->n,
-                   best, 100.f * r[6 + best], r[1], r[2], r[3], r[4]);
-        }
-        free(recs);
-        free(counts);
+    char **names = NULL;
+    int nnames = 0;
+    if (job->datacfg) {
+        char *name_list = data_cfg_find(job->datacfg, "names");
+        if (name_list) { names = get_labels(name_list, &nnames); free(name_list); }
+        else fprintf(stderr, "%s has no names= entry: classes are printed by index\n", job->datacfg);
     }
-    if (dumpdir) for (int i = 0; i < net->n; ++i) dump_layer(dumpdir, net, i);
-    free(img);
+    network *net;
+    if (job->packed_in || (job->comm_id && job->rank != 0)) { /* deployed model / broadcast receiver: cfg only, blobs arrive packed */
+        net = parse_network_cfg((char *)job->cfgfile, 0);
+    } else {
+        net = load_network((char *)job->cfgfile, (char *)job->weightfile, 0);
+    }
+    net->gpu_index = job->gpu;
+    net->accum_mode = job->accum;
+    net->store_mode = job->store;
+    net->dump_int32 = job->dumpdir != NULL;
+    net->use_graph = job->use_graph;
+    set_batch_network(net, job->batch);
+    if (job->packed_in) network_load_packed(net, (char *)job->packed_in);
+    if (job->comm_id) { /* one-shot RCCL broadcast of the packed weights from replica 0 (xGMI), ~9 MB for yolov3-tiny */
+        void *comm = NULL;
+        if (mi355_init(job->gpu) || mi355_comm_init(&comm, job->nranks, job->comm_id, job->rank)) {
+            fprintf(stderr, "RCCL: %s %s\n", mi355_last_error(), mi355_comm_last_error());
+            error("mi355_comm_init");
+        }
+        if (job->rank == 0 && !job->packed_in) quantization_prep_host(net, 1.0f / 255.0f, 0);
+        network_bcast_packed(net, comm, job->rank, 0);
+        mi355_comm_destroy(comm);
+    }
+
+    image im = load_image_any(job->filename, net->c, net->h, net->w);
+    /* input path on the device: the float image goes up once, letterbox_image + the layer-0 quantiser run in HBM */
+    float *im_gpu = NULL;
+    const size_t imbytes = (size_t)im.c * im.h * im.w * sizeof(float);
+    if (mi355_init(job->gpu) || mi355_alloc((void **)&im_gpu, imbytes) || mi355_h2d(im_gpu, im.data, imbytes, NULL) || mi355_stream_sync(NULL)) {
+        fprintf(stderr, "MI355: %s\n", mi355_last_error());
+        error("cannot stage the image on the device (this build has no CPU data path)");
+    }
+    for (int b = 0; b < job->batch; ++b) network_letterbox_input_gpu(net, b, im_gpu, im.w, im.h);
+    network_quantize_input_gpu(net); /* == quantization_weights_and_activations on the letterboxed floats (ref :918) */
+    if (job->packed_out) network_save_packed(net, (char *)job->packed_out);
+
+    double t0 = what_time_is_it_now();
+    for (int it = 0; it < job->iters; ++it) network_predict(net, net->input);
+    job->seconds = (what_time_is_it_now() - t0) / job->iters;
+    if (!job->quiet)
+        printf("%s: Predicted in %f seconds. (batch %d, %.1f images/s, gpu %d, accum=%s, parity=%s)\n", job->filename, job->seconds,
+               job->batch, job->batch / job->seconds, job->gpu, job->accum == MI355_ACC_EXACT ? "exact" : "ref-f32",
+               job->store == MI355_STORE_WRAP ? "wrap" : "saturate");
+
+    int classes = 0;
+    for (int i = 0; i < net->n; ++i)
+        if (net->layers[i].type == YOLO) classes = net->layers[i].classes; /* ref: `l = net->layers[net->n-1]` (:910) */
+    if (classes && !job->quiet) {
+        const float nms = .45f; /* ref :892 */
+        int nboxes = 0;
+        detection *dets = get_network_boxes(net, im.w, im.h, job->thresh, job->hier_thresh, 0, 1, &nboxes);
+        printf("%d\n", nboxes);
+        printf("-----------------------\n");
+        if (nms) do_nms_sort(dets, nboxes, classes, nms);
+        for (int i = 0; i < nboxes; ++i) /* draw_detections' console output (src/image.c:246-257) */
+            for (int j = 0; j < classes; ++j)
+                if (dets[i].prob[j] > job->thresh) {
+                    if (names && j < nnames) printf("%s: %.0f%%\n", names[j], dets[i].prob[j] * 100);
+                    else printf("class %d: %.0f%%\n", j, dets[i].prob[j] * 100);
+                    if (job->boxes)
+                        printf("box: class %d prob %.9g x %.9g y %.9g w %.9g h %.9g\n", j, dets[i].prob[j], dets[i].bbox.x,
+                               dets[i].bbox.y, dets[i].bbox.w, dets[i].bbox.h);
+                }
+        free_detections(dets, nboxes);
+    }
+    if (job->dumpdir) for (int i = 0; i < net->n; ++i) dump_layer(job->dumpdir, net, i);
+    mi355_free(im_gpu);
+    free(im.data);
+    for (int i = 0; i < nnames; ++i) free(names[i]);
+    free(names);
     free_network(net);
+}
+
+static void *detector_thread(void *p)
+{
+    test_detector((detect_job *)p);
+    return NULL;
 }
 
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s detector test <data> <cfg> <weights> <image> [-thresh t] [-i gpu] [-batch B] "
-                        "[-accum exact|ref-f32] [-parity wrap|saturate] [-dump dir] [-graph] [-n iters]\n", argv[0]);
+        fprintf(stderr, "usage: %s detector test <data> <cfg> <weights> <image> [-thresh t] [-i gpu | -gpus a,b,..] [-batch B] "
+                        "[-accum exact|ref-f32] [-parity wrap|saturate] [-dump dir] [-graph] [-n iters] [-boxes] "
+                        "[-save_packed file] [-packed file] [-bcast]\n", argv[0]);
         return 0;
     }
-    int gpu = atoi(find_char_arg(argc, argv, "-i", "0"));
+    detect_job job;
+    memset(&job, 0, sizeof(job));
+    job.gpu = atoi(find_char_arg(argc, argv, "-i", "0"));
+    const char *gpu_list = find_char_arg(argc, argv, "-gpus", NULL);
     if (find_arg(argc, argv, "-nogpu")) error("-nogpu: this build has no CPU data path");
     if (find_arg(argc, argv, "-close_quantization")) error("-close_quantization: the float path is not built");
-    float thresh = (float)atof(find_char_arg(argc, argv, "-thresh", ".5"));
-    int batch = atoi(find_char_arg(argc, argv, "-batch", "1"));
+    job.thresh = (float)atof(find_char_arg(argc, argv, "-thresh", ".5"));
+    job.hier_thresh = (float)atof(find_char_arg(argc, argv, "-hier", ".5"));
+    job.batch = atoi(find_char_arg(argc, argv, "-batch", "1"));
     const char *accum_s = find_char_arg(argc, argv, "-accum", "exact");
     const char *parity_s = find_char_arg(argc, argv, "-parity", "wrap");
-    const char *dumpdir = find_char_arg(argc, argv, "-dump", NULL);
-    int use_graph = find_arg(argc, argv, "-graph");
-    int iters = atoi(find_char_arg(argc, argv, "-n", "1"));
-    int accum = 0 == strcmp(accum_s, "ref-f32") ? MI355_ACC_REF_F32 : MI355_ACC_EXACT;
-    int store = 0 == strcmp(parity_s, "saturate") ? MI355_STORE_SATURATE : MI355_STORE_WRAP;
-    if (0 == strcmp(argv[1], "detector")) {
-        if (argc < 7 || !argv[2] || strcmp(argv[2], "test")) {
-            fprintf(stderr, "only `detector test` is part of the INT8 inference path (train/valid/recall: SURVEY.md 2 rows 12,22)\n");
-            return 0;
-        }
-        test_detector(argv[4], argv[5], argv[6], thresh, batch, accum, store, dumpdir, use_graph, iters < 1 ? 1 : iters, gpu);
-    } else {
+    job.dumpdir = find_char_arg(argc, argv, "-dump", NULL);
+    job.packed_in = find_char_arg(argc, argv, "-packed", NULL);
+    job.packed_out = find_char_arg(argc, argv, "-save_packed", NULL);
+    job.use_graph = find_arg(argc, argv, "-graph");
+    job.boxes = find_arg(argc, argv, "-boxes");
+    const int bcast = find_arg(argc, argv, "-bcast");
+    job.iters = atoi(find_char_arg(argc, argv, "-n", "1"));
+    if (job.iters < 1) job.iters = 1;
+    if (job.batch < 1) job.batch = 1;
+    job.accum = 0 == strcmp(accum_s, "ref-f32") ? MI355_ACC_REF_F32 : MI355_ACC_EXACT;
+    job.store = 0 == strcmp(parity_s, "saturate") ? MI355_STORE_SATURATE : MI355_STORE_WRAP;
+    if (strcmp(argv[1], "detector")) {
         fprintf(stderr, "Not an option: %s\n", argv[1]);
+        return 0;
     }
+    if (argc < 7 || !argv[2] || strcmp(argv[2], "test") || !argv[3] || !argv[4] || !argv[5] || !argv[6]) {
+        fprintf(stderr, "only `detector test <data> <cfg> <weights> <image>` is part of the INT8 inference path (train/valid/recall: SURVEY.md 2 rows 12,22)\n");
+        return 0;
+    }
+    job.datacfg = argv[3]; job.cfgfile = argv[4]; job.weightfile = argv[5]; job.filename = argv[6];
+    if (!gpu_list) {
+        test_detector(&job);
+        return 0;
+    }
+    /* -gpus a,b,c (ref: examples/detector.c:954-977 parses the same list for training): one host thread per device, each
+     * with its own network replica and its own `-batch` images -- images shard embarrassingly, no steady-state traffic.
+     * Weights reach every device from the file, or with -bcast from replica 0 by one RCCL broadcast (mi355_bcast_blob). */
+    int gpus[64], ngpus = 0;
+    char *list = malloc(strlen(gpu_list) + 1);
+    strcpy(list, gpu_list);
+    for (char *tok = strtok(list, ","); tok && ngpus < 64; tok = strtok(NULL, ",")) gpus[ngpus++] = atoi(tok);
+    if (ngpus < 1) error("-gpus: empty list");
+    if (mi355_device_count() < 1) error("no HIP device visible (this build has no CPU data path)");
+    static char comm_id[128];
+    if (bcast && mi355_comm_unique_id(comm_id)) {
+        fprintf(stderr, "RCCL: %s\n", mi355_comm_last_error());
+        error("-bcast needs librccl");
+    }
+    detect_job *jobs = calloc((size_t)ngpus, sizeof(detect_job));
+    pthread_t *th = calloc((size_t)ngpus, sizeof(pthread_t));
+    for (int g = 0; g < ngpus; ++g) {
+        jobs[g] = job;
+        jobs[g].gpu = gpus[g];
+        jobs[g].rank = g; jobs[g].nranks = ngpus;
+        jobs[g].comm_id = bcast ? comm_id : NULL;
+        jobs[g].quiet = g != 0; /* device 0 of the list prints the detections */
+        jobs[g].dumpdir = g == 0 ? job.dumpdir : NULL;
+        jobs[g].packed_out = g == 0 ? job.packed_out : NULL;
+        if (pthread_create(&th[g], NULL, detector_thread, &jobs[g])) error("pthread_create");
+    }
+    double slowest = 0;
+    for (int g = 0; g < ngpus; ++g) {
+        pthread_join(th[g], NULL);
+        if (jobs[g].seconds > slowest) slowest = jobs[g].seconds;
+    }
+    printf("%d GPUs x batch %d: %.1f images/s (slowest replica %f s per pass)\n", ngpus, job.batch, ngpus * job.batch / slowest, slowest);
+    free(jobs); free(th); free(list);
     return 0;
 }

@@ -658,17 +658,23 @@ static size_t l0_record_bytes(const layer *l)
     return (sz + 15) & ~(size_t)15;
 }
 
-size_t network_packed_size(network *net)
+size_t network_packed_size(network *net) /* a function of the cfg alone: every rank knows it without communication */
 {
-    if (!net->layers[0].blob_host) error("network_packed_size before prep");
     size_t sz = sizeof(pack_head) + (size_t)net->n * sizeof(pack_rec);
     sz = (sz + 15) & ~(size_t)15;
-    for (int i = 0; i < net->n; ++i) sz += (net->layers[i].blob_bytes + 15) & ~(size_t)15;
+    for (int i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        if (l->type != CONVOLUTIONAL) continue;
+        const size_t b = mi355_conv_pack_size(l->n, l->c, l->size);
+        if (!b) error("network_packed_size: unsupported convolution shape");
+        sz += (b + 15) & ~(size_t)15;
+    }
     return sz + l0_record_bytes(&net->layers[0]);
 }
 
 void network_export_packed(network *net, void *buf)
 {
+    if (!net->layers[0].blob_host) error("network_export_packed before the host prep");
     char *p = buf;
     const size_t total = network_packed_size(net);
     memset(buf, 0, total);
@@ -805,6 +811,30 @@ void network_import_packed_gpu(network *net, const void *dev_buf, size_t bytes)
     check_mi355(mi355_stream_sync(NULL), "sync");
     network_import_packed(net, host, bytes);
     free(host);
+}
+
+/* Multi-GPU start-up behind the C ABI (SURVEY 8(b) `mi355_bcast_weights`, 8(e)): the root rank holds a prepared network
+ * (weights file read, per-channel integers derived, blobs packed); every rank calls this with its communicator rank and
+ * ends up with the packed state on its device.  One RCCL broadcast of network_packed_size() bytes, in place in HBM. */
+void network_bcast_packed(network *net, void *comm, int rank, int root)
+{
+    check_mi355(mi355_init(net->gpu_index), "mi355_init");
+    if (!net->stream) check_mi355(mi355_stream_create(&net->stream), "stream");
+    const size_t sz = network_packed_size(net);
+    void *dev = NULL;
+    check_mi355(mi355_alloc(&dev, sz), "alloc packed");
+    void *host = NULL;
+    if (rank == root) {
+        host = malloc(sz);
+        network_export_packed(net, host);
+        check_mi355(mi355_h2d(dev, host, sz, net->stream), "upload packed");
+    }
+    int rc = mi355_bcast_blob(comm, dev, sz, root, net->stream);
+    if (rc) { fprintf(stderr, "%s\n", mi355_comm_last_error()); error("mi355_bcast_blob"); }
+    check_mi355(mi355_stream_sync(net->stream), "sync");
+    free(host);
+    if (rank != root) network_import_packed_gpu(net, dev, sz);
+    mi355_free(dev);
 }
 
 void free_network(network *net)
