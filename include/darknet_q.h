@@ -123,6 +123,9 @@ struct network {
     float *quant_mm_gpu;      /* device scratch of the layer-0 quantiser: max, min of the float image */
     float *input_gpu;         /* batch x inputs floats on the device: the letterboxed images of the device input path */
     mi355_tensor input_t;     /* cs==4 image tensor */
+    mi355_tensor input_nchw_t; /* input_uint8_gpu described as it is (planar): layer 0 reads it in place where its kernel can */
+    int *input_direct_p;      /* executor -> layer 0: where to clear input_direct (the network travels by value) */
+    int input_direct;         /* 1: layer 0 is fed input_nchw_t, no conversion pass; cleared by the first MI355_EINVAL */
     const mi355_tensor *cur_t; /* uint8 hand-off: the reference's `net.input_uint8 = l.output_uint8_final` */
     const float *cur_f32_gpu;  /* float hand-off: `net.input = l.output` */
 

@@ -100,6 +100,12 @@ typedef struct mi355_tensor {
 
 /* Fill in cs/lead/tail for (B,H,W,C) and return the byte size of the buffer (0 on bad dims). data untouched. */
 size_t mi355_tensor_describe(mi355_tensor *t, int B, int H, int W, int C);
+/* The reference's own input layout as a tensor descriptor: [B][C][H][W] uint8 planes, plain bytes, no pad cells (cs = 1,
+ * lead = tail = 0) -- `net.input_uint8` as it is (ref: src/network.c:248).  Accepted as `x` by mi355_conv_forward /
+ * mi355_conv_pool_forward for the 3-channel first layer only (exact mode, 16 or 32 filters, even map, W % 4 == 0): the kernel
+ * reads the three colour planes in place and pads with desc.zp_in, so the network input needs no layout conversion pass.
+ * Other shapes return MI355_EINVAL: convert with mi355_nchw_to_tensor then.  Returns the byte size. */
+size_t mi355_tensor_describe_nchw(mi355_tensor *t, int B, int H, int W, int C);
 /* Set every byte of the buffer (pads included) to the biased zero point (zp ^ 0x80). */
 int mi355_tensor_fill(const mi355_tensor *t, uint8_t zero_point, void *stream);
 /* Reference layout <-> device layout.  nchw is the reference's `net.input_uint8` / `l.output_uint8_final`

@@ -1,0 +1,102 @@
+"""GPU suite, part 5 (`-m gpu`): kernel variants added in round 2, each against the kernel / oracle it must equal."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from yolo_quantization_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+C = binding.C
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    binding.init(0)
+
+
+def _rand_layer(rng, n, c, k, m_lo=2.0 ** -11, m_hi=2.0 ** -7):
+    K = c * k * k
+    wq = rng.integers(0, 256, (n, K), dtype=np.uint8)
+    zp_w = rng.integers(90, 166, n, dtype=np.uint8)
+    bias = rng.integers(-20000, 20000, n).astype(np.int32)
+    M = rng.uniform(m_lo, m_hi, n)
+    shift = np.floor(-np.log2(M)).astype(int)
+    M0 = np.round(M * 2.0 ** shift * 2 ** 31)
+    return wq, zp_w, bias, M0 * 2.0 ** -31, 2.0 ** -shift.astype(np.float64)
+
+
+def _planar_tensor(x):
+    """The reference's [B][3][H][W] bytes on the device, described in place (mi355_tensor_describe_nchw)."""
+    S = binding.shim()
+    S.mi355_tensor_describe_nchw.restype = C.c_size_t
+    S.mi355_tensor_describe_nchw.argtypes = [C.POINTER(binding.Tensor), C.c_int, C.c_int, C.c_int, C.c_int]
+    B, Cc, H, W = x.shape
+    t = binding.Tensor()
+    assert S.mi355_tensor_describe_nchw(C.byref(t), B, H, W, Cc) == x.size
+    buf = binding.DevBuf.from_numpy(x)
+    t.data = buf.ptr
+    return t, buf
+
+
+@pytest.mark.parametrize("n,act,store", [(16, "leaky", binding.STORE_WRAP), (32, "relu6", binding.STORE_SATURATE), (16, "linear", binding.STORE_WRAP)])
+@pytest.mark.parametrize("B,H,W,zp_in", [(2, 32, 64, 0), (1, 48, 100, 37), (3, 18, 36, 255), (1, 416, 416, 0)])
+def test_first_layer_reads_nchw_planes_in_place(n, act, store, B, H, W, zp_in):
+    """The first-layer MFMA kernels fed the reference's colour planes directly (no nchw -> 4-byte-cell conversion pass):
+    with and without the fused 2x2/2 maxpool, bytes equal the oracle's conv (+ maxpool); ragged tile edges, non-zero input
+    zero point in the pad, every W % 4 == 0."""
+    rng = np.random.default_rng(n + B + H + W)
+    x = rng.integers(0, 256, (B, 3, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, 3, 3, 2.0 ** -8, 2.0 ** -5)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, 3, 3, bias, mv, sv))
+    xt, keep = _planar_tensor(x)
+    d = binding.ConvDesc(n, 3, 3, 1, 1, binding.ACT[act], store, binding.ACC_EXACT, zp_in, 23, 0.05)
+    S = binding.shim()
+    want = np.stack([oracle.requant(oracle.conv_acc(x[b], wq, zp_w, 3, 1, 1, zp_in), bias, mv, sv, 23, oracle.ACT[act], store).reshape(n, H, W)
+                     for b in range(B)])
+    y = binding.DevTensor(B, H, W, n, 23)
+    binding.check(S.mi355_conv_forward(C.byref(d), C.byref(xt), blob.ptr, None, None, y.ref(), None, None, None), "conv (planar input)")
+    assert S.mi355_last_conv_kernel() == 1
+    assert np.array_equal(y.to_nchw(), want)
+    yp = binding.DevTensor(B, H // 2, W // 2, n, 23)
+    binding.check(S.mi355_conv_pool_forward(C.byref(d), C.byref(xt), blob.ptr, None, yp.ref(), None), "conv+pool (planar input)")
+    pooled = np.stack([oracle.maxpool_u8(want[b], 2, 2, 1) for b in range(B)])
+    assert np.array_equal(yp.to_nchw(), pooled)
+
+
+def test_planar_input_is_refused_outside_its_domain():
+    rng = np.random.default_rng(0)
+    S = binding.shim()
+    for (n, H, W) in ((20, 32, 32), (16, 32, 34), (16, 31, 32)):   # filters not 16 / 32; W % 4 != 0; odd map
+        x = rng.integers(0, 256, (1, 3, H, W), dtype=np.uint8)
+        wq, zp_w, bias, mv, sv = _rand_layer(rng, n, 3, 3)
+        blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, 3, 3, bias, mv, sv))
+        xt, keep = _planar_tensor(x)
+        d = binding.ConvDesc(n, 3, 3, 1, 1, binding.ACT["leaky"], 0, 0, 0, 23, 0.05)
+        y = binding.DevTensor(1, H, W, n, 23)
+        assert S.mi355_conv_forward(C.byref(d), C.byref(xt), blob.ptr, None, None, y.ref(), None, None, None) == -22
+
+
+def test_net_falls_back_to_conversion_when_layer0_cannot_read_planes(cfg_dir, tmp_path):
+    """A net whose first layer is outside the in-place kernel's domain (24 filters) still runs: the host converts the input
+    and clears the flag; bytes equal the oracle."""
+    txt = open(os.path.join(cfg_dir, "tiny_unit.cfg")).read().replace("filters=16", "filters=48", 1)
+    cfg = str(tmp_path / "t.cfg")
+    open(cfg, "w").write(txt)
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=2)
+    x = synth.synth_image_u8(3, 12, 12, seed=5, batch=2)
+    net = binding.Net(cfg, wts, batch=2)
+    net.prepare_fixed(1.0 / 255.0, 0)
+    net.push_input(x)
+    net.forward(); net.forward(); net.sync()
+    onet = oracle.OracleNet(cfg, wts)
+    onet.prepare(np.float32(1.0 / 255.0), 0)
+    for b in range(2):
+        want = onet.forward(x[b])
+        for i, inf in enumerate(net.info):
+            if inf["type"] != binding.T_YOLO and not net.is_fused(i):
+                per = inf["outputs"]
+                assert np.array_equal(net.pull(i)["u8"][b * per:(b + 1) * per], want[i]["u8"].ravel()), (b, i)
+    net.close()

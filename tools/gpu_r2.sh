@@ -12,6 +12,10 @@ tests)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log ;;
 newtests)
   timeout 2400 python -m pytest tests/test_gpu_refpin.py tests/test_gpu_residual.py -m gpu -x -q 2>&1 | tail -60 | tee gpurun_out/pytest_gpu_new.log ;;
+k2tests)
+  timeout 2400 python -m pytest tests/test_gpu_r2_kernels.py -m gpu -x -q 2>&1 | tail -60 | tee gpurun_out/pytest_gpu_k2.log ;;
+quicktests)
+  timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_r2_kernels.py -m gpu -x -q 2>&1 | tail -30 | tee gpurun_out/pytest_gpu_quick.log ;;
 bench)
   timeout 900 python bench.py --steps 200 --warmup 20 --layers 2>gpurun_out/bench.err | tee gpurun_out/bench.json
   tail -40 gpurun_out/bench.err

@@ -253,10 +253,15 @@ int conv_ref_f32_launch(AuxArgs &a, hipStream_t st)
 // a workgroup walks 8 x 16 pooled patches persistently, staging the next 18 x 34 cell image (biased to signed bytes)
 // through registers into a double-buffered LDS plane.  Result bytes are identical to conv_first_pool_u8_kernel's.
 // ---------------------------------------------------------------------------------------------------------------
-template <int ACT, bool SAT, int NM>
+// cells per LDS image row of the first-layer MFMA kernels: 34 (x = 32 tx - 1 .. + 32) from the 4-byte-cell tensor, 40
+// (x = 32 tx - 4 .. + 35, whole 4-pixel groups) when the image is read from the reference's colour planes in place
+__host__ __device__ constexpr int first_stage_rowc(bool planar) { return planar ? 40 : 34; }
+
+template <int ACT, bool SAT, int NM, bool PLANAR>
 __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxArgs a)
 {
-    __shared__ uint32_t img[2][18 * 34];
+    constexpr int ROWC = first_stage_rowc(PLANAR), XO = PLANAR ? 3 : 0;
+    __shared__ __attribute__((aligned(16))) uint32_t img[2][18 * ROWC];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile rows and output rows stay on the scalar unit
@@ -330,15 +335,47 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         if (p.tx >= tiles_x) { p.tx -= tiles_x; ++p.ty; }
         if (p.ty >= tiles_y) { p.ty -= tiles_y; ++p.b; }
     };
+    // PLANAR (the reference's [B][3][H][W] uint8 planes read in place: no layout conversion pass): thread t < 180 owns image
+    // row t / 10 and the 4-pixel group t % 10 of the 40-cell LDS row (image x = 32 tx - 4 + 4 q .. + 3): one aligned dword
+    // from each colour plane, interleaved into four (c0, c1, c2, 0) cells on the way into LDS.  W % 4 == 0, so a group is
+    // either inside the image or entirely pad (cells of the input zero point, ref: src/convolutional_layer.c:703-705).
+    const int prow_ix = tid / 10, pq = tid - prow_ix * 10;
+    const uint32_t zsplat = (uint32_t)a.zp_in * 0x01010101u;
     auto fetch = [&](const Pos &p, uint32_t(&v)[3]) {  // cell indices fit an int (the launcher checks in_cells)
-        const int org = a.in_lead + (p.b * (a.H + 1) + 16 * p.ty) * W1 + 32 * p.tx - 1;  // image cell (0, 0)
+        if constexpr (PLANAR) {
+            const int y = 16 * p.ty - 1 + prow_ix, x0 = 32 * p.tx - 4 + 4 * pq;
+            const bool inside = tid < 180 && y >= 0 && y < a.H && x0 >= 0 && x0 < a.W;
+            const uint8_t *src = a.x + ((size_t)p.b * 3 * a.H + (inside ? y : 0)) * a.W + (inside ? x0 : 0);
+            const size_t plane = (size_t)a.H * a.W;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] = xc[min(max(org + soff[k], 0), a.in_cells - 1)];
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t t = *reinterpret_cast<const uint32_t *>(src + k * plane);
+                v[k] = inside ? t : zsplat;
+            }
+        } else {
+            const int org = a.in_lead + (p.b * (a.H + 1) + 16 * p.ty) * W1 + 32 * p.tx - 1;  // image cell (0, 0)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = xc[min(max(org + soff[k], 0), a.in_cells - 1)];
+        }
     };
     auto stash = [&](int buf, const uint32_t(&v)[3]) {
+        if constexpr (PLANAR) {
+            if (tid < 180) {
+                uint4 c;
+                // byte i of the three plane dwords -> cell i = (c0, c1, c2, 0), then x' = x - 128 (pad byte: weight 0)
+                const uint32_t lo01 = __builtin_amdgcn_perm(v[1], v[0], 0x05010400u);  // (p0.b0, p1.b0, p0.b1, p1.b1)
+                const uint32_t hi01 = __builtin_amdgcn_perm(v[1], v[0], 0x07030602u);  // (p0.b2, p1.b2, p0.b3, p1.b3)
+                c.x = __builtin_amdgcn_perm(v[2], lo01, 0x0c040100u) ^ 0x80808080u;    // (lo01.b0, lo01.b1, p2.b0, 0)
+                c.y = __builtin_amdgcn_perm(v[2], lo01, 0x0c050302u) ^ 0x80808080u;
+                c.z = __builtin_amdgcn_perm(v[2], hi01, 0x0c060100u) ^ 0x80808080u;
+                c.w = __builtin_amdgcn_perm(v[2], hi01, 0x0c070302u) ^ 0x80808080u;
+                *reinterpret_cast<uint4 *>(&img[buf][prow_ix * ROWC + 4 * pq]) = c;
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (tid + 256 * k < 18 * 34) img[buf][tid + 256 * k] = v[k] ^ 0x80808080u;  // x' = x - 128 (pad byte: weight 0)
+            for (int k = 0; k < 3; ++k)
+                if (tid + 256 * k < 18 * 34) img[buf][tid + 256 * k] = v[k] ^ 0x80808080u;  // x' = x - 128 (pad byte: weight 0)
+        }
     };
 
     int tile = blockIdx.x;
@@ -365,12 +402,12 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
             const int prow = 8 * ty + pr, pcol = 16 * tx + pc;
             const bool valid = prow < OH && pcol < OW;
             // two image rows x five cells feed the four window positions of this lane's k-group
-            const uint32_t *p0 = img[buf] + (2 * pr + (g < 3 ? g : 2)) * 34 + 2 * pc;
+            const uint32_t *p0 = img[buf] + (2 * pr + (g < 3 ? g : 2)) * ROWC + 2 * pc + XO;
             uint32_t rw[2][5];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 rw[0][i] = p0[i];
-                rw[1][i] = p0[34 + i];
+                rw[1][i] = p0[ROWC + i];
             }
             // wave-uniform part of the pooled cell (scalar arithmetic) + the lane's column (precomputed byte offset)
             const long rowcell = (long)a.pool_lead + ((long)b * (OH + 1) + (prow + 1)) * (OW + 1) + 16 * tx;
@@ -444,10 +481,11 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
 // The same kernel without the pool: the first layer of the non-tiny networks (YOLOv3's 3 -> 32 at full resolution) stores
 // every conv pixel.  Same tiling (a lane's four MFMAs are the 2x2 block of conv pixels at (2 prow + jy, 2 pcol + jx)), all
 // sixteen values of a lane requantised, four 4-byte stores per m-tile.
-template <int ACT, bool SAT, int NM>
+template <int ACT, bool SAT, int NM, bool PLANAR>
 __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a)
 {
-    __shared__ uint32_t img[2][18 * 34];
+    constexpr int ROWC = first_stage_rowc(PLANAR), XO = PLANAR ? 3 : 0;
+    __shared__ __attribute__((aligned(16))) uint32_t img[2][18 * ROWC];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile rows and output rows stay on the scalar unit
@@ -517,15 +555,47 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
         if (p.tx >= tiles_x) { p.tx -= tiles_x; ++p.ty; }
         if (p.ty >= tiles_y) { p.ty -= tiles_y; ++p.b; }
     };
+    // PLANAR (the reference's [B][3][H][W] uint8 planes read in place: no layout conversion pass): thread t < 180 owns image
+    // row t / 10 and the 4-pixel group t % 10 of the 40-cell LDS row (image x = 32 tx - 4 + 4 q .. + 3): one aligned dword
+    // from each colour plane, interleaved into four (c0, c1, c2, 0) cells on the way into LDS.  W % 4 == 0, so a group is
+    // either inside the image or entirely pad (cells of the input zero point, ref: src/convolutional_layer.c:703-705).
+    const int prow_ix = tid / 10, pq = tid - prow_ix * 10;
+    const uint32_t zsplat = (uint32_t)a.zp_in * 0x01010101u;
     auto fetch = [&](const Pos &p, uint32_t(&v)[3]) {  // cell indices fit an int (the launcher checks in_cells)
-        const int org = a.in_lead + (p.b * (a.H + 1) + 16 * p.ty) * W1 + 32 * p.tx - 1;  // image cell (0, 0)
+        if constexpr (PLANAR) {
+            const int y = 16 * p.ty - 1 + prow_ix, x0 = 32 * p.tx - 4 + 4 * pq;
+            const bool inside = tid < 180 && y >= 0 && y < a.H && x0 >= 0 && x0 < a.W;
+            const uint8_t *src = a.x + ((size_t)p.b * 3 * a.H + (inside ? y : 0)) * a.W + (inside ? x0 : 0);
+            const size_t plane = (size_t)a.H * a.W;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] = xc[min(max(org + soff[k], 0), a.in_cells - 1)];
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t t = *reinterpret_cast<const uint32_t *>(src + k * plane);
+                v[k] = inside ? t : zsplat;
+            }
+        } else {
+            const int org = a.in_lead + (p.b * (a.H + 1) + 16 * p.ty) * W1 + 32 * p.tx - 1;  // image cell (0, 0)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = xc[min(max(org + soff[k], 0), a.in_cells - 1)];
+        }
     };
     auto stash = [&](int buf, const uint32_t(&v)[3]) {
+        if constexpr (PLANAR) {
+            if (tid < 180) {
+                uint4 c;
+                // byte i of the three plane dwords -> cell i = (c0, c1, c2, 0), then x' = x - 128 (pad byte: weight 0)
+                const uint32_t lo01 = __builtin_amdgcn_perm(v[1], v[0], 0x05010400u);  // (p0.b0, p1.b0, p0.b1, p1.b1)
+                const uint32_t hi01 = __builtin_amdgcn_perm(v[1], v[0], 0x07030602u);  // (p0.b2, p1.b2, p0.b3, p1.b3)
+                c.x = __builtin_amdgcn_perm(v[2], lo01, 0x0c040100u) ^ 0x80808080u;    // (lo01.b0, lo01.b1, p2.b0, 0)
+                c.y = __builtin_amdgcn_perm(v[2], lo01, 0x0c050302u) ^ 0x80808080u;
+                c.z = __builtin_amdgcn_perm(v[2], hi01, 0x0c060100u) ^ 0x80808080u;
+                c.w = __builtin_amdgcn_perm(v[2], hi01, 0x0c070302u) ^ 0x80808080u;
+                *reinterpret_cast<uint4 *>(&img[buf][prow_ix * ROWC + 4 * pq]) = c;
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (tid + 256 * k < 18 * 34) img[buf][tid + 256 * k] = v[k] ^ 0x80808080u;  // x' = x - 128 (pad byte: weight 0)
+            for (int k = 0; k < 3; ++k)
+                if (tid + 256 * k < 18 * 34) img[buf][tid + 256 * k] = v[k] ^ 0x80808080u;  // x' = x - 128 (pad byte: weight 0)
+        }
     };
 
     int tile = blockIdx.x;
@@ -552,12 +622,12 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
             const int prow = 8 * ty + pr, pcol = 16 * tx + pc;
             const bool valid = prow < OH && pcol < OW;
             // two image rows x five cells feed the four window positions of this lane's k-group
-            const uint32_t *p0 = img[buf] + (2 * pr + (g < 3 ? g : 2)) * 34 + 2 * pc;
+            const uint32_t *p0 = img[buf] + (2 * pr + (g < 3 ? g : 2)) * ROWC + 2 * pc + XO;
             uint32_t rw[2][5];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 rw[0][i] = p0[i];
-                rw[1][i] = p0[34 + i];
+                rw[1][i] = p0[ROWC + i];
             }
             // wave-uniform part of the output cells (scalar arithmetic) + the lane's column (precomputed byte offset)
             const long rowcell = (long)a.out_lead + ((long)b * (a.H + 1) + (2 * prow + 1)) * W1 + 32 * tx;
@@ -616,28 +686,38 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
 template <int ACT, int NM>
 static int first_mfma_launch_sat(AuxArgs &a, hipStream_t st, int grid)
 {
-    if (a.store_mode == MI355_STORE_SATURATE)
-        hipLaunchKernelGGL((conv_first_mfma_pool_kernel<ACT, true, NM>), dim3(grid), dim3(256), 0, st, a);
+    if (a.planar) {
+        if (a.store_mode == MI355_STORE_SATURATE)
+            hipLaunchKernelGGL((conv_first_mfma_pool_kernel<ACT, true, NM, true>), dim3(grid), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_first_mfma_pool_kernel<ACT, false, NM, true>), dim3(grid), dim3(256), 0, st, a);
+    } else if (a.store_mode == MI355_STORE_SATURATE)
+        hipLaunchKernelGGL((conv_first_mfma_pool_kernel<ACT, true, NM, false>), dim3(grid), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_first_mfma_pool_kernel<ACT, false, NM>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_first_mfma_pool_kernel<ACT, false, NM, false>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
 
 template <int ACT, int NM>
 static int first_mfma_nopool_launch_sat(AuxArgs &a, hipStream_t st, int grid)
 {
-    if (a.store_mode == MI355_STORE_SATURATE)
-        hipLaunchKernelGGL((conv_first_mfma_kernel<ACT, true, NM>), dim3(grid), dim3(256), 0, st, a);
+    if (a.planar) {
+        if (a.store_mode == MI355_STORE_SATURATE)
+            hipLaunchKernelGGL((conv_first_mfma_kernel<ACT, true, NM, true>), dim3(grid), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_first_mfma_kernel<ACT, false, NM, true>), dim3(grid), dim3(256), 0, st, a);
+    } else if (a.store_mode == MI355_STORE_SATURATE)
+        hipLaunchKernelGGL((conv_first_mfma_kernel<ACT, true, NM, false>), dim3(grid), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_first_mfma_kernel<ACT, false, NM>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_first_mfma_kernel<ACT, false, NM, false>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
 
 // first layer without a pool on the matrix pipe; MI355_EINVAL outside its domain (the caller uses the VALU kernel)
 int conv_first_mfma_launch(AuxArgs &a, hipStream_t st)
 {
-    if ((a.n != 16 && a.n != 32) || !a.y || a.ypool || a.acc_out || a.y_f32 || (a.H & 1) || (a.W & 1) || !a.cwb || a.in_cs != 4)
-        return MI355_EINVAL;
+    if ((a.n != 16 && a.n != 32) || !a.y || a.ypool || a.acc_out || a.y_f32 || (a.H & 1) || (a.W & 1) || !a.cwb) return MI355_EINVAL;
+    if (a.planar ? ((a.W & 3) || (reinterpret_cast<size_t>(a.x) & 3)) : a.in_cs != 4) return MI355_EINVAL;
     if ((long)a.in_cells + 64L * (a.W + 1) >= (1L << 31)) return MI355_EINVAL;  // 32-bit cell arithmetic in the kernel
     const int OH = a.H / 2, OW = a.W / 2;
     const long ntiles = (long)a.B * ((OW + 15) / 16) * ((OH + 7) / 8);
@@ -655,8 +735,8 @@ int conv_first_mfma_launch(AuxArgs &a, hipStream_t st)
 // returns MI355_EINVAL when the shape is outside the MFMA kernel's domain (the caller uses the VALU kernel)
 int conv_first_mfma_pool_launch(AuxArgs &a, hipStream_t st)
 {
-    if ((a.n != 16 && a.n != 32) || a.y || a.acc_out || a.y_f32 || (a.H & 1) || (a.W & 1) || !a.cwb || a.in_cs != 4)
-        return MI355_EINVAL;
+    if ((a.n != 16 && a.n != 32) || a.y || a.acc_out || a.y_f32 || (a.H & 1) || (a.W & 1) || !a.cwb) return MI355_EINVAL;
+    if (a.planar ? ((a.W & 3) || (reinterpret_cast<size_t>(a.x) & 3)) : a.in_cs != 4) return MI355_EINVAL;
     if ((long)a.in_cells + 64L * (a.W + 1) >= (1L << 31)) return MI355_EINVAL;  // 32-bit cell arithmetic in the kernel
     const int OH = a.H / 2, OW = a.W / 2;
     const long ntiles = (long)a.B * ((OW + 15) / 16) * ((OH + 7) / 8);

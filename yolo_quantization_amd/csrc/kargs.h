@@ -63,6 +63,7 @@ struct AuxArgs {
     int pool_cs, pool_lead;
     const ConvBlobHeader *hdr;  // device copy of the blob header (data-dependent pow2 flag)
     const int32_t *cwb;         // cw + bias (first-layer MFMA kernel)
+    int planar;                 // x is the reference's [B][3][H][W] uint8 planes (no cells, no pads), read in place
 };
 
 struct PoolArgs {

@@ -176,9 +176,18 @@ size_t mi355_tensor_describe(mi355_tensor *t, int B, int H, int W, int C)
     return tensor_cells(t) * (size_t)t->cs;
 }
 
+size_t mi355_tensor_describe_nchw(mi355_tensor *t, int B, int H, int W, int C)
+{
+    if (!t || B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    t->B = B; t->H = H; t->W = W; t->C = C;
+    t->cs = 1; t->lead = 0; t->tail = 0;
+    return (size_t)B * C * H * W;
+}
+
 int mi355_tensor_fill(const mi355_tensor *t, uint8_t zero_point, void *stream)
 {
     if (!t || !t->data) return einval("tensor");
+    if (t->cs == 1) return einval("tensor_fill: a planar tensor has no pad cells");
     const size_t cells = tensor_cells(t);
     if (t->cs == 4) {
         const uint32_t v = (uint32_t)zero_point | ((uint32_t)zero_point << 8) | ((uint32_t)zero_point << 16);
@@ -406,6 +415,8 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     const int total_n = x->B * OH * OW;
     const int in_cells = (int)tensor_cells(x);
 
+    if (x->cs == 1 && (!h.first || d->accum_mode == MI355_ACC_REF_F32))
+        return einval("conv_forward: the planar (cs==1) layout is accepted for the exact-mode 3-channel first layer only");
     if (d->accum_mode == MI355_ACC_REF_F32 || h.first) {
         AuxArgs a;
         memset(&a, 0, sizeof(a));
@@ -430,16 +441,20 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
             return conv_ref_f32_launch(a, st);
         }
         g_last_kernel = 1;
-        if (x->cs != 4) return einval("conv_forward: first layer expects a cs==4 image tensor");
+        if (x->cs != 4 && x->cs != 1) return einval("conv_forward: first layer expects a cs==4 image tensor or the planar (cs==1) reference layout");
+        a.planar = x->cs == 1;
+        if (a.planar) a.in_cells = 0;
         if (ypool) {
             int rc = (mi355_debug_flags_get() & 1024) ? MI355_EINVAL : conv_first_mfma_pool_launch(a, st);
-            if (rc == MI355_EINVAL) rc = conv_first_pool_launch(a, st);
+            if (rc == MI355_EINVAL && !a.planar) rc = conv_first_pool_launch(a, st);
             return rc == MI355_OK ? MI355_OK : einval("conv_pool_forward: shape not fusable");
         }
         {  // no pool: the MFMA kernel where it applies (even maps, 16 / 32 filters, no dumps), else the VALU kernel
             const int rc = (mi355_debug_flags_get() & 1024) ? MI355_EINVAL : conv_first_mfma_launch(a, st);
             if (rc != MI355_EINVAL) return rc;
         }
+        if (a.planar) return einval("conv_forward: the planar input layout is served by the first-layer MFMA kernels only (16 / 32 filters, "
+                                    "even map, W % 4 == 0, no dumps); convert with mi355_nchw_to_tensor otherwise");
         return conv_first_launch(a, st);
     }
     if (x->cs % 16) return einval("conv_forward: x.cs must be a multiple of 16");

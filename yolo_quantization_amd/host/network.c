@@ -256,6 +256,9 @@ static void alloc_network_device(network *net)
     size_t bytes = mi355_tensor_describe(&net->input_t, net->batch, net->h, net->w, net->c);
     check_mi355(mi355_alloc(&net->input_t.data, bytes), "alloc input tensor");
     check_mi355(mi355_tensor_fill(&net->input_t, net->layers[0].input_data_uint8_zero_point[0], net->stream), "fill input");
+    mi355_tensor_describe_nchw(&net->input_nchw_t, net->batch, net->h, net->w, net->c);
+    net->input_nchw_t.data = net->input_uint8_gpu;
+    net->input_direct = net->c == 3 && !net->dump_int32;
     for (int i = 0; i < net->n; ++i) alloc_layer_device(net, i);
     plan_views(net);
     if (net->graph) { mi355_graph_destroy(net->graph); net->graph = NULL; }
@@ -493,9 +496,13 @@ static void run_layers(network *netp)
     if (netp->prof_ev && netp->prof_used < netp->prof_cap && !netp->use_graph && netp->prof_calls++ % netp->prof_stride == 0)
         ev = netp->prof_ev + (size_t)(netp->prof_used++) * (net.n + 2);
     if (ev) check_mi355(mi355_event_record(ev[0], net.stream), "event");
-    check_mi355(mi355_nchw_to_tensor(netp->input_uint8_gpu, &netp->input_t, net.stream), "input layout");
+    /* The first layer reads the reference's [B][3][H][W] planes in place where its kernel can (no conversion pass); else the
+     * input goes through the 4-byte-cell tensor.  The conv's forward_gpu falls back itself on MI355_EINVAL and clears the flag. */
+    const int direct = netp->input_direct && net.accum_mode == MI355_ACC_EXACT && !net.dump_int32;
+    if (!direct) check_mi355(mi355_nchw_to_tensor(netp->input_uint8_gpu, &netp->input_t, net.stream), "input layout");
     if (ev) check_mi355(mi355_event_record(ev[1], net.stream), "event");
-    net.cur_t = &netp->input_t;
+    net.cur_t = direct ? &netp->input_nchw_t : &netp->input_t;
+    net.input_direct_p = &netp->input_direct;
     net.cur_f32_gpu = NULL;
     for (int i = 0; i < net.n; ++i) {
         net.index = i;
