@@ -187,6 +187,8 @@ def main():
                 net = binding.Net(args.cfg, None, batch=B, gpu=local_rank, use_graph=args.graph)
             net.import_packed_gpu(blob.data_ptr(), nbytes)
 
+    if os.environ.get("BENCH_NO_DIRECT_INPUT") == "1":  # A/B: layer 0 through the 4-byte-cell conversion pass instead of reading the planes
+        net.set("input_direct", 0)
     # ---- synthetic input, resident in HBM in the reference layout before the timed region
     in_c, in_h, in_w = net.info[0]["c"], net.info[0]["h"], net.info[0]["w"]  # 3 x 416 x 416 for the headline cfg
     x = synth.synth_image_u8(in_c, in_h, in_w, seed=1000 + rank, batch=B)

@@ -102,6 +102,7 @@ struct layer {
     int fuse_next_upsample; /* this conv stores its pixels straight into the upsample layer's tensor after it */
     int conv_kernel;    /* kernel family that served this conv's last forward (mi355_last_conv_kernel) */
     int fuse_next_yolo; /* this quant_stop head conv also writes the activations of the yolo layer after it */
+    int fuse_next_shortcut; /* this conv's epilogue also does the quantized residual add of the [shortcut] after it */
     int prepared;
 };
 
@@ -139,6 +140,7 @@ struct network {
     float *fused_yolo_out;            /* run-time: yolo output buffer the conv being run has to fill, or NULL */
     int fused_yolo_classes;
     const mi355_tensor *fused_pool_t; /* executor -> conv forward_gpu: pooled output tensor of the fused pair */
+    const struct layer *fused_shortcut; /* executor -> conv forward_gpu: the [shortcut] layer whose add this conv performs, or NULL */
     int verbose;
     int prepared;
     int has_host_weights; /* load_weights ran: raw weights_uint8 / biases / scales of every layer are on the host */

@@ -163,6 +163,15 @@ int mi355_conv_yolo_forward(const mi355_conv_desc *desc, const mi355_tensor *x, 
 int mi355_conv_upsample_forward(const mi355_conv_desc *desc, const mi355_tensor *x, const void *blob, const mi355_tensor *y_up,
                                 int stride, void *stream);
 
+/* A convolution fused with the quantized residual add that follows it (`[shortcut] quantized=1`, mi355_shortcut_forward below):
+ * every requantised byte a of the convolution (zero point desc.zp_act) is combined with the byte b of `from` at the same
+ * pixel and channel, y_sum = clamp(zp_out + ((Ka*(a - zp_act) + Kb*(b - zp_from) + 2^15) >> 16)); the convolution's own
+ * tensor is not stored.  Stride-1 exact-mode 3x3 layers with 128 / 256 input channels (conv_ws3.hip: 16 of YOLOv3's 23 residual
+ * blocks); MI355_EINVAL otherwise and the caller runs the two layers separately (measured faster for the other kernels).  Bytes are identical to
+ * mi355_conv_forward + mi355_shortcut_forward. */
+int mi355_conv_shortcut_forward(const mi355_conv_desc *desc, const mi355_tensor *x, const void *blob, const mi355_tensor *from,
+                                const mi355_tensor *y_sum, int32_t Ka, int32_t Kb, uint8_t zp_from, uint8_t zp_out, void *stream);
+
 /* Tile configuration override for benchmarking (0 = auto). */
 int mi355_conv_set_tile(int bm, int bn);
 /* Development switches.  Bits 0..8 are timing ablations of the K loop (no DMA / no s_barrier / no MFMA / ...), compiled

@@ -100,3 +100,46 @@ def test_net_falls_back_to_conversion_when_layer0_cannot_read_planes(cfg_dir, tm
                 per = inf["outputs"]
                 assert np.array_equal(net.pull(i)["u8"][b * per:(b + 1) * per], want[i]["u8"].ravel()), (b, i)
     net.close()
+
+
+@pytest.mark.parametrize("B,c,n,H,W,act,fam", [(3, 128, 256, 19, 19, "relu6", 4), (2, 256, 512, 20, 18, "leaky", 4), (1, 128, 256, 76, 76, "leaky", 4),
+                                              (32, 256, 512, 38, 38, "leaky", 4)])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+def test_conv_with_fused_residual_add(B, c, n, H, W, act, fam, store):
+    """mi355_conv_shortcut_forward (the 3x3 conv of a residual block + the `[shortcut] quantized=1` after it in one kernel)
+    equals conv -> requantise -> orc_shortcut_u8 of the oracle (conv_ws3.hip: the 128- / 256-channel 3x3 layers, 16 of YOLOv3's
+    23 residual blocks; the other kernels refuse and the host runs the add on its own -- measured faster there)."""
+    S = binding.shim()
+    S.mi355_conv_shortcut_forward.argtypes = [C.POINTER(binding.ConvDesc), C.POINTER(binding.Tensor), C.c_void_p, C.POINTER(binding.Tensor),
+                                              C.POINTER(binding.Tensor), C.c_int32, C.c_int32, C.c_uint8, C.c_uint8, C.c_void_p]
+    rng = np.random.default_rng(B + c + n + H)
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    r = rng.integers(0, 256, (B, n, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3)
+    zp_in, zp_act, zp_from, zp_out = 23, 23, 40, 31
+    Ka = oracle.shortcut_multiplier(np.float32(6.6 / 255), np.float32(9.0 / 255)); Kb = oracle.shortcut_multiplier(np.float32(5.0 / 255), np.float32(9.0 / 255))
+    xt = binding.DevTensor.from_nchw(x, zp_in); rt = binding.DevTensor.from_nchw(r, zp_from)
+    yt = binding.DevTensor(B, H, W, n, zp_out)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv))
+    d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT[act], store, binding.ACC_EXACT, zp_in, zp_act, 0.05)
+    binding.check(S.mi355_conv_shortcut_forward(C.byref(d), xt.ref(), blob.ptr, rt.ref(), yt.ref(), Ka, Kb, zp_from, zp_out, None), "conv+shortcut")
+    assert S.mi355_last_conv_kernel() == fam
+    conv = np.stack([oracle.requant(oracle.conv_acc(x[b], wq, zp_w, 3, 1, 1, zp_in), bias, mv, sv, zp_act, oracle.ACT[act], store).reshape(n, H, W)
+                     for b in range(B)])
+    want = oracle.shortcut_u8(conv, r, Ka, Kb, zp_act, zp_from, zp_out)
+    assert np.array_equal(yt.to_nchw(), want)
+    assert (want == 0).any() and (want == 255).any()
+
+
+def test_fused_residual_add_is_refused_where_no_kernel_has_it():
+    S = binding.shim()
+    S.mi355_conv_shortcut_forward.argtypes = [C.POINTER(binding.ConvDesc), C.POINTER(binding.Tensor), C.c_void_p, C.POINTER(binding.Tensor),
+                                              C.POINTER(binding.Tensor), C.c_int32, C.c_int32, C.c_uint8, C.c_uint8, C.c_void_p]
+    rng = np.random.default_rng(1)
+    for (c, n, k) in ((512, 1024, 3), (64, 32, 1), (32, 64, 3)):   # row-image kernel, 1x1 kernel, few-channel kernel
+        x = rng.integers(0, 256, (1, c, 19, 19), dtype=np.uint8)
+        wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, k)
+        xt = binding.DevTensor.from_nchw(x, 0); rt = binding.DevTensor(1, 19, 19, n, 0); yt = binding.DevTensor(1, 19, 19, n, 0)
+        blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, k, bias, mv, sv))
+        d = binding.ConvDesc(n, c, k, 1, k // 2, binding.ACT["leaky"], 0, 0, 0, 23, 0.05)
+        assert S.mi355_conv_shortcut_forward(C.byref(d), xt.ref(), blob.ptr, rt.ref(), yt.ref(), 40000, 40000, 0, 0, None) == -22

@@ -255,6 +255,25 @@ __device__ __forceinline__ uint32_t pack4_biased(int32_t v0, int32_t v1, int32_t
     return __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;
 }
 
+// Quantized residual add on four packed (biased) bytes: a = this conv's requantised bytes, b = the `from` tensor's
+//     q = (Ka*a + Kb*b + k0) >> 16, clamp(0, 255)          k0 = 2^15 + (zp_out << 16) - Ka*zp_a - Kb*zp_b
+// (oracle.c:orc_shortcut_u8).  The empty asm keeps shift and clamp apart: fused, hipcc (ROCm 7.2) pairs
+// them into V_ASHR_PK_U8_I32 and ORs further bytes into its result assuming bits 31:16 are zero, which gfx950 does not do.
+__device__ __forceinline__ uint32_t shortcut4_biased(uint32_t a_biased, uint32_t b_biased, int ka, int kb, int k0)
+{
+    const uint32_t wa = a_biased ^ 0x80808080u, wb = b_biased ^ 0x80808080u;
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int av = (int)((wa >> (8 * e)) & 0xFFu), bv = (int)((wb >> (8 * e)) & 0xFFu);
+        int q = (ka * av + kb * bv + k0) >> 16;
+        asm volatile("" : "+v"(q));
+        q = q < 0 ? 0 : (q > 255 ? 255 : q);
+        w |= (uint32_t)q << (8 * e);
+    }
+    return w ^ 0x80808080u;
+}
+
 template <int ACT, bool SAT, int NS>
 __device__ __forceinline__ void requant_group(const int32_t (&accb)[4][NS], const double (&mp)[4], int zp_act,
                                               uint32_t (&packed)[NS])

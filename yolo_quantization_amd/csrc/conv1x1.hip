@@ -194,6 +194,7 @@ bool conv1x1_ws_eligible(int n, int c, int ksize)
 // returns MI355_EINVAL when the shape is outside this kernel's domain (the caller falls back to conv_rows / conv_igemm)
 int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
 {
+    if (a.res) return MI355_EINVAL;  // no fused residual add in this kernel
     const int c = a.cb * a.nchunks;
     if (!conv1x1_ws_eligible(a.n, c, a.ksize) || !a.ws || !a.y || a.acc_out || a.ypool || a.stride != 1) return MI355_EINVAL;
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets

@@ -253,14 +253,15 @@ int conv_ref_f32_launch(AuxArgs &a, hipStream_t st)
 // a workgroup walks 8 x 16 pooled patches persistently, staging the next 18 x 34 cell image (biased to signed bytes)
 // through registers into a double-buffered LDS plane.  Result bytes are identical to conv_first_pool_u8_kernel's.
 // ---------------------------------------------------------------------------------------------------------------
-// cells per LDS image row of the first-layer MFMA kernels: 34 (x = 32 tx - 1 .. + 32) from the 4-byte-cell tensor, 40
-// (x = 32 tx - 4 .. + 35, whole 4-pixel groups) when the image is read from the reference's colour planes in place
-__host__ __device__ constexpr int first_stage_rowc(bool planar) { return planar ? 40 : 34; }
+// cells per LDS image row of the first-layer MFMA kernels: 34 (x = 32 tx - 1 .. + 32) from the 4-byte-cell tensor; 42 when
+// the image is read from the reference's colour planes in place: whole 4-pixel groups x = 32 tx - 4 .. + 35 stored from
+// column 1, so that x = 32 tx - 1 sits at the EVEN column 4 and a lane's five-cell reads stay 8-byte aligned (ds_read_b64)
+__host__ __device__ constexpr int first_stage_rowc(bool planar) { return planar ? 42 : 34; }
 
 template <int ACT, bool SAT, int NM, bool PLANAR>
 __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxArgs a)
 {
-    constexpr int ROWC = first_stage_rowc(PLANAR), XO = PLANAR ? 3 : 0;
+    constexpr int ROWC = first_stage_rowc(PLANAR), XO = PLANAR ? 4 : 0;
     __shared__ __attribute__((aligned(16))) uint32_t img[2][18 * ROWC];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -341,15 +342,19 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     // either inside the image or entirely pad (cells of the input zero point, ref: src/convolutional_layer.c:703-705).
     const int prow_ix = tid / 10, pq = tid - prow_ix * 10;
     const uint32_t zsplat = (uint32_t)a.zp_in * 0x01010101u;
+    const size_t plane_sz = (size_t)a.H * a.W;
+    const int planar_off = (prow_ix - 1) * a.W + 4 * pq - 4;  // byte offset of this thread's group from the tile's (16 ty, 32 tx)
     auto fetch = [&](const Pos &p, uint32_t(&v)[3]) {  // cell indices fit an int (the launcher checks in_cells)
         if constexpr (PLANAR) {
+            // wave-uniform tile base on the scalar unit + the thread's loop-invariant 32-bit offset (scalar-base loads);
+            // out-of-image groups read a clamped in-image address and are replaced by the pad value
             const int y = 16 * p.ty - 1 + prow_ix, x0 = 32 * p.tx - 4 + 4 * pq;
-            const bool inside = tid < 180 && y >= 0 && y < a.H && x0 >= 0 && x0 < a.W;
-            const uint8_t *src = a.x + ((size_t)p.b * 3 * a.H + (inside ? y : 0)) * a.W + (inside ? x0 : 0);
-            const size_t plane = (size_t)a.H * a.W;
+            const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x0 < (unsigned)a.W && tid < 180;
+            const uint8_t *tbase = a.x + (size_t)p.b * 3 * plane_sz + (size_t)(16 * p.ty) * a.W + 32 * p.tx;
+            const unsigned off = inside ? (unsigned)(planar_off + (int)plane_sz) : (unsigned)plane_sz;  // biased by one plane: never negative
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const uint32_t t = *reinterpret_cast<const uint32_t *>(src + k * plane);
+                const uint32_t t = *reinterpret_cast<const uint32_t *>(tbase - plane_sz + off + (size_t)k * plane_sz);
                 v[k] = inside ? t : zsplat;
             }
         } else {
@@ -369,7 +374,8 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                 c.y = __builtin_amdgcn_perm(v[2], lo01, 0x0c050302u) ^ 0x80808080u;
                 c.z = __builtin_amdgcn_perm(v[2], hi01, 0x0c060100u) ^ 0x80808080u;
                 c.w = __builtin_amdgcn_perm(v[2], hi01, 0x0c070302u) ^ 0x80808080u;
-                *reinterpret_cast<uint4 *>(&img[buf][prow_ix * ROWC + 4 * pq]) = c;
+                uint32_t *dst = &img[buf][prow_ix * ROWC + 4 * pq + 1];
+                dst[0] = c.x; dst[1] = c.y; dst[2] = c.z; dst[3] = c.w;
             }
         } else {
 #pragma unroll
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
 template <int ACT, bool SAT, int NM, bool PLANAR>
 __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a)
 {
-    constexpr int ROWC = first_stage_rowc(PLANAR), XO = PLANAR ? 3 : 0;
+    constexpr int ROWC = first_stage_rowc(PLANAR), XO = PLANAR ? 4 : 0;
     __shared__ __attribute__((aligned(16))) uint32_t img[2][18 * ROWC];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -561,15 +567,19 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
     // either inside the image or entirely pad (cells of the input zero point, ref: src/convolutional_layer.c:703-705).
     const int prow_ix = tid / 10, pq = tid - prow_ix * 10;
     const uint32_t zsplat = (uint32_t)a.zp_in * 0x01010101u;
+    const size_t plane_sz = (size_t)a.H * a.W;
+    const int planar_off = (prow_ix - 1) * a.W + 4 * pq - 4;  // byte offset of this thread's group from the tile's (16 ty, 32 tx)
     auto fetch = [&](const Pos &p, uint32_t(&v)[3]) {  // cell indices fit an int (the launcher checks in_cells)
         if constexpr (PLANAR) {
+            // wave-uniform tile base on the scalar unit + the thread's loop-invariant 32-bit offset (scalar-base loads);
+            // out-of-image groups read a clamped in-image address and are replaced by the pad value
             const int y = 16 * p.ty - 1 + prow_ix, x0 = 32 * p.tx - 4 + 4 * pq;
-            const bool inside = tid < 180 && y >= 0 && y < a.H && x0 >= 0 && x0 < a.W;
-            const uint8_t *src = a.x + ((size_t)p.b * 3 * a.H + (inside ? y : 0)) * a.W + (inside ? x0 : 0);
-            const size_t plane = (size_t)a.H * a.W;
+            const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x0 < (unsigned)a.W && tid < 180;
+            const uint8_t *tbase = a.x + (size_t)p.b * 3 * plane_sz + (size_t)(16 * p.ty) * a.W + 32 * p.tx;
+            const unsigned off = inside ? (unsigned)(planar_off + (int)plane_sz) : (unsigned)plane_sz;  // biased by one plane: never negative
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const uint32_t t = *reinterpret_cast<const uint32_t *>(src + k * plane);
+                const uint32_t t = *reinterpret_cast<const uint32_t *>(tbase - plane_sz + off + (size_t)k * plane_sz);
                 v[k] = inside ? t : zsplat;
             }
         } else {
@@ -589,7 +599,8 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
                 c.y = __builtin_amdgcn_perm(v[2], lo01, 0x0c050302u) ^ 0x80808080u;
                 c.z = __builtin_amdgcn_perm(v[2], hi01, 0x0c060100u) ^ 0x80808080u;
                 c.w = __builtin_amdgcn_perm(v[2], hi01, 0x0c070302u) ^ 0x80808080u;
-                *reinterpret_cast<uint4 *>(&img[buf][prow_ix * ROWC + 4 * pq]) = c;
+                uint32_t *dst = &img[buf][prow_ix * ROWC + 4 * pq + 1];
+                dst[0] = c.x; dst[1] = c.y; dst[2] = c.z; dst[3] = c.w;
             }
         } else {
 #pragma unroll

@@ -626,6 +626,7 @@ static int launch_any(ConvArgs &a, hipStream_t st, int bm, int bn, bool patch)
 
 int conv_igemm_launch(ConvArgs &a, hipStream_t st)
 {
+    if (a.res) return MI355_EINVAL;  // no fused residual add in the implicit-GEMM / row-image kernels: the caller runs the layers separately
     int bm = g_force_bm, bn = g_force_bn;
     if (!bm) bm = a.n >= 128 ? 128 : (a.n > 32 ? 64 : 32);
     a.debug = g_debug;

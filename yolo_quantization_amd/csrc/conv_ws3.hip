@@ -278,6 +278,13 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
         const int sx = ldsSX[g * 32 + lj];
         const int cell = ldsCell[g * 32 + lj];
         uint8_t *dst = a.y + (size_t)(cell < 0 ? 0 : cell) * a.out_cs + f0 + lw + 4 * kh;
+        // fused residual add: the `from` tensor's bytes of the same pixel and channels, fetched before the requantisation
+        uint32_t resv[4] = {0, 0, 0, 0};
+        if (a.res) {
+            const uint8_t *rp = a.res + (size_t)(cell < 0 ? 0 : cell + a.res_delta) * a.res_cs + f0 + lw + 4 * kh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) resv[j] = *reinterpret_cast<const uint32_t *>(rp + 8 * j);
+        }
 #ifdef MI355_ABLATE
         if (a.debug & (1 << 18)) {  // timing ablation: stores only
             if (cell >= 0)
@@ -303,9 +310,14 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
                     }
                 }
                 requant_values_mp<ACT, SAT, 8>(accb, mp, a.zp_act, v);
+                uint32_t o0 = pack4_biased(v[0], v[1], v[2], v[3]), o1 = pack4_biased(v[4], v[5], v[6], v[7]);
+                if (a.res) {
+                    o0 = shortcut4_biased(o0, resv[2 * half], a.sc_ka, a.sc_kb, a.sc_k0);
+                    o1 = shortcut4_biased(o1, resv[2 * half + 1], a.sc_ka, a.sc_kb, a.sc_k0);
+                }
                 if (cell >= 0) {
-                    *reinterpret_cast<uint32_t *>(dst + 16 * half) = pack4_biased(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<uint32_t *>(dst + 16 * half + 8) = pack4_biased(v[4], v[5], v[6], v[7]);
+                    *reinterpret_cast<uint32_t *>(dst + 16 * half) = o0;
+                    *reinterpret_cast<uint32_t *>(dst + 16 * half + 8) = o1;
                 }
             }
         } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
@@ -317,7 +329,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
                 for (int r = 0; r < 4; ++r)
                     v[r] = (int32_t)requant_u8(acc[grp * 4 + r] + __mul24(ldsDZ[cl + r], sx), 0, a.mval[ch0 + r], a.sval[ch0 + r],
                                                a.zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
-                if (cell >= 0) *reinterpret_cast<uint32_t *>(dst + 8 * grp) = pack4_biased(v[0], v[1], v[2], v[3]);
+                uint32_t o = pack4_biased(v[0], v[1], v[2], v[3]);
+                if (a.res) o = shortcut4_biased(o, resv[grp], a.sc_ka, a.sc_kb, a.sc_k0);
+                if (cell >= 0) *reinterpret_cast<uint32_t *>(dst + 8 * grp) = o;
             }
         }
     };

@@ -152,25 +152,11 @@ __global__ __launch_bounds__(256) void shortcut_u8_kernel(const ShortcutArgs s)
     const long cell = ((long)b * (s.H + 1) + (y + 1)) * (s.W + 1) + x;
     const uint4 va = *reinterpret_cast<const uint4 *>(s.a + (cell + s.a_lead) * s.a_cs + g * 16);
     const uint4 vb = *reinterpret_cast<const uint4 *>(s.b + (cell + s.b_lead) * s.b_cs + g * 16);
-    const uint32_t wa[4] = {va.x ^ 0x80808080u, va.y ^ 0x80808080u, va.z ^ 0x80808080u, va.w ^ 0x80808080u};
-    const uint32_t wb[4] = {vb.x ^ 0x80808080u, vb.y ^ 0x80808080u, vb.z ^ 0x80808080u, vb.w ^ 0x80808080u};
     uint32_t o[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        uint32_t w = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int av = (int)((wa[d] >> (8 * e)) & 0xFFu), bv = (int)((wb[d] >> (8 * e)) & 0xFFu);
-            int q = (s.ka * av + s.kb * bv + s.k0) >> 16;
-            // Keep shift and clamp apart: fused, hipcc (ROCm 7.2) emits V_ASHR_PK_U8_I32 for pairs of them and ORs bytes 2, 3
-            // into its result assuming bits 31:16 are zero -- on gfx950 the instruction leaves the destination's old upper
-            // half there (measured: byte 2 came back OR'ed with the first lane value; tools/dbg/shortcut_dbg.py).
-            asm volatile("" : "+v"(q));
-            q = q < 0 ? 0 : (q > 255 ? 255 : q);
-            w |= (uint32_t)q << (8 * e);
-        }
-        o[d] = w ^ 0x80808080u;
-    }
+    o[0] = shortcut4_biased(va.x, vb.x, s.ka, s.kb, s.k0);
+    o[1] = shortcut4_biased(va.y, vb.y, s.ka, s.kb, s.k0);
+    o[2] = shortcut4_biased(va.z, vb.z, s.ka, s.kb, s.k0);
+    o[3] = shortcut4_biased(va.w, vb.w, s.ka, s.kb, s.k0);
     *reinterpret_cast<uint4 *>(s.y + (cell + s.y_lead) * s.y_cs + g * 16) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 

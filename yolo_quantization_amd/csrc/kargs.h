@@ -40,6 +40,11 @@ struct ConvArgs {
     int up;                  // conv_rows: fused nearest-neighbour upsample factor of the stored tensor (1 = none)
     float *yolo_out;         // fused yolo head: activated copy of y_f32 (same layout) or null
     int yolo_per;            // classes + 5
+    // fused quantized residual add (mi355_conv_shortcut_forward): the stored byte is shortcut(conv byte, res byte); res is
+    // the `from` layer's tensor, same map as y.  res_delta = (res.lead - y.lead): res cell = y cell + res_delta
+    const uint8_t *res;
+    int res_cs, res_delta;
+    int sc_ka, sc_kb, sc_k0;
 };
 
 struct AuxArgs {

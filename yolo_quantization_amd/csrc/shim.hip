@@ -391,7 +391,8 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
 // ------------------------------------------------------------------------------------------------ convolution
 static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const uint8_t *w_u8,
                              const uint8_t *zp_w, const mi355_tensor *y, const mi355_tensor *ypool, int32_t *acc_out,
-                             float *y_f32, void *stream, float *yolo_out = nullptr, int yolo_classes = 0, int up = 1)
+                             float *y_f32, void *stream, float *yolo_out = nullptr, int yolo_classes = 0, int up = 1,
+                             const mi355_tensor *res = nullptr, int sc_ka = 0, int sc_kb = 0, int sc_k0 = 0)
 {
     if (!d || !x || !x->data || !blob) return einval("conv_forward: null");
     if (d->stride != 1 && d->stride != 2) return einval("conv_forward: stride must be 1 or 2");
@@ -417,6 +418,8 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
 
     if (x->cs == 1 && (!h.first || d->accum_mode == MI355_ACC_REF_F32))
         return einval("conv_forward: the planar (cs==1) layout is accepted for the exact-mode 3-channel first layer only");
+    if (res && (d->accum_mode == MI355_ACC_REF_F32 || h.first || !y || ypool || acc_out || y_f32 || yolo_out || up != 1 || d->stride != 1))
+        return einval("conv_shortcut_forward: plain exact-mode stride-1 convolutions with c % 16 == 0 only");
     if (d->accum_mode == MI355_ACC_REF_F32 || h.first) {
         AuxArgs a;
         memset(&a, 0, sizeof(a));
@@ -484,6 +487,10 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     a.ws = h.off_ws ? (const int8_t *)(base + h.off_ws) : nullptr;
     a.yolo_out = yolo_out; a.yolo_per = yolo_classes + 5;
     a.up = up;
+    if (res) {
+        a.res = (const uint8_t *)res->data; a.res_cs = res->cs; a.res_delta = res->lead - y->lead;
+        a.sc_ka = sc_ka; a.sc_kb = sc_kb; a.sc_k0 = sc_k0;
+    }
     if (up != 1 && (h.cb != 64 || ypool)) return einval("conv_upsample_forward: 64-channel-chunk layers only");
     int rc = MI355_EINVAL;
     if (ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) { rc = conv_small_pool_launch(a, st); g_last_kernel = 2; }  // few-channel layers
@@ -493,6 +500,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     if (rc == MI355_EINVAL && a.ws && d->ksize == 1 && !(mi355_debug_flags_get() & 8192)) { rc = conv1x1_ws_launch(a, st); g_last_kernel = 3; }  // 1x1 layers
     if (rc == MI355_EINVAL && a.ws && d->ksize == 3 && !ypool && !(mi355_debug_flags_get() & 16384)) { rc = conv_ws3_launch(a, st); g_last_kernel = 4; }  // mid layers
     if (rc == MI355_EINVAL) { rc = conv_igemm_launch(a, st); g_last_kernel = 5; }
+    if (rc == MI355_EINVAL && res) return einval("conv_shortcut_forward: no kernel fuses the residual add for this shape");
     if (rc == MI355_EINVAL) return einval("conv_forward: no tile configuration fits this shape");
     if (rc != MI355_OK) return hip_fail(hipGetLastError(), "conv_igemm launch");
     return rc;
@@ -518,6 +526,17 @@ int mi355_conv_upsample_forward(const mi355_conv_desc *d, const mi355_tensor *x,
     if (!d || !y_up || stride < 1 || stride > 4) return einval("conv_upsample_forward: y_up, 1 <= stride <= 4");
     if (d->accum_mode != MI355_ACC_EXACT || d->c % 64) return einval("conv_upsample_forward: exact mode, c % 64 == 0 only");
     return conv_forward_impl(d, x, blob, nullptr, nullptr, y_up, nullptr, nullptr, nullptr, stream, nullptr, 0, stride);
+}
+
+int mi355_conv_shortcut_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const mi355_tensor *from,
+                                const mi355_tensor *y_sum, int32_t Ka, int32_t Kb, uint8_t zp_from, uint8_t zp_out, void *stream)
+{
+    if (!d || !from || !from->data || !y_sum) return einval("conv_shortcut_forward: null");
+    if (from->cs % 16 || from->B != y_sum->B || from->H != y_sum->H || from->W != y_sum->W || from->C != y_sum->C)
+        return einval("conv_shortcut_forward: `from` and the sum must share batch, map and channels");
+    if (Ka < 1 || Kb < 1 || Ka >= (1 << 21) || Kb >= (1 << 21)) return einval("conv_shortcut_forward: multipliers must be in [1, 2^21)");
+    const int k0 = 32768 + ((int)zp_out << 16) - Ka * (int)d->zp_act - Kb * (int)zp_from;
+    return conv_forward_impl(d, x, blob, nullptr, nullptr, y_sum, nullptr, nullptr, nullptr, stream, nullptr, 0, 1, from, Ka, Kb, k0);
 }
 
 int mi355_conv_pool_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const mi355_tensor *y,

@@ -20,6 +20,7 @@ int dnq_net_set(network *net, const char *key, int val)
     else if (!strcmp(key, "use_graph")) net->use_graph = val;
     else if (!strcmp(key, "gpu_index")) net->gpu_index = val;
     else if (!strcmp(key, "verbose")) net->verbose = val;
+    else if (!strcmp(key, "input_direct")) net->input_direct = val; /* 0: always convert the input to 4-byte cells (A/B runs) */
     else return -1;
     return 0;
 }
@@ -74,7 +75,7 @@ int dnq_layer_conv_kernel(network *net, int i)
 int dnq_layer_is_fused(network *net, int i)
 {
     if (i < 0 || i >= net->n) return 0;
-    return (net->layers[i].fuse_next_pool || net->layers[i].fuse_next_upsample) && net->fuse_maxpool && !net->dump_int32 &&
+    return (net->layers[i].fuse_next_pool || net->layers[i].fuse_next_upsample || net->layers[i].fuse_next_shortcut) && net->fuse_maxpool && !net->dump_int32 &&
            net->accum_mode == MI355_ACC_EXACT;
 }
 

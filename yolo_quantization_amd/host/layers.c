@@ -57,6 +57,13 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
         if (rc != MI355_EINVAL) { check_mi355(rc, "mi355_conv_upsample_forward"); return; }
         self->fuse_next_upsample = 0;
     }
+    if (net.fused_shortcut) { /* this conv + the quantized residual add after it; the conv's own tensor is not stored */
+        const layer *sc = net.fused_shortcut, *from = &net.layers[sc->index];
+        const int rc = mi355_conv_shortcut_forward(&d, net.cur_t, l.blob_gpu, &from->out_t, &sc->out_t, sc->shortcut_Ka, sc->shortcut_Kb,
+                                                   from->activ_data_uint8_zero_point[0], sc->activ_data_uint8_zero_point[0], net.stream);
+        if (rc != MI355_EINVAL) { check_mi355(rc, "mi355_conv_shortcut_forward"); return; }
+        self->fuse_next_shortcut = 0;
+    }
     if (net.fused_yolo_out) { /* quant_stop head + the yolo layer after it (ref: src/yolo_layer.c:132-146) in one kernel */
         const int rc = mi355_conv_yolo_forward(&d, net.cur_t, l.blob_gpu, &l.out_t, l.output_gpu, net.fused_yolo_out,
                                                net.fused_yolo_classes, net.stream);

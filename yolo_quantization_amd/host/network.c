@@ -322,7 +322,13 @@ void quantization_prep_host(network *net, float in_scale, uint8_t in_zp)
  * even map, the conv is 3x3 and nothing else (a route) reads the conv's own output */
 static void plan_fusion(network *net)
 {
-    for (int i = 0; i < net->n; ++i) net->layers[i].fuse_next_pool = net->layers[i].fuse_next_yolo = 0;
+    for (int i = 0; i < net->n; ++i) net->layers[i].fuse_next_pool = net->layers[i].fuse_next_yolo = net->layers[i].fuse_next_shortcut = 0;
+    for (int i = 0; i + 1 < net->n; ++i) { /* conv + quantized residual add: the conv's own tensor has no other reader */
+        layer *c = &net->layers[i], *sc = &net->layers[i + 1];
+        if (c->type == CONVOLUTIONAL && sc->type == SHORTCUT && c->stride == 1 && !c->quant_stop_flag && !sc->quant_stop_flag &&
+            c->c % 16 == 0 && sc->index != i && !output_read_elsewhere(net, i))
+            c->fuse_next_shortcut = 1;
+    }
     for (int i = 0; i < net->n; ++i) net->layers[i].fuse_next_upsample = 0;
     for (int i = 0; i + 1 < net->n; ++i) { /* conv + nearest upsample: the conv stores every pixel stride x stride times */
         layer *c = &net->layers[i], *u = &net->layers[i + 1];
@@ -512,6 +518,8 @@ static void run_layers(network *netp)
         net.fused_pool_t = fuse0 ? &netp->layers[i + 1].out_t : NULL;
         net.fused_yolo_out = fuse_yolo0 ? netp->layers[i + 1].output_gpu : NULL;
         net.fused_yolo_classes = fuse_yolo0 ? netp->layers[i + 1].classes : 0;
+        const int fuse_sc0 = l.fuse_next_shortcut && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
+        net.fused_shortcut = fuse_sc0 ? &netp->layers[i + 1] : NULL;
         const int fuse_up0 = l.fuse_next_upsample && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
         net.fused_up_t = fuse_up0 ? &netp->layers[i + 1].out_t : NULL;
         net.fused_up_stride = fuse_up0 ? netp->layers[i + 1].stride : 1;
@@ -523,6 +531,15 @@ static void run_layers(network *netp)
         const int fuse = fuse0 && netp->layers[i].fuse_next_pool;
         const int fuse_yolo = fuse_yolo0 && netp->layers[i].fuse_next_yolo;
         const int fuse_up = fuse_up0 && netp->layers[i].fuse_next_upsample;
+        const int fuse_sc = fuse_sc0 && netp->layers[i].fuse_next_shortcut;
+        if (fuse_sc) { /* the shortcut layer's tensor was written by the conv kernel: hand it on and skip the layer */
+            if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
+            ++i;
+            net.cur_t = &netp->layers[i].out_t;
+            net.cur_f32_gpu = NULL;
+            if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
+            continue;
+        }
         if (ev) check_mi355(mi355_event_record(ev[i + 2], net.stream), "event");
         if (fuse_up) { /* the upsample layer's tensor was written by the conv kernel: hand it on and skip the layer */
             ++i;
