@@ -8,12 +8,12 @@ export TMPDIR=/tmp
 for what in "$@"; do
 case $what in
 tests)
-  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 | tee gpurun_out/pytest_gpu.log
+  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/pytest_gpu.log; echo
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log ;;
 newtests)
-  timeout 2400 python -m pytest tests/test_gpu_refpin.py tests/test_gpu_residual.py -m gpu -x -q 2>&1 | tail -60 | tee gpurun_out/pytest_gpu_new.log ;;
+  timeout 2400 python -m pytest tests/test_gpu_refpin.py tests/test_gpu_residual.py -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/pytest_gpu_new.log; echo ;;
 k2tests)
-  timeout 2400 python -m pytest tests/test_gpu_r2_kernels.py -m gpu -x -q 2>&1 | tail -60 | tee gpurun_out/pytest_gpu_k2.log ;;
+  timeout 2400 python -m pytest tests/test_gpu_r2_kernels.py -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/pytest_gpu_k2.log; echo ;;
 quicktests)
   timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_r2_kernels.py -m gpu -x -q 2>&1 | tail -30 | tee gpurun_out/pytest_gpu_quick.log ;;
 bench)

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         p.tx = r - p.ty * tiles_x;
         return p;
     };
-    const Pos step = pos_of(gridDim.x);
+    const Pos step = pos_of(((gridDim.x & 7) == 0 && !(a.debug_flags & 2048)) ? (int)(gridDim.x >> 3) : (int)gridDim.x);
     auto advance = [&](Pos &p) {
         p.tx += step.tx;
         p.ty += step.ty;
@@ -384,10 +384,19 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         }
     };
 
-    int tile = blockIdx.x;
+    // XCD-aware tile walk: workgroup id b runs on XCD b % 8 (each with its own L2).  Neighbouring tiles share the cache lines
+    // of their halo columns / rows, so every XCD takes one CONTIGUOUS eighth of the tiles and its workgroups walk it side by
+    // side: tile = xcd * per + idx, idx = b / 8 + k * (gridDim / 8).  (Plain b + k * gridDim put neighbours on different
+    // XCDs: 2.3x - 3x the input bytes fetched, profiles/r01_v6_pmc_traffic.json, r02_v1_pmc_traffic.json.)
+    const bool xcd_walk = (gridDim.x & 7) == 0 && !(a.debug_flags & 2048);
+    const int per_x = xcd_walk ? (ntiles + 7) >> 3 : ntiles;
+    const int tstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int tbase_x = xcd_walk ? (int)(blockIdx.x & 7) * per_x : 0;
+    const int tend = min(tbase_x + per_x, ntiles);
+    int tile = tbase_x + (xcd_walk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
     Pos cur = pos_of(tile), nxp = cur;
     uint32_t nxt[3];
-    if (tile < ntiles) {
+    if (tile < tend) {
         fetch(cur, nxt);
         stash(0, nxt);
     }
@@ -396,9 +405,9 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     // prefetch issued a few instructions earlier and for the previous tile's stores -- a memory round trip per tile.
     __builtin_amdgcn_s_waitcnt(0x0F70);
     int buf = 0;
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1, cur = nxp) {
+    for (; tile < tend; tile += tstride, buf ^= 1, cur = nxp) {
         __syncthreads();  // this tile's image is complete; every wave is past the previous tile
-        const bool more = tile + gridDim.x < ntiles;
+        const bool more = tile + tstride < tend;
         advance(nxp);
         if (more) fetch(nxp, nxt);
         const int b = cur.b, ty = cur.ty, tx = cur.tx;
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
         p.tx = r - p.ty * tiles_x;
         return p;
     };
-    const Pos step = pos_of(gridDim.x);
+    const Pos step = pos_of(((gridDim.x & 7) == 0 && !(a.debug_flags & 2048)) ? (int)(gridDim.x >> 3) : (int)gridDim.x);
     auto advance = [&](Pos &p) {
         p.tx += step.tx;
         p.ty += step.ty;
@@ -609,10 +618,19 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
         }
     };
 
-    int tile = blockIdx.x;
+    // XCD-aware tile walk: workgroup id b runs on XCD b % 8 (each with its own L2).  Neighbouring tiles share the cache lines
+    // of their halo columns / rows, so every XCD takes one CONTIGUOUS eighth of the tiles and its workgroups walk it side by
+    // side: tile = xcd * per + idx, idx = b / 8 + k * (gridDim / 8).  (Plain b + k * gridDim put neighbours on different
+    // XCDs: 2.3x - 3x the input bytes fetched, profiles/r01_v6_pmc_traffic.json, r02_v1_pmc_traffic.json.)
+    const bool xcd_walk = (gridDim.x & 7) == 0 && !(a.debug_flags & 2048);
+    const int per_x = xcd_walk ? (ntiles + 7) >> 3 : ntiles;
+    const int tstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int tbase_x = xcd_walk ? (int)(blockIdx.x & 7) * per_x : 0;
+    const int tend = min(tbase_x + per_x, ntiles);
+    int tile = tbase_x + (xcd_walk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
     Pos cur = pos_of(tile), nxp = cur;
     uint32_t nxt[3];
-    if (tile < ntiles) {
+    if (tile < tend) {
         fetch(cur, nxt);
         stash(0, nxt);
     }
@@ -621,9 +639,9 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
     // prefetch issued a few instructions earlier and for the previous tile's stores -- a memory round trip per tile.
     __builtin_amdgcn_s_waitcnt(0x0F70);
     int buf = 0;
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1, cur = nxp) {
+    for (; tile < tend; tile += tstride, buf ^= 1, cur = nxp) {
         __syncthreads();  // this tile's image is complete; every wave is past the previous tile
-        const bool more = tile + gridDim.x < ntiles;
+        const bool more = tile + tstride < tend;
         advance(nxp);
         if (more) fetch(nxp, nxt);
         const int b = cur.b, ty = cur.ty, tx = cur.tx;

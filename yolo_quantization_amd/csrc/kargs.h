@@ -69,6 +69,7 @@ struct AuxArgs {
     const ConvBlobHeader *hdr;  // device copy of the blob header (data-dependent pow2 flag)
     const int32_t *cwb;         // cw + bias (first-layer MFMA kernel)
     int planar;                 // x is the reference's [B][3][H][W] uint8 planes (no cells, no pads), read in place
+    int debug_flags;            // mi355_debug_flags (2048: plain tile walk instead of the XCD-aware one, A/B runs)
 };
 
 struct PoolArgs {

@@ -446,6 +446,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
         g_last_kernel = 1;
         if (x->cs != 4 && x->cs != 1) return einval("conv_forward: first layer expects a cs==4 image tensor or the planar (cs==1) reference layout");
         a.planar = x->cs == 1;
+        a.debug_flags = mi355_debug_flags_get();
         if (a.planar) a.in_cells = 0;
         if (ypool) {
             int rc = (mi355_debug_flags_get() & 1024) ? MI355_EINVAL : conv_first_mfma_pool_launch(a, st);

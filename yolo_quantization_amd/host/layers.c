@@ -46,7 +46,19 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
      * point means "no kernel fuses this shape" (nothing was launched): the flag is cleared in the network's layer array
      * (net.layers points at it; `l` is a by-value copy) and the convolution runs unfused below, the layer after it on its
      * own. */
-    layer *self = &net.layers[l.count];
+    layer *self = &net.layers[net.index];
+    mi355_tensor converted;
+    if (net.cur_t->cs == 1) { /* planar network input: try the in-place read; MI355_EINVAL -> convert, once and for all */
+        int rc = MI355_EINVAL;
+        if (net.fused_pool_t) rc = mi355_conv_pool_forward(&d, net.cur_t, l.blob_gpu, NULL, net.fused_pool_t, net.stream);
+        else if (!net.fused_up_t && !net.fused_yolo_out && !net.fused_shortcut && !l.quant_stop_flag)
+            rc = mi355_conv_forward(&d, net.cur_t, l.blob_gpu, NULL, NULL, &l.out_t, NULL, NULL, net.stream);
+        if (rc != MI355_EINVAL) { check_mi355(rc, "mi355_conv_forward (planar input)"); return; }
+        if (net.input_direct_p) *net.input_direct_p = 0;
+        converted = net.input_t;
+        check_mi355(mi355_nchw_to_tensor((const uint8_t *)net.cur_t->data, &converted, net.stream), "input layout");
+        net.cur_t = &converted;
+    }
     if (net.fused_pool_t) { /* this conv + the 2x2/2 maxpool after it as one kernel; the pre-pool tensor is not stored */
         const int rc = mi355_conv_pool_forward(&d, net.cur_t, l.blob_gpu, NULL, net.fused_pool_t, net.stream);
         if (rc != MI355_EINVAL) { check_mi355(rc, "mi355_conv_pool_forward"); return; }
