@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+LIB_DIR = os.environ.get("MI355_LIB_DIR") or os.path.join(_HERE, "lib")   # override: A/B runs against another build of the libraries
 
 ACT = {"relu": 1, "linear": 3, "relu6": 8, "leaky": 9}
 STORE_WRAP, STORE_SATURATE = 0, 1

@@ -3,7 +3,7 @@
 # must execute the reference's double operations one by one (no FMA contraction).
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="$HERE/../lib"
+OUT="${MI355_BUILD_OUT:-$HERE/../lib}"
 mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"

@@ -29,6 +29,10 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
     int *ldsDZ = reinterpret_cast<int *>(ldsMP + N32);                    // [N32] 128 - zp_w
     int *ldsCB = ldsDZ + N32;                                             // [N32] cw + bias
     float *ldsYL = reinterpret_cast<float *>(ldsCB + N32);                // [256] fused yolo head: logistic per byte
+    // per pixel of the tile: output cell (-1: no pixel), image index and offset inside the image -- computed once per pixel by
+    // the DMA loop below (which divides for its input cell anyway) instead of twice per group by every wave of the tile
+    int *ldsCell = reinterpret_cast<int *>(ldsYL + 256);                  // [chunks * 16]
+    int *ldsImg = ldsCell + chunks * 16, *ldsRem = ldsImg + chunks * 16;  // [chunks * 16] each
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
     const int tid = threadIdx.x, NT = blockDim.x;
@@ -48,17 +52,27 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
     {
         const int nck = (n1 - n0 + 15) >> 4;
         const int nQ = KST >> 1;
-        for (int ck = wave; ck < nck; ck += nwave) {
+        for (int ck = wave; ck < chunks; ck += nwave) {  // chunks past the tile's last pixel only fill the tables (no pixel)
             const int n = min(n0 + ck * 16 + (lane & 15), n1 - 1);
             const int b = n / hw, rem = n - b * hw;
             const int y = rem / a.W, x = rem - y * a.W;
             const long cell = (long)a.in_lead + ((long)b * (a.H + 1) + (y + 1)) * W1 + x;
             const unsigned voff = (unsigned)(cell * a.in_cs) + (lane >> 4) * 16;
-            for (int Q = 0; Q < nQ; ++Q) {
-                const unsigned dst = lds0 + Q * qb + ck * 1024;
-                const unsigned v = voff + Q * 64;
-                DMA_S(dst, a.x, v);
+            if (lane < 16) {
+                const int up = a.up;
+                const long oc = up == 1 ? cell - a.in_lead + a.out_lead
+                                        : (long)a.out_lead + ((long)b * (up * a.H + 1) + (up * y + 1)) * (up * a.W + 1) + up * x;
+                const int pi = ck * 16 + lane;
+                ldsCell[pi] = n0 + pi < n1 ? (int)oc : -1;  // output cells fit an int: the launcher checks
+                ldsImg[pi] = b;
+                ldsRem[pi] = rem;
             }
+            if (ck < nck)
+                for (int Q = 0; Q < nQ; ++Q) {
+                    const unsigned dst = lds0 + Q * qb + ck * 1024;
+                    const unsigned v = voff + Q * 64;
+                    DMA_S(dst, a.x, v);
+                }
         }
     }
     // ---- parameters and this wave's A fragments (overlap the DMA)
@@ -100,15 +114,11 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
         }
         const int sx = sxr + __shfl_xor(sxr, 32);  // the two 16-byte k-halves of every K-step
 
-        // ---- this lane's pixel
-        const int n = n0 + g * 32 + lj;
-        const bool valid = n < n1;
-        const int nn = valid ? n : n1 - 1;
-        const int b = nn / hw, rem = nn - b * hw;
-        const int y = rem / a.W, x = rem - y * a.W;
+        // ---- this lane's pixel (tables filled by the DMA loop)
+        const int ocell = ldsCell[g * 32 + lj];
+        const bool valid = ocell >= 0;
+        const int b = ldsImg[g * 32 + lj], rem = ldsRem[g * 32 + lj];
         const int up = a.up;
-        const long ocell = up == 1 ? (long)a.out_lead + ((long)b * (a.H + 1) + (y + 1)) * W1 + x
-                                   : (long)a.out_lead + ((long)b * (up * a.H + 1) + (up * y + 1)) * (up * a.W + 1) + up * x;
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
             const int ch0 = chw + 8 * grp + 4 * kh;
@@ -213,7 +223,7 @@ int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
     size_t lds = (size_t)(c / 64) * a.sm_ncell * 1024;
     a.lds_param_off = (int)lds;
     const int n32 = (a.n + 31) & ~31;
-    lds += (size_t)n32 * 16 + 1024;
+    lds += (size_t)n32 * 16 + 1024 + (size_t)a.sm_ncell * 16 * 12;  // parameters, logistic table, the three per-pixel tables
     if (lds > 96 * 1024) return MI355_EINVAL;  // two workgroups per CU when a layer needs more than one round
     const int nq = n32 / 32;
     const int sets = 8 / nq > 0 ? 8 / nq : 1;  // at most 8 waves per workgroup
