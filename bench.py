@@ -330,7 +330,8 @@ def main():
         if layers:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             json.dump({"ms_per_step": ms_per_step, "layers": layers},
-                      open(os.path.join(ROOT, "gpurun_out", f"bench_layers_n{world}.json"), "w"), indent=1)
+                      open(os.path.join(ROOT, "gpurun_out", f"bench_layers_n{world}.json" if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg"
+                                        else f"bench_layers_{os.path.splitext(os.path.basename(args.cfg))[0]}_n{world}.json"), "w"), indent=1)
     try:
         os.remove(wts)
     except OSError:

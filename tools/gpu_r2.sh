@@ -36,5 +36,7 @@ pmc)
         python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-ref-f32 > "$OLDPWD/gpurun_out/pmc_$ctr.json" 2> "$OLDPWD/gpurun_out/pmc_$ctr.err" )
   done
   python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_traffic.json | head -30 ;;
+sq)
+  bash tools/pmc_bench.sh 2>&1 | tail -5 ;;
 esac
 done

@@ -1,7 +1,7 @@
 set -uo pipefail
 cd "$(dirname "$0")/.."; mkdir -p gpurun_out/pmcb; export TMPDIR=/tmp; R=$PWD
 run_pass() { local name=$1; shift
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/gpurun_out/pmcb/$name" -o p -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/pmcb/$name.out" 2> "$R/gpurun_out/pmcb/$name.err" )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/gpurun_out/pmcb/$name" -o p -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-ref-f32 > "$R/gpurun_out/pmcb/$name.out" 2> "$R/gpurun_out/pmcb/$name.err" )
   local f=$(find gpurun_out/pmcb/$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py "$f" | tee gpurun_out/pmcb/$name.summary
 }

@@ -240,6 +240,22 @@ __device__ void small_safe_range(double mp, int zp, int32_t &lo, int32_t &hi)
     lo = (int32_t)l;
 }
 
+// The pooled kernels keep their accumulators BIASED by the lower end of the safe range: seeded with cw + bias - lo instead of
+// cw + bias (the seed is the MFMA's C operand: free).  Then  u = acc - lo  as an unsigned number is <= hi - lo exactly when
+// lo <= acc <= hi, so one unsigned maximum over the 2x2 window answers both "is every accumulator of the window inside the
+// safe range" (max_u <= hi - lo) and "what is the window's largest accumulator" (max_u + lo, valid when the first holds):
+// 4 VALU instructions per pooled output instead of ~8 (signed max, signed min, two compares).  Exact for every int32
+// accumulator as long as -2^30 <= lo and hi < 2^30 (no modular alias of an out-of-range value lands in [0, hi - lo]); any
+// sub-range of the true safe range is safe, so the ends are simply clamped.  Returns false when no accumulator is safe for
+// this channel (the caller then requantises every value of every window: the reference's order).
+__device__ __forceinline__ bool biased_safe_range(int32_t lo, int32_t hi, int32_t &lo_b, uint32_t &range)
+{
+    const int32_t L = lo < -(1 << 30) ? -(1 << 30) : lo, H = hi > (1 << 30) - 1 ? (1 << 30) - 1 : hi;
+    lo_b = L;
+    range = H >= L ? (uint32_t)(H - L) : 0u;
+    return H >= L;
+}
+
 // yolo head activation of entry e = channel % (classes + 5): logistic on x, y, objectness and the class scores, identity on
 // w, h (ref: src/yolo_layer.c:132-146, src/activations.h:39; double precision exp as the reference's logistic_activate)
 __device__ __forceinline__ float yolo_entry_act(float v, int e)

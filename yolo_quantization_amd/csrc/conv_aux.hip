@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     v4i wa[NM], wd1[NM], wd2[NM], cb[NM], lo[NM], hi[NM];
     int chq[NM];
     double mp[NM][4];
+    int never_l = 0;
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt) {
         const int ch = 16 * mt + pc;
@@ -298,13 +299,16 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
             const int c2 = chq[mt] + r;
             const double m = a.mprime[c2];
             mp[mt][r] = m;
-            cb[mt][r] = a.cwb[c2];
             int32_t l = -2147483647 - 1, h = 2147483647;
             if (!SAT) small_safe_range<ACT>(m, a.zp_act, l, h);
-            lo[mt][r] = l;
-            hi[mt][r] = h;
+            int32_t lb = 0; uint32_t rg = 0;
+            if (!biased_safe_range(l, h, lb, rg)) never_l = 1;
+            cb[mt][r] = (int32_t)((uint32_t)a.cwb[c2] - (uint32_t)lb);  // accumulators biased by the safe range's lower end (common.h)
+            lo[mt][r] = lb;
+            hi[mt][r] = (int32_t)rg;  // hi - lo
         }
     }
+    const bool never = __syncthreads_or(never_l) != 0;
     bool need_d2 = false;
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt) need_d2 |= __builtin_amdgcn_ballot_w64(wd2[mt][0] != 0) != 0;
@@ -452,16 +456,16 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                         acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt], bf, acc[j], 0, 0, 0);
                     }
                 }
+                // accumulators are biased by lo: one unsigned maximum gives the range test and the window maximum (common.h)
                 int32_t accb[4][4], amax[4][1];
-                bool bad = false;
+                bool bad = never;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) accb[r][j] = acc[j][r];
-                    const int32_t mx = max(max(accb[r][0], accb[r][1]), max(accb[r][2], accb[r][3]));
-                    const int32_t mn = min(min(accb[r][0], accb[r][1]), min(accb[r][2], accb[r][3]));
-                    bad |= (mx > hi[mt][r]) | (mn < lo[mt][r]);
-                    amax[r][0] = mx;
+                    const uint32_t u = max(max((uint32_t)accb[r][0], (uint32_t)accb[r][1]), max((uint32_t)accb[r][2], (uint32_t)accb[r][3]));
+                    bad |= u > (uint32_t)hi[mt][r];
+                    amax[r][0] = (int32_t)(u + (uint32_t)lo[mt][r]);
                 }
                 int32_t m[4];
                 if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {
@@ -469,21 +473,27 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                     requant_values<ACT, SAT, 1>(amax, mp[mt], a.zp_act, v1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m[r] = v1[r][0];
-                } else if (pow2) {
-                    int32_t v[4][4];
-                    requant_values<ACT, SAT, 4>(accb, mp[mt], a.zp_act, v);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int32_t t = 0;
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            t = max(t, (int32_t)requant_u8(accb[r][j], 0, a.mval[chq[mt] + r], a.sval[chq[mt] + r], a.zp_act,
-                                                           ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
-                        m[r] = t;
+                        for (int j = 0; j < 4; ++j) accb[r][j] = (int32_t)((uint32_t)accb[r][j] + (uint32_t)lo[mt][r]);  // true accumulators
+                    if (pow2) {
+                        int32_t v[4][4];
+                        requant_values<ACT, SAT, 4>(accb, mp[mt], a.zp_act, v);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int32_t t = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                t = max(t, (int32_t)requant_u8(accb[r][j], 0, a.mval[chq[mt] + r], a.sval[chq[mt] + r], a.zp_act,
+                                                               ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
+                            m[r] = t;
+                        }
                     }
                 }
                 if (valid) *reinterpret_cast<uint32_t *>(outp + chq[mt]) = pack4_biased(m[0], m[1], m[2], m[3]);
