@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
 #pragma unroll
             for (int mt = 0; mt < NM; ++mt) {
                 v4i acc[4];
+                if (!(a.debug_flags & 131072)) __builtin_amdgcn_s_setprio(3);  // the MFMA chain outranks the other waves' requantisation
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int jy = j >> 1, jx = j & 1;
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                         acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt], bf, acc[j], 0, 0, 0);
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
                 // accumulators are biased by lo: one unsigned maximum gives the range test and the window maximum (common.h)
                 int32_t accb[4][4], amax[4][1];
                 bool bad = never;
@@ -674,6 +676,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
 #pragma unroll
             for (int mt = 0; mt < NM; ++mt) {
                 v4i acc[4];
+                if (!(a.debug_flags & 131072)) __builtin_amdgcn_s_setprio(3);  // the MFMA chain outranks the other waves' requantisation
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int jy = j >> 1, jx = j & 1;
@@ -694,6 +697,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
                         acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt], bf, acc[j], 0, 0, 0);
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
                 // every window position is an output pixel of its own: requantise all sixteen values of the lane
                 int32_t accb[4][4], v[4][4];
 #pragma unroll

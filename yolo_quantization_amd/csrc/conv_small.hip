@@ -323,6 +323,10 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
                     acc[j][grp * 4 + 2] = c4.z; acc[j][grp * 4 + 3] = c4.w;
                 }
             }
+            // the wave inside its MFMA chain outranks the co-resident waves that requantise: its MFMAs get their issue slot at
+            // once (one in eight) and the others' VALU work fills the rest, instead of the matrix pipe idling behind an older
+            // wave's VALU stream (issue arbitration is by priority, then age)
+            if (!(a.debug & 131072)) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int s = 0; s < KST; ++s)
 #pragma unroll
@@ -340,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
                         }
                     }
                 }
+            __builtin_amdgcn_s_setprio(0);
             // ---- epilogue: window max, one requantisation per (pixel, channel), biased packed store
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
@@ -583,6 +588,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
                 acc[j][grp * 4 + 2] = c4.z; acc[j][grp * 4 + 3] = c4.w;
             }
         }
+        if (!(a.debug & 131072)) __builtin_amdgcn_s_setprio(3);  // see conv_small_pool_kernel
 #pragma unroll
         for (int s = 0; s < KST; ++s) {
             const int soff = ((s >> 1) / 3) * rowb + (s & 1) * 2 * pieceb;  // scalar
@@ -593,6 +599,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
             }
             if (s & 1) __builtin_amdgcn_sched_barrier(0);  // keep the B fragments of at most two K-steps live (registers)
         }
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
             const int ch0 = chw + 8 * grp + 4 * kh;
@@ -711,6 +718,7 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
     // conv + maxpool (ypool, no y), or the same kernels without the pool (y, no ypool): four output pixels per lane
     if (!conv_small_eligible(a.n, c, a.ksize) || a.acc_out || a.y_f32 || !a.ws) return MI355_EINVAL;
     if (a.ypool ? (a.y != nullptr || a.stride != 1) : (a.y == nullptr || a.out_w < a.n || a.up != 1)) return MI355_EINVAL;
+    a.debug = mi355_debug_flags_get();
     if ((a.H & 1) || (a.W & 1) || a.in_cs != c) return MI355_EINVAL;
     // no fused residual add here: measured (YOLOv3 @608, batch 32) 412 us fused against 150 us + an 88 us stand-alone add for
     // 32 -> 64 @304 -- these kernels' stores are already their bottleneck, the add's loads queue in front of them
