@@ -44,10 +44,15 @@ extern "C" {
 
 /* uint8 store behaviour of the requantise epilogue */
 #define MI355_STORE_WRAP 0      /* ref default path: stored before clamp -> wraps mod 256 (convolutional_layer.c:737-749) */
-#define MI355_STORE_SATURATE 1  /* ref MKL path: clamp(0,255) then store (convolutional_layer.c:594) */
+#define MI355_STORE_SATURATE 1  /* builder-defined: the default path's formulas with clamp(0,255) BEFORE the store.  Equals the MKL
+                                   flavour's epilogue (convolutional_layer.c:572-596) for LEAKY / LINEAR / RELU6 on every int32
+                                   (proved exhaustively, tests/test_host_cpu.py), differs for RELU (:591 adds no zero point);
+                                   that flavour cannot be built here, so this mode is NOT pinned against a reference output */
 
 /* accumulation semantics */
-#define MI355_ACC_EXACT 0    /* exact int32 on V_MFMA_I32_16X16X64_I8 (== ref MKL path, cblas_gemm_s16s16s32) */
+#define MI355_ACC_EXACT 0    /* exact int32 on V_MFMA_I32_*_I8: the integers the reference's formula defines; equals the default build
+                                wherever its fp32 accumulation is exact (pinned: tests/test_gpu_refpin.py) and, by cblas_gemm_s16s16s32's
+                                contract, the MKL flavour's accumulators (that flavour is unbuildable here: unpinned) */
 #define MI355_ACC_REF_F32 1  /* bit-faithful emulation of ref src/gemm.c:279-299 (fp32 step-wise accumulate,
                                 two passes); slow verification kernel, never on the throughput path */
 

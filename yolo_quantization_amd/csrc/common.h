@@ -39,7 +39,7 @@ struct ConvBlobHeader {
 
 // ---------------------------------------------------------------------------------------------------------
 // Requantise epilogue: ref src/convolutional_layer.c:726-751.  FP64 with two truncations, activation, zero point,
-// uint8 store that wraps (default path) or saturates (MKL path).  `acc` is the true pre-requant accumulator.
+// uint8 store that wraps (default path) or saturates (builder-defined mode, see mi355_yolo_int8.h).  `acc` is the true pre-requant accumulator.
 // Compile with -ffp-contract=off: every double op below must stay a separate IEEE operation.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t requant_u8(int32_t acc, int32_t bias, double M, double S, int zp_act, int act,
