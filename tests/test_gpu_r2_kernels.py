@@ -143,3 +143,17 @@ def test_fused_residual_add_is_refused_where_no_kernel_has_it():
         blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, k, bias, mv, sv))
         d = binding.ConvDesc(n, c, k, 1, k // 2, binding.ACT["leaky"], 0, 0, 0, 23, 0.05)
         assert S.mi355_conv_shortcut_forward(C.byref(d), xt.ref(), blob.ptr, rt.ref(), yt.ref(), 40000, 40000, 0, 0, None) == -22
+
+
+def test_route_with_channel_counts_not_multiple_of_16():
+    """forward_route_layer_quant (ref: src/route_layer.c:107-130) concatenates any channel counts; the 16-byte-group copy kernel
+    serves aligned offsets, a byte-granular one the rest."""
+    rng = np.random.default_rng(8)
+    S = binding.shim()
+    for chans in ((30, 48, 20), (16, 30), (255, 255), (7,)):
+        xs = [rng.integers(0, 256, (2, c, 5, 7), dtype=np.uint8) for c in chans]
+        ts = [binding.DevTensor.from_nchw(x, 3) for x in xs]
+        y = binding.DevTensor(2, 5, 7, sum(chans), 3)
+        arr = (C.POINTER(binding.Tensor) * len(ts))(*[C.pointer(t.t) for t in ts])
+        binding.check(S.mi355_route_forward(arr, len(ts), y.ref(), None), "route")
+        assert np.array_equal(y.to_nchw(), np.concatenate(xs, axis=1)), chans

@@ -53,6 +53,30 @@ __global__ __launch_bounds__(256) void copy_cells_kernel(const CopyArgs a)
 }
 
 
+// route inputs whose channel count is not a multiple of 16 (a concat offset then falls inside a 16-byte group): one thread per
+// (cell, byte).  Rare (the reference's nets concatenate 128- / 256-channel maps); correctness path, not a tuned one.
+__global__ __launch_bounds__(256) void copy_cell_bytes_kernel(const CopyArgs a, int nbytes)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.B * a.OH * a.OW * nbytes;
+    if (idx >= total) return;
+    const int c = (int)(idx % nbytes);
+    const long p = idx / nbytes;
+    const int ox = (int)(p % a.OW);
+    const int oy = (int)((p / a.OW) % a.OH);
+    const int b = (int)(p / ((long)a.OW * a.OH));
+    const long cell = a.in_lead + ((long)b * (a.H + 1) + (oy + 1)) * (a.W + 1) + ox;
+    const long ocell = a.out_lead + ((long)b * (a.OH + 1) + (oy + 1)) * (a.OW + 1) + ox;
+    a.y[ocell * a.cs_out + a.coff + c] = a.x[cell * a.cs_in + c];
+}
+
+int copy_cell_bytes_launch(const CopyArgs &a, int nbytes, hipStream_t st)
+{
+    const long total = (long)a.B * a.OH * a.OW * nbytes;
+    hipLaunchKernelGGL(copy_cell_bytes_kernel, dim3(nblk(total)), dim3(256), 0, st, a, nbytes);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
 // reference layout [B][C][H][W] uint8 -> PHWC.  cs == 4: plain bytes (c0,c1,c2,0); else biased (^0x80).
 __global__ __launch_bounds__(256) void nchw_to_phwc_kernel(const LayoutArgs a)
 {

@@ -125,6 +125,7 @@ int conv_first_mfma_launch(AuxArgs &a, hipStream_t st);
 int conv_ref_f32_launch(AuxArgs &a, hipStream_t st);
 int maxpool_launch(const PoolArgs &a, hipStream_t st);
 int copy_cells_launch(const CopyArgs &a, hipStream_t st);
+int copy_cell_bytes_launch(const CopyArgs &a, int nbytes, hipStream_t st);
 int nchw_to_phwc_launch(const LayoutArgs &a, hipStream_t st);
 int phwc_to_nchw_launch(const LayoutArgs &a, hipStream_t st);
 int dequant_cells_launch(const DequantArgs &a, hipStream_t st);

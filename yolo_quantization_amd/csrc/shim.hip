@@ -573,18 +573,25 @@ int mi355_route_forward(const mi355_tensor *const *xs, int n, const mi355_tensor
 {
     if (!xs || n <= 0 || !y || !y->data) return einval("route: null");
     int coff = 0;
+    bool aligned = true;  // every input starts on a 16-byte group of the output cell
     for (int i = 0; i < n; ++i) {
         const mi355_tensor *x = xs[i];
-        if (!x || !x->data || x->cs % 16 || x->C % 16 || x->B != y->B || x->H != y->H || x->W != y->W)
-            return einval("route: input layout (channels must be multiples of 16)");
-        if (coff + x->C > y->cs) return einval("route: too many channels");
-        CopyArgs a{(const uint8_t *)x->data, (uint8_t *)y->data, x->B, x->H, x->W, y->H, y->W, x->cs, y->cs, x->lead,
-                   y->lead, x->C / 16, 1, coff};
-        int rc = copy_cells_launch(a, (hipStream_t)stream);
-        if (rc) return rc;
+        if (!x || !x->data || x->cs % 16 || x->B != y->B || x->H != y->H || x->W != y->W) return einval("route: input layout");
+        if (i + 1 < n && x->C % 16) aligned = false;
         coff += x->C;
     }
     if (coff != y->C) return einval("route: channel sum != y.C");
+    coff = 0;
+    for (int i = 0; i < n; ++i) {
+        const mi355_tensor *x = xs[i];
+        CopyArgs a{(const uint8_t *)x->data, (uint8_t *)y->data, x->B, x->H, x->W, y->H, y->W, x->cs, y->cs, x->lead,
+                   y->lead, (x->C + 15) / 16, 1, coff};
+        // 16-byte groups when every offset is aligned (the last input may end inside a group: its pad bytes land in the output
+        // cell's own padding); else byte by byte
+        const int rc = aligned ? copy_cells_launch(a, (hipStream_t)stream) : copy_cell_bytes_launch(a, x->C, (hipStream_t)stream);
+        if (rc) return rc;
+        coff += x->C;
+    }
     return MI355_OK;
 }
 
