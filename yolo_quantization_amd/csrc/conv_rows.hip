@@ -117,14 +117,20 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     constexpr int TM = BM / WMW, TN = BN / WNW;
     constexpr int MS = TM / 32, NS = TN / 32;
     constexpr int ACH = BM / 16;
-    constexpr int APT = (ACH + NW - 1) / NW;
+    // DMA waves: in the 8-wave 3x3 kernel only the older half of the workgroup (waves 0..3, one per SIMD) issues DMA.  The
+    // younger wave of every SIMD loses the issue arbitration and reaches the barrier last anyway; freed of its DMA
+    // instructions (~60-180 clocks each) the two halves arrive together.  A wave that issues nothing has vmcnt = 0: the
+    // counted waits below are no-ops for it
+    // (Sharing the prologue DMA out over all eight waves -- the younger ones fetching what step 0 needs -- measured the same.)
+    constexpr int DW = (NW == 8 && KS == 3) ? 4 : NW;
+    constexpr int APT = (ACH + DW - 1) / DW;
     constexpr int HALO = (KS == 3) ? 1 : 0;
     constexpr int PIECEB = RS * 16;     // bytes between 16-byte pieces of a row
     constexpr int CPR = RS / 16;        // 1 KiB DMA chunks per row
     constexpr int OSTR = BM + 4;
     constexpr int RA_STAGES = ra_stages<KS, BN>();
     constexpr int RB_STAGES = rb_stages<KS, BN>();
-    constexpr int NBS = rows_nb_slots(BN, RS, NW, KS);  // B DMA slots per wave per chunk
+    constexpr int NBS = rows_nb_slots(BN, RS, DW, KS);  // B DMA slots per (DMA) wave per chunk
     constexpr int SPS = (NBS + 3) / 4;                  // ... issued per K-step over a chunk's first four steps (3x3 loop)
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
 
@@ -149,6 +155,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WNW, wn = wave % WNW;
     const int kh = lane >> 5, lj = lane & 31;
+    const int dwave = wave & (DW - 1);  // index into the DMA tables
+    const bool issuer = wave < DW;      // steady-state DMA wave
     TS(0);
 
     int logical;
@@ -229,12 +237,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     unsigned adst[APT];
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
-        const int ch = min(wave + i * NW, ACH - 1);
+        const int ch = min(dwave + i * DW, ACH - 1);
         aptr[i] = a.wp + ((size_t)(mtile * ACH + ch) * a.ksteps + (size_t)rot * (a.ksteps / a.nchunks)) * 1024;
         adst[i] = lds0 + (ch << 10);
     }
     const unsigned lane16 = lane * 16;
     auto issueA_next = [&](unsigned stage_off) {  // fetch the next slab into the ring stage at byte offset stage_off
+        if (DW < NW && !issuer) return;
         const bool wrap = --aleft == 0;
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     unsigned bvoff[NBS], bdst[NBS];
 #pragma unroll
     for (int i = 0; i < NBS; ++i) {
-        const int j = min(wave + i * NW, ndma - 1);
+        const int j = min(dwave + i * DW, ndma - 1);
         const int r = j / CPR, cj = j - r * CPR;
         const int o = cj * 1024 + lane * 16;
         const int p = o / PIECEB, c = (o - p * PIECEB) >> 4;
@@ -262,6 +271,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     }
     auto issueB_slots = [&](int chunk, auto lo_c, auto hi_c) {  // slots [LO, HI) of channel chunk `chunk`
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        if (DW < NW && !issuer) return;
         const unsigned boff = (chunk % RB_STAGES) * bbytes;
         int phys = chunk + rot;  // rotated walk, see above
         if (phys >= a.nchunks) phys -= a.nchunks;
@@ -767,6 +777,7 @@ template <int BM, int BN, int WMW, int WNW, int RS, int KS>
 static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
 {
     constexpr int NW = WMW * WNW, NT = 64 * NW;
+    constexpr int DW = (NW == 8 && KS == 3) ? 4 : NW;  // DMA waves, as in the kernel
     constexpr int HALO = (KS == 3) ? 1 : 0;
     if (a.mpad % BM) return MI355_EINVAL;
     a.mtiles = a.mpad / BM;
@@ -774,7 +785,7 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     // rows spanned by BN consecutive pixels: pixel rows + one pad row per image boundary crossed, + halo rows
     a.rows_cap = (BN - 2 + a.W) / a.W + 1 + (BN - 2 + a.H * a.W) / (a.H * a.W) + 2 * HALO;
     const int ndma = a.rows_cap * (RS / 16);
-    if ((ndma + NW - 1) / NW > rows_nb_slots(BN, RS, NW, KS)) return MI355_EINVAL;  // map too narrow for this tile
+    if ((ndma + DW - 1) / DW > rows_nb_slots(BN, RS, DW, KS)) return MI355_EINVAL;  // map too narrow for this tile
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     a.rowb = RS * 64 + 16 * (a.W & 15);
     size_t lds = (size_t)ra_stages<KS, BN>() * BM * 64 + (size_t)rb_stages<KS, BN>() * a.rows_cap * a.rowb + (size_t)a.rows_cap * RS * 4;
