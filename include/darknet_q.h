@@ -98,7 +98,8 @@ struct layer {
     int32_t *output_int32_gpu;     /* reference layout; allocated only when net->dump_int32 */
     float *output_gpu;             /* reference layout float (quant_stop convs, yolo) */
     uint8_t *output_uint8_nchw_gpu; /* scratch for pull_layer_output */
-    int fuse_next_pool; /* this conv and the 2x2/2 maxpool after it run as one kernel (set by the prep) */
+    int fuse_next_pool; /* this conv and the 2x2 maxpool (stride 2, or stride 1 behind a 128 / 256-channel conv) after it run as one kernel (set by the prep) */
+    int fuse_pool_keep; /* ... which also stores the conv's own tensor: a route reads it */
     int fuse_next_upsample; /* this conv stores its pixels straight into the upsample layer's tensor after it */
     int conv_kernel;    /* kernel family that served this conv's last forward (mi355_last_conv_kernel) */
     int fuse_next_yolo; /* this quant_stop head conv also writes the activations of the yolo layer after it */

@@ -614,7 +614,7 @@ def _run_host_net(cfg, wts, x_u8_batch, accum, store=binding.STORE_WRAP, graph=F
         net.forward()
     net.sync()
     outs = [net.pull(i) for i in range(net.n)]
-    info = [dict(inf, fused=net.is_fused(i), kernel=net.conv_kernel(i)) for i, inf in enumerate(net.info)]
+    info = [dict(inf, fused=net.is_fused(i), fuses_next=net.fuses_next(i), kernel=net.conv_kernel(i)) for i, inf in enumerate(net.info)]
     net.close()
     return outs, info
 
@@ -722,7 +722,9 @@ def test_yolov3_tiny_batch64_properties(cfg_dir, tmp_path):
     xb[1::2] = synth.synth_image_u8(3, 416, 416, seed=8)  # two distinct images interleaved
     outs, info = _run_host_net(cfg, wts, xb, binding.ACC_EXACT, graph=True, dump_int32=False)
     one, _ = _run_host_net(cfg, wts, x[None], binding.ACC_EXACT)
-    assert sum(inf["fused"] for inf in info) == 5  # L0, L2, L4, L6 fused with their maxpools, L18 with its upsample
+    # L0, L2, L4, L6, L10 (stride-1 pool) fused with their maxpools, L18 with its upsample: own tensor not stored; L8 + L9 fused too, but
+    # L8's tensor is stored as well (the route to layer 20 reads it); the two heads carry their yolo layers
+    assert sum(inf["fused"] for inf in info) == 6 and [i for i, inf in enumerate(info) if inf["fuses_next"]] == [0, 2, 4, 6, 8, 10, 15, 18, 22]
     # every specialised kernel is exercised by the batch-64 net: first layer, conv + pool (16 / 32 / 64 channels), the
     # weights-stationary 3x3 (conv_ws3) and 1x1 (conv1x1) kernels, the row-image kernel on the two deep 3x3 layers
     assert {i: inf["kernel"] for i, inf in enumerate(info) if inf["type"] == binding.T_CONV} == \

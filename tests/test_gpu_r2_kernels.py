@@ -157,3 +157,60 @@ def test_route_with_channel_counts_not_multiple_of_16():
         arr = (C.POINTER(binding.Tensor) * len(ts))(*[C.pointer(t.t) for t in ts])
         binding.check(S.mi355_route_forward(arr, len(ts), y.ref(), None), "route")
         assert np.array_equal(y.to_nchw(), np.concatenate(xs, axis=1)), chans
+
+
+@pytest.mark.parametrize("B,c,n,H,W,act,mode", [(64, 128, 256, 26, 26, "leaky", "s2"),    # yolov3-tiny layers 8 + 9 at the bench's batch
+                                               (24, 128, 256, 26, 26, "relu6", "s2"),    # tiles of 16 windows that straddle images
+                                               (16, 256, 512, 20, 18, "leaky", "s2"),    # two K parts: the bytes are staged in the partial-sum slots
+                                               (64, 256, 512, 13, 13, "leaky", "s1"),    # layers 10 + 11
+                                               (40, 256, 512, 13, 13, "linear", "s1"),   # fewer images than workgroups
+                                               (300, 128, 256, 9, 11, "relu6", "s1")])   # several whole-image tiles per (persistent) workgroup
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+@pytest.mark.parametrize("keep", [False, True], ids=["pooled-only", "both-tensors"])
+def test_ws3_conv_with_fused_maxpool(B, c, n, H, W, act, mode, store, keep):
+    """conv_ws3.hip + the maxpool behind it in one kernel (mi355_conv_pool_forward): the 2x2 / stride-2 window (ypool of half
+    the size) and the reference's 2x2 / stride-1 window (pad = 1: ypool of the conv's own size, windows clipped at the right /
+    lower border; ref src/maxpool_layer.c:109-146), with and without the conv's own tensor.  The kernel pools the STORED
+    bytes, so wrapped values inside a window behave as in the reference.  Oracle: conv -> requantise -> orc_maxpool_u8 on the
+    distinct images (the batch repeats four images)."""
+    rng = np.random.default_rng(B + c + n + H)
+    S = binding.shim()
+    x4 = rng.integers(0, 256, (4, c, H, W), dtype=np.uint8)
+    x = x4[np.arange(B) % 4]
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3, 2.0 ** -13, 2.0 ** -9)   # some accumulators leave 0..255: wrap != saturate
+    zp_in, zp_act = 23, 31
+    xt = binding.DevTensor.from_nchw(x, zp_in)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv))
+    y = binding.DevTensor(B, H, W, n, zp_act) if keep else None
+    yp = binding.DevTensor(B, H // 2, W // 2, n, zp_act) if mode == "s2" else binding.DevTensor(B, H, W, n, zp_act)
+    d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT[act], store, binding.ACC_EXACT, zp_in, zp_act, 0.05)
+    binding.check(S.mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, y.ref() if keep else None, yp.ref(), None), "conv_pool")
+    assert S.mi355_last_conv_kernel() == 4
+    u8 = np.stack([oracle.requant(oracle.conv_acc(x4[b], wq, zp_w, 3, 1, 1, zp_in), bias, mv, sv, zp_act, oracle.ACT[act], store).reshape(n, H, W)
+                   for b in range(4)])
+    sat = np.stack([oracle.requant(oracle.conv_acc(x4[0], wq, zp_w, 3, 1, 1, zp_in), bias, mv, sv, zp_act, oracle.ACT[act], binding.STORE_SATURATE)])
+    if store == binding.STORE_WRAP:
+        assert (sat[0].reshape(n, H, W) != u8[0]).any(), "case should exercise wrapped bytes"
+    pool = np.stack([oracle.maxpool_u8(u8[b], 2, 2 if mode == "s2" else 1, 1) for b in range(4)])
+    got = yp.to_nchw()
+    for b in range(B):
+        assert np.array_equal(got[b], pool[b % 4]), f"pooled tensor, image {b}"
+    if keep:
+        goty = y.to_nchw()
+        for b in range(B):
+            assert np.array_equal(goty[b], u8[b % 4]), f"conv tensor, image {b}"
+
+
+def test_ws3_fused_maxpool_is_refused_outside_its_domain():
+    """MI355_EINVAL (nothing launched) where the weights-stationary kernel cannot fuse: too few pixels per workgroup, odd
+    maps for the stride-2 window, the stride-1 window behind any other kernel family."""
+    S = binding.shim()
+    rng = np.random.default_rng(3)
+    for (B, c, n, H, W, s1) in ((1, 128, 256, 26, 26, False), (8, 128, 256, 13, 13, False), (6, 256, 512, 13, 13, True), (8, 64, 128, 13, 13, True), (8, 512, 1024, 13, 13, True)):
+        x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+        wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3)
+        xt = binding.DevTensor.from_nchw(x, 0)
+        yp = binding.DevTensor(B, H, W, n, 0) if s1 else binding.DevTensor(B, H // 2, W // 2, n, 0)
+        blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv))
+        d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT["leaky"], 0, 0, 0, 23, 0.05)
+        assert S.mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, None, yp.ref(), None) == -22, (B, c, n, H, W, s1)

@@ -267,6 +267,7 @@ def host():
             getattr(L, n).argtypes = [vp, ci]
         L.dnq_layer_prep.argtypes = [vp, ci] + [vp] * 6
         L.dnq_layer_is_fused.argtypes = [vp, ci]
+        L.dnq_layer_fuses_next.argtypes = [vp, ci]
         L.dnq_layer_shortcut.argtypes = [vp, ci, vp]
         L.network_save_packed.argtypes = [vp, C.c_char_p]
         L.network_load_packed.argtypes = [vp, C.c_char_p]
@@ -396,8 +397,12 @@ class Net:
         return int(self.H.dnq_layer_conv_kernel(self.h, i))
 
     def is_fused(self, i):
-        """conv i runs fused with the maxpool after it: its own uint8 tensor is not stored."""
+        """conv i runs fused with the layer after it and its own uint8 tensor is not stored."""
         return bool(self.H.dnq_layer_is_fused(self.h, i))
+
+    def fuses_next(self, i):
+        """layer i + 1 runs inside conv i's kernel (conv i's own tensor may be stored too: a conv + pool whose output a route reads)."""
+        return bool(self.H.dnq_layer_fuses_next(self.h, i))
 
     def prep(self, i):
         n = max(self.info[i]["n"], 1)

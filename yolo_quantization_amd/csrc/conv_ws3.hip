@@ -58,10 +58,28 @@ extern "C" int mi355_debug_read_wp3(long long *host)
 #define WP3_STORE() do { } while (0)
 #endif
 
+// Fused stride-2 pool: pixel order inside a block of 32 (= 8 windows = 2 image rows x 16 columns).  A ds_read_b128 is served
+// in lane groups {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (one LDS cycle each when the 16 lanes hit 16 different 16-byte
+// bank groups): 16 consecutive cells of ONE image row always do (cells are an odd number of 16-byte units apart), cells of two
+// rows generally do not.  So the first lane group takes the windows' upper row, the second their lower row.
+__host__ __device__ constexpr int ws3_pm2_cell(int l)  // lane of the block -> row << 4 | column
+{
+    return l < 4 ? l : l < 12 ? 16 | (l - 4) : l < 16 ? l - 8 : l < 20 ? 16 | (l - 8) : l < 28 ? l - 12 : 16 | (l - 16);
+}
+__host__ __device__ constexpr int ws3_pm2_lane(int row, int col)  // inverse
+{
+    return row == 0 ? (col < 4 ? col : col < 8 ? col + 8 : col + 12) : (col < 8 ? col + 4 : col < 12 ? col + 8 : col + 16);
+}
 constexpr int WS3_GMAX = 8;    // groups of 32 pixels per tile
 constexpr int WS3_UB = 8;      // 16-byte staging loads in flight per thread
 
-template <int KP, int ACT, bool SAT>
+// PM: fused maxpool after the conv (ConvArgs::pool_mode).  The requantised bytes of the tile are staged in LDS (one 32 pixel x
+// 32 filter slot per wave and group: for KP == 2 the slot of the partial sums the wave has just consumed), and after the last
+// group the workgroup forms the window maxima from the bytes -- the reference's order (bytes first, then the maximum:
+// src/maxpool_layer.c:134-146), so wrapped bytes need no special case.  PM == 2: the tile is a run of whole 2x2 windows,
+// pixel 4 w + j = position j of window w, and the conv's own tensor is stored too when a.y is given (a route reads it);
+// PM == 1: whole-image tiles, window = the pixel, its right, lower and lower-right neighbours inside the image.
+template <int KP, int ACT, bool SAT, int PM>
 __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
 {
     constexpr int KST = 36, PIECES = 8 * KP, PSH = (KP == 1) ? 3 : 4;
@@ -70,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     const int ncell = a.sm_ncell;                               // cells per LDS image row = W + 2
     const int RS = a.rows_cap;                                  // LDS image rows (row R lives at R % RS)
     const int NQ = a.sm_nq, NF = 32 * NQ;
-    const int TP = a.sm_tp, G = (TP + 31) >> 5;
+    const int TP = a.sm_tp, G = ((PM == 2 ? 4 * TP : TP) + 31) >> 5;  // PM == 2: TP counts 2x2 windows (8 per group of 32 pixels)
     int *ldsS = reinterpret_cast<int *>(smem + a.sm_pieceb);              // [RS * ncell] per-cell channel sums
     int *ldsSX = ldsS + ((RS * ncell + 3) & ~3);                          // [G][32] 3x3 box sum of the pixel
     int *ldsBase = ldsSX + G * 32;                                        // [G][32] image row | column << 16 of tap (0,0)
@@ -79,6 +97,8 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     int *ldsDZ = reinterpret_cast<int *>(ldsMP + NF);                     // [NF] 128 - zp_w
     int *ldsCB = ldsDZ + NF;                                              // [NF] cw + bias
     char *ldsRed = smem + a.sm_red_off;                                   // K-part partial sums, 4 KiB per (quad, set, group)
+    char *ldsPT = smem + a.sm_pt_off;                                     // PM: staged bytes, slot (set, quad, group) = [32 px][36 B]
+    int *ldsPCell = ldsCell + G * 32;                                     // PM == 2: [G * 8] pooled cell of window w, -1: none
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -94,6 +114,21 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     // S x - 1 .. S x + 1, so only the pixel -> image-cell tables know about the stride
     const int W1 = a.W + 1, S = a.stride, OHd = a.OH, OWd = a.OW, hw = OHd * OWd;
     const bool pow2 = a.hdr->pow2 == 1;
+    const int OWp = OWd >> 1, ohwp = (OHd >> 1) * OWp;  // PM == 2: the pooled map
+    const int total_u = PM == 2 ? a.B * ohwp : a.total_n;  // tile units: windows or pixels
+    // first image row (flattened (b, y) row space) and row count of a tile's LDS image, halo rows included
+    auto tile_rows = [&](int u0, int u1, int &gr_first, int &nrows) {
+        int b0, r0, b1, r1;
+        if (PM == 2) {  // windows [u0, u1): conv rows 2 py .. 2 py + 1
+            b0 = u0 / ohwp; r0 = 2 * ((u0 - b0 * ohwp) / OWp);
+            b1 = (u1 - 1) / ohwp; r1 = 2 * (((u1 - 1) - b1 * ohwp) / OWp) + 1;
+        } else {
+            b0 = u0 / hw; r0 = (u0 - b0 * hw) / OWd;
+            b1 = (u1 - 1) / hw; r1 = ((u1 - 1) - b1 * hw) / OWd;
+        }
+        gr_first = b0 * (a.H + 1) + S * r0 + 1;
+        nrows = b1 * (a.H + 1) + S * r1 + 1 - gr_first + 3;
+    };
     v4i wf[KST];
     WP3_DECL;
     TS3(0);
@@ -101,13 +136,11 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     auto stage = [&](int tile, auto with_a_c) {
         constexpr bool WITH_A = decltype(with_a_c)::value;
         constexpr int UB = WITH_A ? WS3_UB : 4;  // later tiles stage with fewer loads in flight: the A fragments hold 144 VGPRs
-        const int p0 = tile * TP, p1 = min(p0 + TP, a.total_n);  // this tile's pixels [p0, p1)
+        const int p0 = tile * TP, p1 = min(p0 + TP, total_u);  // this tile's pixels (PM == 2: windows) [p0, p1)
 
         // ---- tile geometry: image rows [first - 1, last + 1] of the flattened (b, y) row space, columns -1 .. W
-        const int b0 = p0 / hw, r0 = (p0 - b0 * hw) / OWd;
-        const int b1 = (p1 - 1) / hw, r1 = ((p1 - 1) - b1 * hw) / OWd;
-        const int gr_first = b0 * (a.H + 1) + S * r0 + 1;
-        const int nrows = b1 * (a.H + 1) + S * r1 + 1 - gr_first + 3;
+        int gr_first, nrows;
+        tile_rows(p0, p1, gr_first, nrows);
         const long org = (long)a.in_lead + (long)(gr_first - 1) * W1 - 1;
         // LDS image: cell-major, row R (0 = the row above the tile's first pixel row) at cells [(R % RS) ncell, +ncell), cell
         // c = column c - 1; a cell is its C channels followed by 16 B of skew (CELLB / 16 is odd: the 16 lanes of a
@@ -160,14 +193,11 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
         __syncthreads();  // every wave is done with the previous tile's image, tables and parked partial sums
         stage(tile, std::false_type{});
     }
-    const int p0 = tile * TP, p1 = min(p0 + TP, a.total_n);  // this tile's pixels [p0, p1)
+    const int p0 = tile * TP, p1 = min(p0 + TP, total_u);  // this tile's pixels (PM == 2: windows) [p0, p1)
 
     // ---- tile geometry: image rows [first - 1, last + 1] of the flattened (b, y) row space, columns -1 .. W
-    const int b0 = p0 / hw, r0 = (p0 - b0 * hw) / OWd;
-    const int b1 = (p1 - 1) / hw, r1 = ((p1 - 1) - b1 * hw) / OWd;
-    const int gr_first = b0 * (a.H + 1) + S * r0 + 1;
-    const int nrows = b1 * (a.H + 1) + S * r1 + 1 - gr_first + 3;
-    const long org = (long)a.in_lead + (long)(gr_first - 1) * W1 - 1;
+    int gr_first, nrows;
+    tile_rows(p0, p1, gr_first, nrows);
     // LDS image: cell-major, row R (0 = the row above the tile's first pixel row) at cells [(R % RS) ncell, +ncell), cell
     // c = column c - 1; a cell is its C channels followed by 16 B of skew (CELLB / 16 is odd: the 16 lanes of a
     // B-fragment read, one cell apart, hit 16 different 16-byte bank groups).  Every tap / channel-block offset of a
@@ -184,13 +214,26 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     }
     // ---- pixels of the tile: image offset of tap (0,0), output cell
     for (int idx = tid; idx < G * 32; idx += 512) {
-        const int p = p0 + idx;
-        const bool valid = p < p1;
-        const int pc = valid ? p : p1 - 1;  // idle lanes shadow the tile's last pixel
-        const int b = pc / hw, rem = pc - b * hw;
-        const int y = rem / OWd, x = rem - y * OWd;
-        ldsBase[idx] = (b * (a.H + 1) + S * y + 1 - gr_first) | ((S * x) << 16);
-        ldsCell[idx] = valid ? a.out_lead + (b * (OHd + 1) + (y + 1)) * (OWd + 1) + x : -1;
+        if (PM == 2) {  // a block of 32 pixels = 8 windows = 16 columns x 2 rows; lane -> (row, column) by ws3_pm2_cell
+            const int rc = ws3_pm2_cell(idx & 31), j = ((rc >> 4) << 1) | (rc & 1);
+            const int q = p0 + (idx >> 5) * 8 + ((rc & 15) >> 1);
+            const bool valid = q < p1;
+            const int qc = valid ? q : p1 - 1;  // idle lanes shadow the tile's last window
+            const int b = qc / ohwp, rem = qc - b * ohwp;
+            const int py = rem / OWp, px = rem - py * OWp;
+            const int y = 2 * py + (j >> 1), x = 2 * px + (j & 1);
+            ldsBase[idx] = (b * (a.H + 1) + y + 1 - gr_first) | (x << 16);
+            ldsCell[idx] = valid ? a.out_lead + (b * (OHd + 1) + (y + 1)) * (OWd + 1) + x : -1;
+            if (j == 0) ldsPCell[q - p0] = valid ? a.pool_lead + (b * ((OHd >> 1) + 1) + (py + 1)) * (OWp + 1) + px : -1;
+        } else {
+            const int p = p0 + idx;
+            const bool valid = p < p1;
+            const int pc = valid ? p : p1 - 1;  // idle lanes shadow the tile's last pixel
+            const int b = pc / hw, rem = pc - b * hw;
+            const int y = rem / OWd, x = rem - y * OWd;
+            ldsBase[idx] = (b * (a.H + 1) + S * y + 1 - gr_first) | ((S * x) << 16);
+            ldsCell[idx] = valid ? a.out_lead + (b * (OHd + 1) + (y + 1)) * (OWd + 1) + x : -1;
+        }
     }
     __syncthreads();
     TS3(2);
@@ -274,9 +317,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
             acc[grp * 4 + 0] = c4.x; acc[grp * 4 + 1] = c4.y; acc[grp * 4 + 2] = c4.z; acc[grp * 4 + 3] = c4.w;
         }
     };
-    auto finish = [&](const v16i &acc, int g) {
+    auto finish = [&](const v16i &acc, int g, int i) {  // i: index of group g within this wave set (its staging slot)
         const int sx = ldsSX[g * 32 + lj];
-        const int cell = ldsCell[g * 32 + lj];
+        const int cell = (PM && !a.y) ? -1 : ldsCell[g * 32 + lj];
+        char *pt = ldsPT + (size_t)((wset * NQ + wq) * gsmax + i) * a.sm_pt_stride + lj * 36 + 4 * kh;
         uint8_t *dst = a.y + (size_t)(cell < 0 ? 0 : cell) * a.out_cs + f0 + lw + 4 * kh;
         // fused residual add: the `from` tensor's bytes of the same pixel and channels, fetched before the requantisation
         uint32_t resv[4] = {0, 0, 0, 0};
@@ -319,6 +363,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
                     *reinterpret_cast<uint32_t *>(dst + 16 * half) = o0;
                     *reinterpret_cast<uint32_t *>(dst + 16 * half + 8) = o1;
                 }
+                if (PM) {
+                    *reinterpret_cast<uint32_t *>(pt + 16 * half) = o0;
+                    *reinterpret_cast<uint32_t *>(pt + 16 * half + 8) = o1;
+                }
             }
         } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
 #pragma unroll
@@ -332,6 +380,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
                 uint32_t o = pack4_biased(v[0], v[1], v[2], v[3]);
                 if (a.res) o = shortcut4_biased(o, resv[grp], a.sc_ka, a.sc_kb, a.sc_k0);
                 if (cell >= 0) *reinterpret_cast<uint32_t *>(dst + 8 * grp) = o;
+                if (PM) *reinterpret_cast<uint32_t *>(pt + 8 * grp) = o;
             }
         }
     };
@@ -342,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
             v16i acc;
             seed_bias(acc);
             kloop(acc, ldsBase[g * 32 + lj]);
-            finish(acc, g);
+            finish(acc, g, i);
             WP3_MARK(2);
         }
     } else {
@@ -375,8 +424,43 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
                 acc[4 * j] = t[0]; acc[4 * j + 1] = t[1]; acc[4 * j + 2] = t[2]; acc[4 * j + 3] = t[3];
             }
             kloop(acc, ldsBase[g * 32 + lj]);
-            finish(acc, g);
+            finish(acc, g, i);
             WP3_MARK(2);
+        }
+    }
+    if (PM) {
+        __syncthreads();  // every group's bytes are staged
+        // NQ and nset are powers of two (conv_ws3_eligible): no divisions in the loops below
+        const int lgND = 3 + __builtin_ctz(NQ), ND = 1 << lgND;  // dwords of a pixel's filters in this workgroup
+        const int lgns = __builtin_ctz(nset);
+        // staged dword: pixel idx of the tile, dword d of the workgroup's filters (quad d >> 3, 4 (d & 7) bytes into its 32)
+        auto staged = [&](int idx, int d) {
+            const int g = idx >> 5, st = g & (nset - 1), i = g >> lgns;
+            return *reinterpret_cast<const uint32_t *>(ldsPT + ((st * NQ + (d >> 3)) * gsmax + i) * a.sm_pt_stride + (idx & 31) * 36 + (d & 7) * 4);
+        };
+        if (PM == 2) {
+            const int nw = p1 - p0;
+            for (int it = tid; it < (nw << lgND); it += 512) {
+                const int w = it >> lgND, d = it & (ND - 1);
+                const int blk = (w >> 3) << 5, c0 = (w & 7) << 1;  // the window's two columns in its block
+                const uint32_t m = max_s8x4(max_s8x4(staged(blk + ws3_pm2_lane(0, c0), d), staged(blk + ws3_pm2_lane(0, c0 + 1), d)),
+                                            max_s8x4(staged(blk + ws3_pm2_lane(1, c0), d), staged(blk + ws3_pm2_lane(1, c0 + 1), d)));
+                *reinterpret_cast<uint32_t *>(a.ypool + (size_t)ldsPCell[w] * a.pool_cs + f0 + 4 * d) = m;
+            }
+        } else {  // whole-image tiles (the launcher guarantees it): pixel idx = (y, x) of image p0 / hw; ldsBase holds (y | x << 16)
+            const int np = p1 - p0;
+            const int pdelta = a.pool_lead - a.out_lead;  // the pooled map has the conv map's geometry
+            for (int it = tid; it < (np << lgND); it += 512) {
+                const int idx = it >> lgND, d = it & (ND - 1);
+                const int rx = ldsBase[idx], y = rx & 0xFFFF, x = rx >> 16;
+                uint32_t m = staged(idx, d);
+                if (x + 1 < OWd) m = max_s8x4(m, staged(idx + 1, d));
+                if (y + 1 < OHd) {
+                    m = max_s8x4(m, staged(idx + OWd, d));
+                    if (x + 1 < OWd) m = max_s8x4(m, staged(idx + OWd + 1, d));
+                }
+                *reinterpret_cast<uint32_t *>(a.ypool + (size_t)(ldsCell[idx] + pdelta) * a.pool_cs + f0 + 4 * d) = m;
+            }
         }
     }
     }  // tiles
@@ -384,16 +468,16 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     WP3_STORE();
 }
 
-template <int KP, int ACT>
+template <int KP, int ACT, int PM>
 static int w3_launch_sat(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 {
     if (a.store_mode == MI355_STORE_SATURATE) {
-        auto kern = conv_ws3_kernel<KP, ACT, true>;
+        auto kern = conv_ws3_kernel<KP, ACT, true, PM>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MI355_EHIP;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
     } else {
-        auto kern = conv_ws3_kernel<KP, ACT, false>;
+        auto kern = conv_ws3_kernel<KP, ACT, false, PM>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MI355_EHIP;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -401,12 +485,20 @@ static int w3_launch_sat(ConvArgs &a, hipStream_t st, int grid, size_t lds)
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
 
-template <int KP>
+template <int KP, int PM>
 static int w3_launch_act(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 {
-    if (a.act == MI355_ACT_LEAKY) return w3_launch_sat<KP, MI355_ACT_LEAKY>(a, st, grid, lds);
-    if (a.act == MI355_ACT_RELU6) return w3_launch_sat<KP, MI355_ACT_RELU6>(a, st, grid, lds);
-    return w3_launch_sat<KP, MI355_ACT_LINEAR>(a, st, grid, lds);
+    if (a.act == MI355_ACT_LEAKY) return w3_launch_sat<KP, MI355_ACT_LEAKY, PM>(a, st, grid, lds);
+    if (a.act == MI355_ACT_RELU6) return w3_launch_sat<KP, MI355_ACT_RELU6, PM>(a, st, grid, lds);
+    return w3_launch_sat<KP, MI355_ACT_LINEAR, PM>(a, st, grid, lds);
+}
+
+template <int KP>
+static int w3_launch_pm(ConvArgs &a, hipStream_t st, int grid, size_t lds)
+{
+    if (a.pool_mode == 2) return w3_launch_act<KP, 2>(a, st, grid, lds);
+    if (a.pool_mode == 1) return w3_launch_act<KP, 1>(a, st, grid, lds);
+    return w3_launch_act<KP, 0>(a, st, grid, lds);
 }
 
 static int ws3_quads(int n, int c)
@@ -427,36 +519,56 @@ bool conv_ws3_eligible(int n, int c, int ksize)
 int conv_ws3_launch(ConvArgs &a, hipStream_t st)
 {
     const int c = a.cb * a.nchunks;
-    if (!conv_ws3_eligible(a.n, c, a.ksize) || !a.ws || !a.y || a.acc_out || a.ypool || a.y_f32 || a.yolo_out) return MI355_EINVAL;
-    if ((a.stride != 1 && a.stride != 2) || a.up != 1 || a.out_w < a.n) return MI355_EINVAL;
+    if (!conv_ws3_eligible(a.n, c, a.ksize) || !a.ws || a.acc_out || a.y_f32 || a.yolo_out) return MI355_EINVAL;
+    if (!a.ypool) a.pool_mode = 0;
+    const int pm = a.pool_mode;
+    if (!a.y && !pm) return MI355_EINVAL;
+    if (pm && (a.stride != 1 || a.res || a.pool_w < a.n || (pm == 2 && ((a.OH | a.OW) & 1)))) return MI355_EINVAL;
+    if ((a.stride != 1 && a.stride != 2) || a.up != 1 || (a.y && a.out_w < a.n)) return MI355_EINVAL;
     if (a.stride == 2 && ((a.H & 1) || (a.W & 1))) return MI355_EINVAL;  // even maps: output = the even positions
     const int kp = c / 128, nq = ws3_quads(a.n, c), pieces = 8 * kp;
     const int mtiles = a.n / (32 * nq), nset = 8 / (nq * kp);
-    const long total = a.total_n;
     const int S = a.stride, OHd = a.OH, OWd = a.OW, hw = OHd * OWd;  // pixels enumerate the output map (see the kernel)
+    const int OWp = OWd / 2, ohwp = (OHd / 2) * OWp;
+    const long total = pm == 2 ? (long)a.B * ohwp : a.total_n;  // tile units: 2x2 windows with the fused stride-2 pool, else pixels
+    const int upx = pm == 2 ? 4 : 1;                             // pixels per unit
     const int want = 256 / mtiles > 0 ? 256 / mtiles : 1;  // workgroups per filter tile: one round of the chip
     // LDS need of a plan with tiles of tp pixels (0: does not fit); fills the geometry fields of `a`
     auto plan = [&](int tp, size_t &lds_out) {
         const int ntiles = (int)((total + tp - 1) / tp);
-        const int G = (tp + 31) / 32;
+        const int G = (tp * upx + 31) / 32;
         int rows_cap = 0;
         for (int t = 0; t < ntiles; ++t) {
             const long p0 = (long)t * tp, p1 = (p0 + tp < total ? p0 + tp : total) - 1;
-            const int b0 = (int)(p0 / hw), r0 = (int)((p0 - (long)b0 * hw) / OWd);
-            const int b1 = (int)(p1 / hw), r1 = (int)((p1 - (long)b1 * hw) / OWd);
+            int b0, r0, b1, r1;
+            if (pm == 2) {
+                b0 = (int)(p0 / ohwp); r0 = 2 * (int)((p0 - (long)b0 * ohwp) / OWp);
+                b1 = (int)(p1 / ohwp); r1 = 2 * (int)((p1 - (long)b1 * ohwp) / OWp) + 1;
+            } else {
+                b0 = (int)(p0 / hw); r0 = (int)((p0 - (long)b0 * hw) / OWd);
+                b1 = (int)(p1 / hw); r1 = (int)((p1 - (long)b1 * hw) / OWd);
+            }
             const int nrows = b1 * (a.H + 1) + S * r1 - b0 * (a.H + 1) - S * r0 + 3;
             if (nrows > rows_cap) rows_cap = nrows;
         }
-        if (S == 1 && tp == hw && total % hw == 0 && rows_cap == a.H + 2) rows_cap = a.H + 1;  // whole-image tiles: the two pad rows alias
+        if (S == 1 && pm != 2 && tp == hw && total % hw == 0 && rows_cap == a.H + 2) rows_cap = a.H + 1;  // whole-image tiles: the two pad rows alias
         const int cells = rows_cap * (a.W + 2);
         size_t lds = (size_t)cells * (pieces + 1) * 16;
         const size_t imgb = lds;
-        lds += (size_t)((cells + 3) & ~3) * 4 + (size_t)G * 32 * 12;
+        lds += (size_t)((cells + 3) & ~3) * 4 + (size_t)G * 32 * 12 + (pm == 2 ? (size_t)G * 8 * 4 : 0);
         lds = (lds + 15) & ~(size_t)15;
         const size_t poff = lds;
         lds += (size_t)32 * nq * 16;
         const size_t roff = lds;
         if (kp == 2) lds += (size_t)nq * nset * ((G + nset - 1) / nset) * 4096;
+        // staged bytes of the fused pool: the consumed partial-sum slots when there are K parts, else slots of their own
+        a.sm_pt_off = (int)roff;
+        a.sm_pt_stride = 4096;
+        if (pm && kp == 1) {
+            a.sm_pt_off = (int)lds;
+            a.sm_pt_stride = 32 * 36;
+            lds += (size_t)nq * nset * ((G + nset - 1) / nset) * (32 * 36);
+        }
         if (lds > 160 * 1024) return false;
         a.sm_tp = tp;
         a.ntiles_n = ntiles;
@@ -471,9 +583,15 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
     size_t lds = 0;
     int nwg = 0;
     const int tp1 = (int)((total + want - 1) / want);  // one tile per workgroup
-    if (tp1 < 64) return MI355_EINVAL;                 // tiny batches: the row-image kernel is the better fit
-    if (tp1 <= WS3_GMAX * 32 && plan(tp1, lds)) {
+    if (pm == 1) {  // the stride-1 pool needs whole-image tiles: one per workgroup, or several per (persistent) workgroup
+        if (hw < 64 || hw > WS3_GMAX * 32 || a.B * mtiles < 128 || !plan(hw, lds)) return MI355_EINVAL;  // (half the chip idle: not worth it)
+        nwg = a.ntiles_n < want ? a.ntiles_n : want;
+    } else if (tp1 * upx < 64) {
+        return MI355_EINVAL;                           // tiny batches: the row-image kernel is the better fit
+    } else if (tp1 * upx <= WS3_GMAX * 32 && plan(tp1, lds)) {
         nwg = a.ntiles_n;
+    } else if (pm) {
+        return MI355_EINVAL;  // the fused pools exist for one tile per workgroup
     } else {
         // Several tiles per workgroup cost a staging pass and four barriers per tile: measured 94 us against the row-image
         // kernel's 68 us on 256->256 @52x52 (BASELINE config[1]), but 70 / 74 us against 104 / 103 us where that kernel
@@ -499,5 +617,5 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
     a.debug = mi355_debug_flags_get();
     a.sm_nq = nq;
     a.mtiles = mtiles;
-    return kp == 1 ? w3_launch_act<1>(a, st, mtiles * nwg, lds) : w3_launch_act<2>(a, st, mtiles * nwg, lds);
+    return kp == 1 ? w3_launch_pm<1>(a, st, mtiles * nwg, lds) : w3_launch_pm<2>(a, st, mtiles * nwg, lds);
 }

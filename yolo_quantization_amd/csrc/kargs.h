@@ -37,6 +37,9 @@ struct ConvArgs {
     int sm_ncell, sm_pieceb; // conv_small: cells per LDS image row; bytes of one 16-channel piece plane
     int sm_tp;               // conv_mid_pool: pooled pixels per tile
     int sm_nq, sm_red_off;   // conv_ws3: filter quads (waves) per K part and workgroup; LDS offset of the K-part partial sums
+    int pool_mode;           // conv_ws3: 0 = none, 2 = fused 2x2 / stride-2 maxpool (ypool = the pooled map), 1 = fused 2x2 / stride-1
+                             // maxpool (ypool = a map of the conv's own size; ref: pad = 1 -> window rows y..y+1, columns x..x+1, clipped)
+    int sm_pt_off, sm_pt_stride;  // conv_ws3: LDS offset / slot stride of the staged output bytes the fused pool reads
     int up;                  // conv_rows: fused nearest-neighbour upsample factor of the stored tensor (1 = none)
     float *yolo_out;         // fused yolo head: activated copy of y_f32 (same layout) or null
     int yolo_per;            // classes + 5

@@ -404,11 +404,16 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     if (x->C != d->c) return einval("conv_forward: x.C != desc.c");
     if (y && (y->C != d->n || y->B != x->B || y->H != OH * up || y->W != OW * up || !y->data))
         return einval("conv_forward: y shape");
-    if (ypool) {
+    // ypool of the pooled size: the 2x2 / stride-2 maxpool; ypool of the conv's own size: the 2x2 / stride-1 maxpool (the
+    // reference's pad = 1: windows y..y+1, x..x+1 clipped at the border, src/maxpool_layer.c:109-146)
+    const bool pool_s1 = ypool && d->stride == 1 && ypool->H == OH && ypool->W == OW && OH > 1;
+    if (ypool && !pool_s1) {
         if ((x->H & 1) || (x->W & 1) || ypool->C != d->n || ypool->B != x->B || ypool->H != x->H / 2 ||
             ypool->W != x->W / 2 || !ypool->data || d->ksize != 3 || d->accum_mode != MI355_ACC_EXACT || acc_out || y_f32)
             return einval("conv_pool_forward: fused 2x2/2 maxpool needs a 3x3 conv on an even map, exact mode, no dumps");
     }
+    if (pool_s1 && (ypool->C != d->n || ypool->B != x->B || !ypool->data || d->ksize != 3 || d->accum_mode != MI355_ACC_EXACT || acc_out || y_f32))
+        return einval("conv_pool_forward: fused 2x2/1 maxpool needs a 3x3 stride-1 conv, exact mode, no dumps");
     ConvBlobHeader h;
     if (blob_layout(d->n, d->c, d->ksize, &h) != MI355_OK) return einval("conv_forward: shape");
     const char *base = (const char *)blob;
@@ -444,6 +449,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
             return conv_ref_f32_launch(a, st);
         }
         g_last_kernel = 1;
+        if (pool_s1) return einval("conv_pool_forward: the stride-1 pool is fused for 128 / 256-channel 3x3 layers only");
         if (x->cs != 4 && x->cs != 1) return einval("conv_forward: first layer expects a cs==4 image tensor or the planar (cs==1) reference layout");
         a.planar = x->cs == 1;
         a.debug_flags = mi355_debug_flags_get();
@@ -494,6 +500,15 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     }
     if (up != 1 && (h.cb != 64 || ypool)) return einval("conv_upsample_forward: 64-channel-chunk layers only");
     int rc = MI355_EINVAL;
+    a.pool_mode = ypool ? (pool_s1 ? 1 : 2) : 0;
+    if (ypool && (pool_s1 || d->c == 128 || d->c == 256)) {
+        // the stride-1 pool and the 128 / 256-channel layers: conv_ws3.hip or nothing
+        // (the generic fused kernel would be slower than the two layers run separately)
+        if (a.ws && !res && up == 1 && !yolo_out && !(mi355_debug_flags_get() & (16384 | (1 << 21)))) { rc = conv_ws3_launch(a, st); g_last_kernel = 4; }  // (bit 21: A/B runs without these fusions)
+        if (rc == MI355_EINVAL) return einval("conv_pool_forward: shape not fusable");
+        if (rc != MI355_OK) return hip_fail(hipGetLastError(), "conv_ws3 launch");
+        return rc;
+    }
     if (ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) { rc = conv_small_pool_launch(a, st); g_last_kernel = 2; }  // few-channel layers
     // the same kernel without the pool: few-channel 3x3 layers of the non-tiny nets (even maps, no dumps)
     if (rc == MI355_EINVAL && !ypool && y && a.ws && d->ksize == 3 && up == 1 && !acc_out && !y_f32 && !yolo_out &&

@@ -72,10 +72,21 @@ int dnq_layer_conv_kernel(network *net, int i)
     return net->layers[i].conv_kernel;
 }
 
+/* layer i + 1 runs inside layer i's kernel and layer i's own tensor is NOT stored */
 int dnq_layer_is_fused(network *net, int i)
 {
     if (i < 0 || i >= net->n) return 0;
-    return (net->layers[i].fuse_next_pool || net->layers[i].fuse_next_upsample || net->layers[i].fuse_next_shortcut) && net->fuse_maxpool && !net->dump_int32 &&
+    const layer *l = &net->layers[i];
+    return ((l->fuse_next_pool && !l->fuse_pool_keep) || l->fuse_next_upsample || l->fuse_next_shortcut) && net->fuse_maxpool && !net->dump_int32 &&
+           net->accum_mode == MI355_ACC_EXACT;
+}
+
+/* layer i + 1 runs inside layer i's kernel (whether or not layer i's own tensor is stored as well) */
+int dnq_layer_fuses_next(network *net, int i)
+{
+    if (i < 0 || i >= net->n) return 0;
+    const layer *l = &net->layers[i];
+    return (l->fuse_next_pool || l->fuse_next_upsample || l->fuse_next_shortcut || l->fuse_next_yolo) && net->fuse_maxpool && !net->dump_int32 &&
            net->accum_mode == MI355_ACC_EXACT;
 }
 

@@ -59,8 +59,8 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
         check_mi355(mi355_nchw_to_tensor((const uint8_t *)net.cur_t->data, &converted, net.stream), "input layout");
         net.cur_t = &converted;
     }
-    if (net.fused_pool_t) { /* this conv + the 2x2/2 maxpool after it as one kernel; the pre-pool tensor is not stored */
-        const int rc = mi355_conv_pool_forward(&d, net.cur_t, l.blob_gpu, NULL, net.fused_pool_t, net.stream);
+    if (net.fused_pool_t) { /* this conv + the 2x2 maxpool after it as one kernel; the pre-pool tensor is stored only if a route reads it */
+        const int rc = mi355_conv_pool_forward(&d, net.cur_t, l.blob_gpu, l.fuse_pool_keep ? &l.out_t : NULL, net.fused_pool_t, net.stream);
         if (rc != MI355_EINVAL) { check_mi355(rc, "mi355_conv_pool_forward"); return; }
         self->fuse_next_pool = 0;
     }

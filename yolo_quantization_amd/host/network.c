@@ -191,7 +191,7 @@ static int view_producer_ok(network *net, int j, int r)
     layer *p = &net->layers[j];
     if (j >= r || p->out_view || p->out_c % 16) return 0;
     if (p->type != CONVOLUTIONAL && p->type != UPSAMPLE && p->type != MAXPOOL) return 0;
-    if (p->type == CONVOLUTIONAL && (p->fuse_next_pool && net->fuse_maxpool)) return 0;
+    if (p->type == CONVOLUTIONAL && (p->fuse_next_pool && !p->fuse_pool_keep && net->fuse_maxpool)) return 0;
     if (j > 0 && net->layers[j - 1].fuse_next_pool && net->fuse_maxpool && p->type == MAXPOOL) return 0; /* written by the fused conv */
     const int zp_differs = p->activ_data_uint8_zero_point[0] != net->layers[r].activ_data_uint8_zero_point[0];
     if (j + 1 < net->n) {
@@ -238,7 +238,7 @@ static void plan_views(network *net)
         if (l->type != ROUTE || l->n != 1) continue;
         layer *p = &net->layers[l->input_layers[0]];
         if (l->input_layers[0] >= r || p->type == YOLO || !p->out_t.data) continue;
-        if (p->type == CONVOLUTIONAL && p->fuse_next_pool && net->fuse_maxpool) continue;
+        if (p->type == CONVOLUTIONAL && p->fuse_next_pool && !p->fuse_pool_keep && net->fuse_maxpool) continue;
         mi355_free(l->out_t.data);
         l->out_t = p->out_t;
         l->out_view = 1;
@@ -322,7 +322,8 @@ void quantization_prep_host(network *net, float in_scale, uint8_t in_zp)
  * even map, the conv is 3x3 and nothing else (a route) reads the conv's own output */
 static void plan_fusion(network *net)
 {
-    for (int i = 0; i < net->n; ++i) net->layers[i].fuse_next_pool = net->layers[i].fuse_next_yolo = net->layers[i].fuse_next_shortcut = 0;
+    for (int i = 0; i < net->n; ++i)
+        net->layers[i].fuse_next_pool = net->layers[i].fuse_pool_keep = net->layers[i].fuse_next_yolo = net->layers[i].fuse_next_shortcut = 0;
     for (int i = 0; i + 1 < net->n; ++i) { /* conv + quantized residual add: the conv's own tensor has no other reader */
         layer *c = &net->layers[i], *sc = &net->layers[i + 1];
         if (c->type == CONVOLUTIONAL && sc->type == SHORTCUT && c->stride == 1 && !c->quant_stop_flag && !sc->quant_stop_flag &&
@@ -344,7 +345,19 @@ static void plan_fusion(network *net)
     for (int i = 0; i + 1 < net->n; ++i) {
         layer *c = &net->layers[i], *p = &net->layers[i + 1];
         if (c->type != CONVOLUTIONAL || p->type != MAXPOOL) continue;
-        if (c->size != 3 || c->stride != 1 || c->quant_stop_flag || p->size != 2 || p->stride != 2 || p->pad / 2 != 0) continue;
+        if (c->size != 3 || c->stride != 1 || c->quant_stop_flag || p->quant_stop_flag || p->size != 2 || p->pad / 2 != 0) continue;
+        if (c->c == 128 || c->c == 256) {
+            /* the weights-stationary kernel of the middle layers (conv_ws3.hip) pools the bytes of its tile in LDS: the stride-2
+             * window on even maps, and the reference's stride-1 window (pad = 1: same size as the conv's map; yolov3-tiny's
+             * layer 11); it stores the conv's own tensor as well when a route reads it (layer 8) */
+            const int s2 = p->stride == 2 && !(c->out_h & 1) && !(c->out_w & 1);
+            const int s1 = p->stride == 1 && p->pad == 1 && p->out_h == c->out_h && p->out_w == c->out_w && c->out_h > 1;
+            if (!s2 && !s1) continue;
+            c->fuse_next_pool = 1;
+            c->fuse_pool_keep = output_read_elsewhere(net, i);
+            continue;
+        }
+        if (p->stride != 2) continue;
         if ((c->out_h & 1) || (c->out_w & 1) || (c->c != 3 && c->c % 16)) continue;
         /* 64-byte-chunk layers use the row-image kernel, which has no fused form; 64 -> 64..128 has its own fused kernel */
         if (c->c % 64 == 0 && !(c->c == 64 && c->n % 32 == 0 && c->n >= 64 && c->n <= 128)) continue;
