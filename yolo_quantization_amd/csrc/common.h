@@ -302,15 +302,27 @@ __device__ __forceinline__ void requant_group(const int32_t (&accb)[4][NS], cons
 
 // bytewise signed max of two dwords holding 4 biased (x ^ 0x80) activations each: max_u8 on the raw values ==
 // max_s8 on the biased ones (maxpool, ref src/maxpool_layer.c:134-146).
+// Packed 16-bit maxima: a byte compares like itself << 8 as a signed halfword, so the even bytes are shifted into the high byte of
+// their halfword, the odd bytes are masked in place, and two v_pk_max_i16 do the four comparisons (8 instructions instead of
+// ~20 extract / compare / insert ones: the fused pools of conv_ws3.hip are bound by this count).
+typedef short v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t max_s8x4(uint32_t p, uint32_t q)
 {
-    uint32_t r = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int a = (int)(int8_t)(p >> (8 * i)), b = (int)(int8_t)(q >> (8 * i));
-        r |= ((uint32_t)(a > b ? a : b) & 0xFFu) << (8 * i);
-    }
-    return r;
+    const v2s pe = __builtin_bit_cast(v2s, p) << 8, qe = __builtin_bit_cast(v2s, q) << 8;
+    const v2s po = __builtin_bit_cast(v2s, p & 0xFF00FF00u), qo = __builtin_bit_cast(v2s, q & 0xFF00FF00u);
+    const v2s me = __builtin_elementwise_max(pe, qe), mo = __builtin_elementwise_max(po, qo);
+    return (__builtin_bit_cast(uint32_t, me) >> 8) | __builtin_bit_cast(uint32_t, mo);
+}
+// ... of four dwords (a 2x2 window)
+__device__ __forceinline__ uint32_t max4_s8x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const v2s ae = __builtin_bit_cast(v2s, a) << 8, be = __builtin_bit_cast(v2s, b) << 8, ce = __builtin_bit_cast(v2s, c) << 8,
+              de = __builtin_bit_cast(v2s, d) << 8;
+    const v2s ao = __builtin_bit_cast(v2s, a & 0xFF00FF00u), bo = __builtin_bit_cast(v2s, b & 0xFF00FF00u),
+              co = __builtin_bit_cast(v2s, c & 0xFF00FF00u), dO = __builtin_bit_cast(v2s, d & 0xFF00FF00u);
+    const v2s me = __builtin_elementwise_max(__builtin_elementwise_max(ae, be), __builtin_elementwise_max(ce, de));
+    const v2s mo = __builtin_elementwise_max(__builtin_elementwise_max(ao, bo), __builtin_elementwise_max(co, dO));
+    return (__builtin_bit_cast(uint32_t, me) >> 8) | __builtin_bit_cast(uint32_t, mo);
 }
 
 // cell index of pixel n (n enumerates b,y,x) in a PHWC tensor

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     auto finish = [&](const v16i &acc, int g, int i) {  // i: index of group g within this wave set (its staging slot)
         const int sx = ldsSX[g * 32 + lj];
         const int cell = (PM && !a.y) ? -1 : ldsCell[g * 32 + lj];
-        char *pt = ldsPT + (size_t)((wset * NQ + wq) * gsmax + i) * a.sm_pt_stride + lj * 36 + 4 * kh;
+        // (+ 32 B per quad: the slots are a multiple of 128 B apart, and the pool pass reads one pixel's 32 dwords of all quads at once)
+        char *pt = ldsPT + (size_t)((wset * NQ + wq) * gsmax + i) * a.sm_pt_stride + (wq & 3) * 32 + lj * 36 + 4 * kh;
         uint8_t *dst = a.y + (size_t)(cell < 0 ? 0 : cell) * a.out_cs + f0 + lw + 4 * kh;
         // fused residual add: the `from` tensor's bytes of the same pixel and channels, fetched before the requantisation
         uint32_t resv[4] = {0, 0, 0, 0};
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
             WP3_MARK(2);
         }
     }
-    if (PM) {
+    if (PM && !(a.debug & (1 << 22))) {
         __syncthreads();  // every group's bytes are staged
         // NQ and nset are powers of two (conv_ws3_eligible): no divisions in the loops below
         const int lgND = 3 + __builtin_ctz(NQ), ND = 1 << lgND;  // dwords of a pixel's filters in this workgroup
@@ -436,30 +437,50 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
         // staged dword: pixel idx of the tile, dword d of the workgroup's filters (quad d >> 3, 4 (d & 7) bytes into its 32)
         auto staged = [&](int idx, int d) {
             const int g = idx >> 5, st = g & (nset - 1), i = g >> lgns;
-            return *reinterpret_cast<const uint32_t *>(ldsPT + ((st * NQ + (d >> 3)) * gsmax + i) * a.sm_pt_stride + (idx & 31) * 36 + (d & 7) * 4);
+            return *reinterpret_cast<const uint32_t *>(ldsPT + ((st * NQ + (d >> 3)) * gsmax + i) * a.sm_pt_stride + ((d >> 3) & 3) * 32 + (idx & 31) * 36 + (d & 7) * 4);
         };
+        // The pass is a chain of LDS round trips (tables -> staged bytes -> store address) with two waves per SIMD to hide them:
+        // four independent items per iteration, branch free, so that their reads are in flight together.
+        constexpr int UN = 4;
         if (PM == 2) {
-            const int nw = p1 - p0;
-            for (int it = tid; it < (nw << lgND); it += 512) {
-                const int w = it >> lgND, d = it & (ND - 1);
-                const int blk = (w >> 3) << 5, c0 = (w & 7) << 1;  // the window's two columns in its block
-                const uint32_t m = max_s8x4(max_s8x4(staged(blk + ws3_pm2_lane(0, c0), d), staged(blk + ws3_pm2_lane(0, c0 + 1), d)),
-                                            max_s8x4(staged(blk + ws3_pm2_lane(1, c0), d), staged(blk + ws3_pm2_lane(1, c0 + 1), d)));
-                *reinterpret_cast<uint32_t *>(a.ypool + (size_t)ldsPCell[w] * a.pool_cs + f0 + 4 * d) = m;
+            const int total = (p1 - p0) << lgND;
+            for (int it0 = tid; it0 < total; it0 += 512 * UN) {
+                uint32_t m[UN];
+                int pc[UN], dd[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int it = min(it0 + u * 512, total - 1);
+                    const int w = it >> lgND, d = it & (ND - 1);
+                    const int blk = (w >> 3) << 5, c0 = (w & 7) << 1;  // the window's two columns in its block
+                    m[u] = max4_s8x4(staged(blk + ws3_pm2_lane(0, c0), d), staged(blk + ws3_pm2_lane(0, c0 + 1), d),
+                                     staged(blk + ws3_pm2_lane(1, c0), d), staged(blk + ws3_pm2_lane(1, c0 + 1), d));
+                    pc[u] = ldsPCell[w];
+                    dd[u] = d;
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+                    if (it0 + u * 512 < total) *reinterpret_cast<uint32_t *>(a.ypool + (size_t)pc[u] * a.pool_cs + f0 + 4 * dd[u]) = m[u];
             }
         } else {  // whole-image tiles (the launcher guarantees it): pixel idx = (y, x) of image p0 / hw; ldsBase holds (y | x << 16)
-            const int np = p1 - p0;
+            const int total = (p1 - p0) << lgND;
             const int pdelta = a.pool_lead - a.out_lead;  // the pooled map has the conv map's geometry
-            for (int it = tid; it < (np << lgND); it += 512) {
-                const int idx = it >> lgND, d = it & (ND - 1);
-                const int rx = ldsBase[idx], y = rx & 0xFFFF, x = rx >> 16;
-                uint32_t m = staged(idx, d);
-                if (x + 1 < OWd) m = max_s8x4(m, staged(idx + 1, d));
-                if (y + 1 < OHd) {
-                    m = max_s8x4(m, staged(idx + OWd, d));
-                    if (x + 1 < OWd) m = max_s8x4(m, staged(idx + OWd + 1, d));
+            for (int it0 = tid; it0 < total; it0 += 512 * UN) {
+                uint32_t m[UN];
+                int pc[UN], dd[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int it = min(it0 + u * 512, total - 1);
+                    const int idx = it >> lgND, d = it & (ND - 1);
+                    const int rx = ldsBase[idx], y = rx & 0xFFFF, x = rx >> 16;
+                    // neighbours outside the image fall back on pixels of the window that are inside it
+                    const int i1 = idx + (x + 1 < OWd ? 1 : 0), i2 = idx + (y + 1 < OHd ? OWd : 0), i3 = i2 + (i1 - idx);
+                    m[u] = max4_s8x4(staged(idx, d), staged(i1, d), staged(i2, d), staged(i3, d));
+                    pc[u] = ldsCell[idx] + pdelta;
+                    dd[u] = d;
                 }
-                *reinterpret_cast<uint32_t *>(a.ypool + (size_t)(ldsCell[idx] + pdelta) * a.pool_cs + f0 + 4 * d) = m;
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+                    if (it0 + u * 512 < total) *reinterpret_cast<uint32_t *>(a.ypool + (size_t)pc[u] * a.pool_cs + f0 + 4 * dd[u]) = m[u];
             }
         }
     }
@@ -566,8 +587,8 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
         a.sm_pt_stride = 4096;
         if (pm && kp == 1) {
             a.sm_pt_off = (int)lds;
-            a.sm_pt_stride = 32 * 36;
-            lds += (size_t)nq * nset * ((G + nset - 1) / nset) * (32 * 36);
+            a.sm_pt_stride = 32 * 36 + 128;  // + the per-quad bank offset (3 x 32 B), rounded up to a multiple of 128 B
+            lds += (size_t)nq * nset * ((G + nset - 1) / nset) * (32 * 36 + 128);
         }
         if (lds > 160 * 1024) return false;
         a.sm_tp = tp;
