@@ -325,6 +325,23 @@ __device__ __forceinline__ uint32_t max4_s8x4(uint32_t a, uint32_t b, uint32_t c
     return (__builtin_bit_cast(uint32_t, me) >> 8) | __builtin_bit_cast(uint32_t, mo);
 }
 
+// Division of 0 <= n < 2^31 by a launch constant d >= 1 without the ~35-instruction sequence the compiler emits for a runtime
+// divisor:  q = (mulhi(n, m) + n) >> s  with  s = ceil(log2 d),  m = floor(2^32 (2^s - d) / d) + 1  (exact for n < 2^31).
+struct FastDiv {
+    uint32_t m;
+    int32_t s;
+};
+static inline FastDiv fastdiv_make(uint32_t d)
+{
+    FastDiv f;
+    int s = 0;
+    while ((1ull << s) < d) ++s;
+    f.s = s;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+    return f;
+}
+__device__ __forceinline__ int fd_div(int n, FastDiv f) { return (int)((__umulhi((uint32_t)n, f.m) + (uint32_t)n) >> f.s); }
+
 // cell index of pixel n (n enumerates b,y,x) in a PHWC tensor
 __device__ __forceinline__ int cell_of_pixel(int n, int H, int W, int lead)
 {

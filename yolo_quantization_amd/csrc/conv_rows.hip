@@ -100,12 +100,12 @@ constexpr int rows_nb_slots(int BN, int RS, int NW, int KS)
 }
 
 // global row index (over all image blocks, pad rows included) and column of valid pixel n
-__device__ __forceinline__ void row_of_pixel(int n, int H, int W, int &grow, int &x)
+__device__ __forceinline__ void row_of_pixel(int n, int H, int W, FastDiv fd_hw, FastDiv fd_w, int &grow, int &x)
 {
     const int hw = H * W;
-    const int b = n / hw;
+    const int b = fd_div(n, fd_hw);
     const int r = n - b * hw;
-    const int y = r / W;
+    const int y = fd_div(r, fd_w);
     x = r - y * W;
     grow = b * (H + 1) + y + 1;
 }
@@ -170,26 +170,29 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     // (mtiles / gm) x (ntiles / gn) tiles instead, so that the weights + input slices its L2 has to hold are smallest.
     int mtile, ntile;
     if (a.xcd_gm > 0) {
-        const int per = (int)gridDim.x >> 3, x = logical / per, within = logical - x * per;
-        const int gm = a.xcd_gm, mt_per = a.mtiles / gm, nt_per = a.ntiles_n / (8 / gm);
-        const int xm = x % gm, xn = x / gm;
-        mtile = xm * mt_per + within / nt_per;
-        ntile = xn * nt_per + within % nt_per;
+        // (the launcher sets xcd_gm only when the grid is a multiple of 8: logical = xcd * per + idx, XCD `xcd`, tile `idx` of it)
+        const int x = blockIdx.x & 7, within = blockIdx.x >> 3;
+        const int gm = a.xcd_gm, lg = gm == 8 ? 3 : gm == 4 ? 2 : gm == 2 ? 1 : 0;  // gm is a power of two
+        const int mt_per = a.mtiles >> lg, nt_per = a.ntiles_n >> (3 - lg);
+        const int xm = x & (gm - 1), xn = x >> lg;
+        const int wq = fd_div(within, a.fd_ntper);
+        mtile = xm * mt_per + wq;
+        ntile = xn * nt_per + (within - wq * nt_per);
     } else {
-        mtile = logical / a.ntiles_n;
+        mtile = fd_div(logical, a.fd_ntn);
         ntile = logical - mtile * a.ntiles_n;
     }
     // N tiles split the flattened pixel range evenly (tile widths differ by at most one pixel and never exceed BN):
     // the host picks ntiles_n so that mtiles * ntiles_n fills whole rounds of workgroups over the 256 CUs.
-    const int n0 = (int)(((long)ntile * a.total_n) / a.ntiles_n);
-    const int n_end = (int)(((long)(ntile + 1) * a.total_n) / a.ntiles_n);
+    const int n0 = ntile * a.tile_q + min(ntile, a.tile_r);
+    const int n_end = n0 + a.tile_q + (ntile < a.tile_r ? 1 : 0);
     const int W1 = a.W + 1, hw = a.H * a.W;
 
     // ---- tile rows: LDS row 0 = global row (row of first pixel) - HALO
     int gr0, x0;
-    row_of_pixel(n0, a.H, a.W, gr0, x0);
+    row_of_pixel(n0, a.H, a.W, a.fd_hw, a.fd_w, gr0, x0);
     int gr1, x1;
-    row_of_pixel(n_end - 1, a.H, a.W, gr1, x1);
+    row_of_pixel(n_end - 1, a.H, a.W, a.fd_hw, a.fd_w, gr1, x1);
     const int grow_first = gr0 - HALO;
     const int nrows = gr1 - gr0 + 1 + 2 * HALO;   // <= a.rows_cap (host guarantees)
     const int ndma = nrows * CPR;                 // B DMA instructions per chunk load for the whole workgroup
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         const int n = n0 + (ns * WNW + wn) * 32 + lj;  // 32-column sub-tiles are dealt round-robin to the N waves
         nvalid[ns] = n < n_end;
         int gr, x;
-        row_of_pixel(nvalid[ns] ? n : n_end - 1, a.H, a.W, gr, x);
+        row_of_pixel(nvalid[ns] ? n : n_end - 1, a.H, a.W, a.fd_hw, a.fd_w, gr, x);
         prow[ns] = gr - grow_first - HALO;  // LDS row of tap dy = 0 (top tap)
         pcol[ns] = x + 1 - HALO;            // LDS cell of tap dx = 0 (left tap); cell 0 of a row is x = -1
         bbase[ns] = prow[ns] * rowb + pcol[ns] * 16 + kh * PIECEB;
@@ -230,15 +233,16 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     // (exact int32 accumulation does not care).  All workgroups run in lockstep, and a chunk is the same 64 bytes of
     // every in_cs-byte cell: without the rotation the whole chip reads one quarter of the tensor's cache lines -- a few
     // L2 channels -- at any one time, and every workgroup of an XCD wants the same new weight slab in the same instant.
-    const int rot = a.debug & 512 ? 0 : ntile % a.nchunks;
-    const int kwrap = a.ksteps / a.nchunks * a.nchunks;  // = ksteps (taps * chunks)
-    int aleft = kwrap - rot * (a.ksteps / a.nchunks);    // slabs until the walk wraps to slab 0
+    constexpr int TAPS = KS * KS;                         // K-steps per channel chunk (= ksteps / nchunks)
+    const int rot = a.debug & 512 ? 0 : ntile - fd_div(ntile, a.fd_nch) * a.nchunks;
+    const int kwrap = a.ksteps;                           // taps * chunks
+    int aleft = kwrap - rot * TAPS;                       // slabs until the walk wraps to slab 0
     const int8_t *aptr[APT];  // next K-step slab of this wave's A chunk(s) to fetch
     unsigned adst[APT];
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
         const int ch = min(dwave + i * DW, ACH - 1);
-        aptr[i] = a.wp + ((size_t)(mtile * ACH + ch) * a.ksteps + (size_t)rot * (a.ksteps / a.nchunks)) * 1024;
+        aptr[i] = a.wp + ((size_t)(mtile * ACH + ch) * a.ksteps + (size_t)rot * TAPS) * 1024;
         adst[i] = lds0 + (ch << 10);
     }
     const unsigned lane16 = lane * 16;
@@ -609,9 +613,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         const int nl = (ns * WNW + wn) * 32 + lj;
         nl_[ns] = nl;
         const int nn = nvalid[ns] ? n0 + nl : 0;
-        const int b = nn / hw;
+        const int b = fd_div(nn, a.fd_hw);
         const int rem0 = nn - b * hw;
-        const int y = rem0 / a.W, xx = rem0 - y * a.W;
+        const int y = fd_div(rem0, a.fd_w), xx = rem0 - y * a.W;
         pb_[ns] = b;
         rem[ns] = rem0;
         if (wm == 0 && kh == 0) {
@@ -749,7 +753,18 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
                             *reinterpret_cast<uint32_t *>(a.y + (size_t)(cell + uy * rowc + ux) * a.out_cs + m0 + d * 4) = v;
                 }
             }
-        } else if (dwords == BM / 4) {  // common case: constant divisor
+        } else if (dwords == BM / 4 && !(a.out_cs & 15) && !((size_t)a.y & 15)) {  // common case: 16-byte stores (a quarter of the store instructions)
+#pragma unroll 2
+            for (int p = tid; p < BN * (BM / 16); p += NT) {
+                const int pix = p / (BM / 16), q = p % (BM / 16);
+                const int cell = celltab[pix];
+                if (cell >= 0) {
+                    const uint32_t *sp = reinterpret_cast<const uint32_t *>(otile + pix * OSTR + q * 16);  // rows are 4-byte aligned only
+                    const uint4 v = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+                    *reinterpret_cast<uint4 *>(a.y + (size_t)cell * a.out_cs + m0 + q * 16) = v;
+                }
+            }
+        } else if (dwords == BM / 4) {  // constant divisor
 #pragma unroll 4
             for (int p = tid; p < BN * (BM / 4); p += NT) {
                 const int pix = p / (BM / 4), d = p % (BM / 4);
@@ -788,6 +803,9 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     if ((ndma + DW - 1) / DW > rows_nb_slots(BN, RS, DW, KS)) return MI355_EINVAL;  // map too narrow for this tile
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     a.rowb = RS * 64 + 16 * (a.W & 15);
+    a.fd_hw = fastdiv_make((uint32_t)(a.H * a.W)); a.fd_w = fastdiv_make((uint32_t)a.W);
+    a.fd_ntn = fastdiv_make((uint32_t)a.ntiles_n); a.fd_nch = fastdiv_make((uint32_t)a.nchunks);
+    a.tile_q = a.total_n / a.ntiles_n; a.tile_r = a.total_n % a.ntiles_n;
     size_t lds = (size_t)ra_stages<KS, BN>() * BM * 64 + (size_t)rb_stages<KS, BN>() * a.rows_cap * a.rowb + (size_t)a.rows_cap * RS * 4;
     const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
     if (lds_epi > lds) lds = lds_epi;
@@ -821,6 +839,7 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
             if (a.xcd_gm == 0 || bytes < best) { best = bytes; a.xcd_gm = gm; }
         }
     }
+    a.fd_ntper = fastdiv_make((uint32_t)(a.xcd_gm > 0 ? a.ntiles_n / (8 / a.xcd_gm) : 1));
     dim3 grid(a.ntiles_n * a.mtiles), block(NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;

@@ -18,6 +18,9 @@ struct ConvArgs {
     int ksize, cb, nchunks, upc, spc, ksteps;
     int total_n, ntiles_n, mtiles;
     int xcd_gm;              // conv_rows: the 8 XCDs form an xcd_gm x (8 / xcd_gm) grid over (M tiles, N tiles); 0 = M-major ranges
+    // conv_rows: launch constants of the index arithmetic (divisions by them are multiplications, common.h FastDiv)
+    FastDiv fd_hw, fd_w, fd_ntn, fd_ntper, fd_nch;  // H * W, W, ntiles_n, N tiles per XCD, channel chunks
+    int tile_q, tile_r;      // N tile t covers pixels [t q + min(t, r), + q + (t < r))
     int zp_act, act, store_mode;
     float s_act;
     int mpad;
