@@ -435,53 +435,45 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
         const int lgND = 3 + __builtin_ctz(NQ), ND = 1 << lgND;  // dwords of a pixel's filters in this workgroup
         const int lgns = __builtin_ctz(nset);
         // staged dword: pixel idx of the tile, dword d of the workgroup's filters (quad d >> 3, 4 (d & 7) bytes into its 32)
-        auto staged = [&](int idx, int d) {
-            const int g = idx >> 5, st = g & (nset - 1), i = g >> lgns;
-            return *reinterpret_cast<const uint32_t *>(ldsPT + ((st * NQ + (d >> 3)) * gsmax + i) * a.sm_pt_stride + ((d >> 3) & 3) * 32 + (idx & 31) * 36 + (d & 7) * 4);
+        // The pass is bound by its instruction count (and a 32-bit v_mul_lo / a 64-bit mad is a quarter-rate instruction): a thread
+        // keeps ONE dword column d of the workgroup's filters, so everything that depends on d is computed once; 24-bit multiplies
+        // and 32-bit offsets elsewhere.  Four independent pixels / windows per iteration, branch free (LDS round trips overlap).
+        const unsigned pts = (unsigned)a.sm_pt_stride, pcs = (unsigned)a.pool_cs;
+        const __attribute__((address_space(3))) char *pt3 = (const __attribute__((address_space(3))) char *)ldsPT;
+        const unsigned d = (unsigned)tid & (unsigned)(ND - 1), dq = d >> 3;
+        const unsigned qoff = __umul24(__umul24(dq, (unsigned)gsmax), pts) + (dq & 3) * 32 + (d & 7) * 4;  // this thread's quad and dword in a slot
+        const unsigned setstride = __umul24((unsigned)(NQ * gsmax), pts);                                  // between wave sets
+        auto staged = [&](int idx) {
+            const unsigned g = (unsigned)idx >> 5, st = g & (unsigned)(nset - 1), i = g >> lgns;
+            const unsigned off = qoff + __umul24(st, setstride) + __umul24(i, pts) + __umul24((unsigned)idx & 31, 36u);
+            return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(pt3 + off);
         };
-        // The pass is a chain of LDS round trips (tables -> staged bytes -> store address) with two waves per SIMD to hide them:
-        // four independent items per iteration, branch free, so that their reads are in flight together.
+        uint8_t *pout = a.ypool + f0 + 4 * d;  // + cell * pool_cs: below 2^32 (the launcher checks the pooled tensor's size)
         constexpr int UN = 4;
-        if (PM == 2) {
-            const int total = (p1 - p0) << lgND;
-            for (int it0 = tid; it0 < total; it0 += 512 * UN) {
-                uint32_t m[UN];
-                int pc[UN], dd[UN];
+        const int PPI = 512 >> lgND;  // pixels / windows per sweep of the workgroup
+        const int nu = p1 - p0;
+        for (int u0 = tid >> lgND; u0 < nu; u0 += PPI * UN) {
+            uint32_t m[UN];
+            int pc[UN];
 #pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const int it = min(it0 + u * 512, total - 1);
-                    const int w = it >> lgND, d = it & (ND - 1);
+            for (int u = 0; u < UN; ++u) {
+                const int w = min(u0 + u * PPI, nu - 1);
+                if (PM == 2) {
                     const int blk = (w >> 3) << 5, c0 = (w & 7) << 1;  // the window's two columns in its block
-                    m[u] = max4_s8x4(staged(blk + ws3_pm2_lane(0, c0), d), staged(blk + ws3_pm2_lane(0, c0 + 1), d),
-                                     staged(blk + ws3_pm2_lane(1, c0), d), staged(blk + ws3_pm2_lane(1, c0 + 1), d));
+                    m[u] = max4_s8x4(staged(blk + ws3_pm2_lane(0, c0)), staged(blk + ws3_pm2_lane(0, c0 + 1)),
+                                     staged(blk + ws3_pm2_lane(1, c0)), staged(blk + ws3_pm2_lane(1, c0 + 1)));
                     pc[u] = ldsPCell[w];
-                    dd[u] = d;
-                }
-#pragma unroll
-                for (int u = 0; u < UN; ++u)
-                    if (it0 + u * 512 < total) *reinterpret_cast<uint32_t *>(a.ypool + (size_t)pc[u] * a.pool_cs + f0 + 4 * dd[u]) = m[u];
-            }
-        } else {  // whole-image tiles (the launcher guarantees it): pixel idx = (y, x) of image p0 / hw; ldsBase holds (y | x << 16)
-            const int total = (p1 - p0) << lgND;
-            const int pdelta = a.pool_lead - a.out_lead;  // the pooled map has the conv map's geometry
-            for (int it0 = tid; it0 < total; it0 += 512 * UN) {
-                uint32_t m[UN];
-                int pc[UN], dd[UN];
-#pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const int it = min(it0 + u * 512, total - 1);
-                    const int idx = it >> lgND, d = it & (ND - 1);
-                    const int rx = ldsBase[idx], y = rx & 0xFFFF, x = rx >> 16;
+                } else {  // whole-image tiles (the launcher guarantees it): pixel w = (y, x) of image p0 / hw; ldsBase holds (y | x << 16)
+                    const int rx = ldsBase[w], y = rx & 0xFFFF, x = rx >> 16;
                     // neighbours outside the image fall back on pixels of the window that are inside it
-                    const int i1 = idx + (x + 1 < OWd ? 1 : 0), i2 = idx + (y + 1 < OHd ? OWd : 0), i3 = i2 + (i1 - idx);
-                    m[u] = max4_s8x4(staged(idx, d), staged(i1, d), staged(i2, d), staged(i3, d));
-                    pc[u] = ldsCell[idx] + pdelta;
-                    dd[u] = d;
+                    const int i1 = w + (x + 1 < OWd ? 1 : 0), i2 = w + (y + 1 < OHd ? OWd : 0), i3 = i2 + (i1 - w);
+                    m[u] = max4_s8x4(staged(w), staged(i1), staged(i2), staged(i3));
+                    pc[u] = ldsCell[w] + (a.pool_lead - a.out_lead);  // the pooled map has the conv map's geometry
                 }
-#pragma unroll
-                for (int u = 0; u < UN; ++u)
-                    if (it0 + u * 512 < total) *reinterpret_cast<uint32_t *>(a.ypool + (size_t)pc[u] * a.pool_cs + f0 + 4 * dd[u]) = m[u];
             }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (u0 + u * PPI < nu) *reinterpret_cast<uint32_t *>(pout + __umul24((unsigned)pc[u], pcs)) = m[u];
         }
     }
     }  // tiles
@@ -545,6 +537,10 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
     const int pm = a.pool_mode;
     if (!a.y && !pm) return MI355_EINVAL;
     if (pm && (a.stride != 1 || a.res || a.pool_w < a.n || (pm == 2 && ((a.OH | a.OW) & 1)))) return MI355_EINVAL;
+    if (pm) {  // the pool pass addresses the pooled tensor with 24-bit cell indices and 32-bit byte offsets
+        const long pcells = (long)a.pool_lead + (long)a.B * (a.OH / (pm == 2 ? 2 : 1) + 1) * (a.OW / (pm == 2 ? 2 : 1) + 1);
+        if (pcells >= (1L << 24) || a.pool_cs >= (1 << 24) || pcells * a.pool_cs >= (1L << 32)) return MI355_EINVAL;
+    }
     if ((a.stride != 1 && a.stride != 2) || a.up != 1 || (a.y && a.out_w < a.n)) return MI355_EINVAL;
     if (a.stride == 2 && ((a.H & 1) || (a.W & 1))) return MI355_EINVAL;  // even maps: output = the even positions
     const int kp = c / 128, nq = ws3_quads(a.n, c), pieces = 8 * kp;
