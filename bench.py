@@ -58,7 +58,7 @@ def pmc_traffic_per_launch():
     WRITE_SIZE passes, gfx950 FETCH_SIZE x2 correction) -- NOT measured in this run (PMC collection needs rocprofv3
     around the process).  Returns (bytes or None, source file or None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))  # rNN_vM_...: the name orders them (mtimes do not survive a snapshot)
     if not files:
         return None, None
     rows = [r for r in json.load(open(files[-1])) if "conv_rows_i8_kernel" in r["kernel"]]
