@@ -280,6 +280,11 @@ def main():
                 "conv3x3_s1_aggregate": {"tops": round(s33_ops / (s33_ms * 1e-3) / 1e12, 1) if s33_ms else None,
                                          "frac": round(s33_ops / (s33_ms * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4) if s33_ms else None,
                                          "ms": round(s33_ms, 5), "layers": "every 3x3 stride-1 conv with c > 3"},
+                # what a loop of NOTHING but V_MFMA_I32_32X32X32_I8 sustains on this chip depends on the operand bytes (power
+                # management lowers the shader clock): 4 760-4 940 TOP/s on zeros, 3 490 on uniform random bytes
+                # (tools/ubench/mfma_data_power.hip, profiles/r02_v3_ubench_mfma_data_power.log).  `peak` / `frac` stay nominal.
+                "mfma_only_loop_random_operands": {"tops": 3490.0, "frac_of_it": round(achieved / 3490.0, 4),
+                                                   "source": "profiles/r02_v3_ubench_mfma_data_power.log -- not measured in this run"},
                 "input_layout_ms": round(max(float(ms[0]) / nprof - ev_cost, 0.0), 5),
                 "event_overhead_ms": round(ev_cost, 5)}
         if args.layers:

@@ -29,6 +29,10 @@ def run(c, n, hw, k, batch, iters, tile=None, mode=None, check=False, nt=0):
     rng = np.random.default_rng(1)
     x = rng.integers(0, 256, (batch, c, hw, hw), dtype=np.uint8)
     wq = np.random.default_rng(2).integers(0, 256, (n, c * k * k), dtype=np.uint8)
+    if os.environ.get("UBENCH_DATA") == "const":   # constant operands: the matrix pipe toggles little -> is the kernel power / clock bound?
+        x[:] = 128; wq[:] = 128
+    elif os.environ.get("UBENCH_DATA") == "small":  # low-entropy operands
+        x = (x & 3).astype(np.uint8) + 126; wq = (wq & 3).astype(np.uint8) + 126
     zp_w = np.random.default_rng(3).integers(100, 157, n, dtype=np.uint8)
     bias = np.zeros(n, np.int32)
     mv = np.full(n, 0.75); sv = np.full(n, 2.0 ** -SHIFT)
