@@ -1,80 +1,32 @@
-// conv_rows.hip -- the MFMA implicit-GEMM INT8 convolution for layers whose input channels come in 64-byte chunks
-// (every 3x3 s1 / 1x1 layer of yolov3-tiny from the 4th conv on, and BASELINE config[1]).  Same mathematics as
-// conv_igemm.hip (read its header for the signed-operand decomposition); what differs is the inner loop, which is
-// built so that a K-step is almost nothing but ds_read_b128 + V_MFMA_I32_32X32X32_I8:
+// conv_rows16.hip -- conv_rows.hip's 3x3 kernel on V_MFMA_I32_16X16X64_I8 instead of V_MFMA_I32_32X32X32_I8.
 //
-//   * LDS image of the B operand = whole image ROWS of the PHWC tensor, RS cells per row (RS = 16/32/64 >= W+2,
-//     a template constant), stored per row as [16-byte piece][RS cells][16 B], rows skewed by W mod 16 cells so that a
-//     wave's 32 consecutive pixels never collide in a bank across a row wrap.  A 3x3 tap (dy,dx) is a per-row table
-//     entry plus the immediate dx*16: no per-step address arithmetic.
-//   * the receptive-field sums  sum_k x'  (needed because V_MFMA_*_I8 is signed x signed) are reduced once per channel
-//     chunk from the landed row image into an LDS int32 plane S[cell]; the epilogue forms the 3x3 box sum of S
-//     (1x1: straight from the B fragments in registers).
-//   * A operand: 6-stage DMA ring five K-steps ahead (4 stages in the 128-column configurations, the 1x1 loop 3-4 for
-//     A and B alike); B operand: double-buffered per channel chunk, its DMA slots spread over a chunk's first four
-//     K-steps.  LDS-DMA (global_load_lds_dwordx4) is written by hand with scalar bases; one s_barrier per K-step.
-//   * 3x3 K loop: nine K-steps per chunk fully unrolled in a steady-state and a last-chunk variant, every vmcnt /
-//     lgkmcnt wait an immediate; three fragment register sets, a set is read one K-step before its MFMAs and the
-//     reads are threaded between the MFMAs of the previous sets.
-//   * N tiles split the pixel range evenly (host-side tile planner in conv_igemm_launch), 32-column sub-tiles are dealt
-//     round-robin to the N waves, workgroups walk the channel chunks in rotated order.
-//   * epilogue: accumulators start at cw + bias, one FP64 multiply per output (folded multiplier), branch-free leaky,
-//     LDS-transposed stores; optional fused nearest-neighbour upsample store and fused yolo head activations.
+// Why: the 3x3 layers on this kernel are bound by the shader clock, and the clock by the power the matrix pipe draws, which
+// depends on the operand bytes AND on the instruction (tools/ubench/mfma_data_power.hip): a loop of
+// nothing but MFMAs on uniform random bytes sustains 3 450-3 510 TOP/s with the 32x32x32 instruction and 3 860 TOP/s with
+// the 16x16x64 one (a quarter of the accumulator registers written per operation).
 //
-// Measured motivation and the microbenchmarks behind each of these choices: DESIGN.md section 3.1, profiles/r01_*.
+// Everything outside the K-step body is conv_rows.hip's design, unchanged: row-image LDS layout of the B operand
+// ([16-byte piece][RS cells][16 B] per row: piece = the lane's k quarter), A slabs of [16-row chunk][4 pieces][16 rows][16 B]
+// (a 16x16x64 A fragment is 1 KiB of consecutive bytes: lane l reads bytes [16 l, +16)), 6-stage A ring five K-steps ahead,
+// double-buffered B row images, counted vmcnt waits, one s_barrier per K-step, DMA issued by the older four waves, tile plan,
+// XCD grid, epilogue (folded FP64 requantise, LDS-transposed 16-byte stores, fused upsample / yolo head).
+//
+// What differs: a wave tile of 64 x 96 is 4 x 6 tiles of 16 x 16 (the same 96 accumulator registers); a K-step is
+// 24 MFMAs on 4 A + 6 B fragments of the whole 64-channel chunk (the same 10 ds_read_b128 per K-step), and the fragments
+// are prefetched IN PLACE: a B fragment is dead after its four MFMAs and is reloaded for the next K-step at once, the A
+// fragments are reloaded during the last two rounds -- 40 fragment registers instead of 60, no register-set rotation.
+//   step:  lgkmcnt(2) | for ni in 0..3: 4 MFMAs (A0..A3, B[ni]); read B[ni]' | lgkmcnt(4) |
+//          for mi in 0..3: MFMA(A[mi], B4), MFMA(A[mi], B5); read A[mi]' | read B4', B5'
+// D layout of the instruction: lane l holds rows (= filters) 4 (l / 16) .. + 3 of column (= pixel) l % 16.
 #include "kargs.h"
 #include <type_traits>
 
-// timing-ablation switches (tools/conv_microbench.py --ablate) exist only in builds made with -DMI355_ABLATE;
-// in the product build DBG(x) is the constant 0 and every switch folds away.
-#if defined(MI355_ABLATE) && !defined(ROWS_TU_KS1)
-#define DBG(bit) ((a.debug & (bit)) != 0)
-// phase timestamps (100 MHz wall clock) of wave 0 of every workgroup: tools/conv_microbench.py --timeline
-#define TS_PHASES 6
-#define TS_BLOCKS 4096
-__device__ long long g_rows_ts[TS_PHASES][TS_BLOCKS];
-#define TS(k)                                                                                   \
-    do {                                                                                        \
-        if (threadIdx.x == 0 && blockIdx.x < TS_BLOCKS) g_rows_ts[k][blockIdx.x] = wall_clock64(); \
-    } while (0)
-extern "C" int mi355_debug_read_ts(long long *host)
-{
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rows_ts), sizeof(long long) * TS_PHASES * TS_BLOCKS) == hipSuccess ? 0 : -5;
-}
-// in-loop stall profile (debug bit 256): per wave, shader-clock sums of the five phases of a K-step
-#define WP_PHASES 5
-__device__ long long g_rows_wp[TS_BLOCKS][8][WP_PHASES];
-#define WP_DECL long long wp_acc[WP_PHASES] = {0, 0, 0, 0, 0}; long long wp_t = 0
-#define WP_START()                                                   \
-    do {                                                             \
-        if (DBG(256)) { wp_t = __builtin_readcyclecounter(); }       \
-    } while (0)
-#define WP_MARK(k)                                                   \
-    do {                                                             \
-        if (DBG(256)) {                                              \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
-            const long long wp_n = __builtin_readcyclecounter();     \
-            wp_acc[k] += wp_n - wp_t;                                \
-            wp_t = wp_n;                                             \
-        }                                                            \
-    } while (0)
-#define WP_FLUSH()                                                                                   \
-    do {                                                                                             \
-        if (DBG(256) && lane == 0 && blockIdx.x < TS_BLOCKS && wave < 8)                             \
-            for (int k = 0; k < WP_PHASES; ++k) g_rows_wp[blockIdx.x][wave][k] = wp_acc[k];          \
-    } while (0)
-extern "C" int mi355_debug_read_wp(long long *host)
-{
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rows_wp), sizeof(long long) * TS_BLOCKS * 8 * WP_PHASES) == hipSuccess ? 0 : -5;
-}
-#else
 #define DBG(bit) (false)
 #define TS(k) do { } while (0)
 #define WP_DECL do { } while (0)
 #define WP_START() do { } while (0)
 #define WP_MARK(k) do { } while (0)
 #define WP_FLUSH() do { } while (0)
-#endif
 
 #define DMA16(gsrc, ldst)                                                                               \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),           \
@@ -84,15 +36,15 @@ extern "C" int mi355_debug_read_wp(long long *host)
 // A(g), A(g+1) are being read while A(g+2) .. A(g+5) are in flight) -- 4 in the 128-column configurations, whose LDS
 // then lets two workgroups share a CU (one's epilogue under the other's K loop); 4 (3 for the widest tiles: LDS) for the plain 1x1
 // loop, which then has its DMA two or three K-steps ahead instead of one -- its K-steps took 0.7 us each, the DMA latency
-template <int KS, int BN> constexpr int ra_stages() { return KS == 3 ? (BN <= 128 ? 4 : 6) : (BN <= 128 ? 4 : 3); }
+template <int KS, int BN> constexpr int ra16_stages() { return KS == 3 ? (BN <= 128 ? 4 : 6) : (BN <= 128 ? 4 : 3); }
 // B buffers: two per-chunk row images for 3x3 (a chunk lasts nine K-steps); for 1x1 every K-step is a new chunk and the
 // row image rides the same ring as the weights
-template <int KS, int BN> constexpr int rb_stages() { return KS == 3 ? 2 : ra_stages<KS, BN>(); }
+template <int KS, int BN> constexpr int rb16_stages() { return KS == 3 ? 2 : ra16_stages<KS, BN>(); }
 // B DMA slots per wave per channel-chunk load: a compile-time constant per configuration (one VGPR of source offset
 // each, issued unconditionally -- slots past a tile's last LDS row repeat its last one), so that every vmcnt wait of
 // the K loop is an immediate.  Sized for the rows a BN-pixel tile spans when the map is at least 3/4 as wide as the
 // row image (W >= 12 / 24 / 48 for RS = 16 / 32 / 64); narrower maps are refused by the launcher (other tile or kernel).
-constexpr int rows_nb_slots(int BN, int RS, int NW, int KS)
+constexpr int rows16_nb_slots(int BN, int RS, int NW, int KS)
 {
     const int wmin = RS * 3 / 4, halo = KS == 3 ? 1 : 0;
     const int rows = (BN - 2 + wmin) / wmin + 1 + (BN - 2 + wmin * wmin) / (wmin * wmin) + 2 * halo;
@@ -100,7 +52,7 @@ constexpr int rows_nb_slots(int BN, int RS, int NW, int KS)
 }
 
 // global row index (over all image blocks, pad rows included) and column of valid pixel n
-__device__ __forceinline__ void row_of_pixel(int n, int H, int W, FastDiv fd_hw, FastDiv fd_w, int &grow, int &x)
+__device__ __forceinline__ void row16_of_pixel(int n, int H, int W, FastDiv fd_hw, FastDiv fd_w, int &grow, int &x)
 {
     const int hw = H * W;
     const int b = fd_div(n, fd_hw);
@@ -111,12 +63,13 @@ __device__ __forceinline__ void row_of_pixel(int n, int H, int W, FastDiv fd_hw,
 }
 
 template <int BM, int BN, int WMW, int WNW, int RS, int KS>
-__global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const ConvArgs a)
+__global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const ConvArgs a)
 {
     constexpr int NW = WMW * WNW, NT = 64 * NW;
     constexpr int TM = BM / WMW, TN = BN / WNW;
-    constexpr int MS = TM / 32, NS = TN / 32;
+    constexpr int MI = TM / 16, NI = TN / 16;  // 16 x 16 accumulator tiles of a wave: MI x NI
     constexpr int ACH = BM / 16;
+    static_assert(KS == 3 && TN % 32 == 0, "3x3 only; pixels are dealt in 32-column sub-tiles (two 16-column tiles each)");
     // DMA waves: in the 8-wave 3x3 kernel only the older half of the workgroup (waves 0..3, one per SIMD) issues DMA.  The
     // younger wave of every SIMD loses the issue arbitration and reaches the barrier last anyway; freed of its DMA
     // instructions (~60-180 clocks each) the two halves arrive together.  A wave that issues nothing has vmcnt = 0: the
@@ -128,14 +81,14 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     constexpr int PIECEB = RS * 16;     // bytes between 16-byte pieces of a row
     constexpr int CPR = RS / 16;        // 1 KiB DMA chunks per row
     constexpr int OSTR = BM + 4;
-    constexpr int RA_STAGES = ra_stages<KS, BN>();
-    constexpr int RB_STAGES = rb_stages<KS, BN>();
-    constexpr int NBS = rows_nb_slots(BN, RS, DW, KS);  // B DMA slots per (DMA) wave per chunk
+    constexpr int RA_STAGES = ra16_stages<KS, BN>();
+    constexpr int RB_STAGES = rb16_stages<KS, BN>();
+    constexpr int NBS = rows16_nb_slots(BN, RS, DW, KS);  // B DMA slots per (DMA) wave per chunk
     constexpr int SPS = (NBS + 3) / 4;                  // ... issued per K-step over a chunk's first four steps (3x3 loop)
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *ldsA = smem;                                   // [RA_STAGES][BM*64]
+    // smem: [RA_STAGES][BM*64] A ring first
     char *ldsB = smem + RA_STAGES * BM * 64;             // [RB_STAGES][rows_cap*rowb]
     // bytes between LDS rows: RS*64 of data + a skew of (W mod 16) cells, so that the pixel after a row's last one
     // lands in the next 16-byte bank slot -- a wave's 32 consecutive pixels then never collide across a row wrap
@@ -154,7 +107,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WNW, wn = wave % WNW;
-    const int kh = lane >> 5, lj = lane & 31;
+    const int kq = lane >> 4, lj = lane & 15;  // the lane's k quarter (16 of the chunk's 64 channels) and its row / column in a 16 x 16 tile
     const int dwave = wave & (DW - 1);  // index into the DMA tables
     const bool issuer = wave < DW;      // steady-state DMA wave
     TS(0);
@@ -190,33 +143,28 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
 
     // ---- tile rows: LDS row 0 = global row (row of first pixel) - HALO
     int gr0, x0;
-    row_of_pixel(n0, a.H, a.W, a.fd_hw, a.fd_w, gr0, x0);
+    row16_of_pixel(n0, a.H, a.W, a.fd_hw, a.fd_w, gr0, x0);
     int gr1, x1;
-    row_of_pixel(n_end - 1, a.H, a.W, a.fd_hw, a.fd_w, gr1, x1);
+    row16_of_pixel(n_end - 1, a.H, a.W, a.fd_hw, a.fd_w, gr1, x1);
     const int grow_first = gr0 - HALO;
     const int nrows = gr1 - gr0 + 1 + 2 * HALO;   // <= a.rows_cap (host guarantees)
     const int ndma = nrows * CPR;                 // B DMA instructions per chunk load for the whole workgroup
 
-    // ---- per-lane B base: LDS byte offset of (its pixel's row - HALO, its column - HALO) for k-half kh
+    // ---- per-lane B base: LDS byte offset of (its pixel's row - HALO, its column - HALO) for k quarter kq
+    constexpr int NS = NI;  // (the per-pixel tables below are indexed by the 16-column tile)
     int bbase[NS];
-    int prow[NS], pcol[NS];
-    bool nvalid[NS];
+    // (the pixel's LDS row / cell and validity are recomputed in the epilogue rather than kept in 18 registers across the K loop)
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-        const int n = n0 + (ns * WNW + wn) * 32 + lj;  // 32-column sub-tiles are dealt round-robin to the N waves
-        nvalid[ns] = n < n_end;
+        const int n = n0 + ((ns >> 1) * WNW + wn) * 32 + (ns & 1) * 16 + lj;  // 32-column sub-tiles are dealt round-robin to the N waves
         int gr, x;
-        row_of_pixel(nvalid[ns] ? n : n_end - 1, a.H, a.W, a.fd_hw, a.fd_w, gr, x);
-        prow[ns] = gr - grow_first - HALO;  // LDS row of tap dy = 0 (top tap)
-        pcol[ns] = x + 1 - HALO;            // LDS cell of tap dx = 0 (left tap); cell 0 of a row is x = -1
-        bbase[ns] = prow[ns] * rowb + pcol[ns] * 16 + kh * PIECEB;
+        row16_of_pixel(n < n_end ? n : n_end - 1, a.H, a.W, a.fd_hw, a.fd_w, gr, x);
+        const int prow = gr - grow_first - HALO;  // LDS row of tap dy = 0 (top tap)
+        const int pcol = x + 1 - HALO;            // LDS cell of tap dx = 0 (left tap); cell 0 of a row is x = -1
+        bbase[ns] = prow * rowb + pcol * 16 + kq * PIECEB;
     }
-    int atab[MS];
-#pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
-        const int row = wm * TM + ms * 32 + lj;
-        atab[ms] = ((row >> 4) << 10) + ((row & 15) << 4) + kh * 256;
-    }
+    // A fragment mi of the wave = 16-row chunk wm * MI + mi of the slab = 1 KiB of consecutive bytes: [piece kq][row lj][16 B]
+    const int atab0 = (wm * MI) * 1024 + lane * 16;
 
     // ---- DMA helpers.  Every wave issues exactly APT (A) / NBS (B) instructions per load.  A K-step is bounded by
     // the length of each wave's own instruction stream as much as by the matrix pipe (the in-order wave issues ~50
@@ -305,21 +253,14 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     }
 
     // accumulators start at the per-channel constant cw + bias (blob plane cwb), so the epilogue does not add it:
-    // register grp*4+r of a 32x32 tile holds channel row 8*grp + 4*kh + r (parameter planes are padded to mpad)
-    v16i acc[MS][NS];
+    // register r of tile (mi, ni) holds filter row 16 mi + 4 kq + r (parameter planes are padded to mpad)
+    v4i acc[MI][NI];
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms)
+    for (int mi = 0; mi < MI; ++mi) {
+        const int4 c4 = *reinterpret_cast<const int4 *>(a.cwb + mtile * BM + wm * TM + mi * 16 + 4 * kq);
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            const int4 c4 = *reinterpret_cast<const int4 *>(a.cwb + mtile * BM + wm * TM + ms * 32 + 8 * grp + 4 * kh);
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-                acc[ms][ns][grp * 4 + 0] = c4.x;
-                acc[ms][ns][grp * 4 + 1] = c4.y;
-                acc[ms][ns][grp * 4 + 2] = c4.z;
-                acc[ms][ns][grp * 4 + 3] = c4.w;
-            }
-        }
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = v4i{c4.x, c4.y, c4.z, c4.w};
+    }
 
     // zero the S plane, stage the epilogue parameters (both visible after the first barrier of the K loop)
     for (int i = tid; i < a.rows_cap * RS; i += NT) ldsS[i] = 0;
@@ -336,30 +277,6 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         ldsPM[2 * BM + i] = a.mprime[oc];
     }
 
-    int sxr[NS];  // 1x1 only: the receptive field is the pixel itself -- its channel sum accumulates from the B fragments
-#pragma unroll
-    for (int ns = 0; ns < NS; ++ns) sxr[ns] = 0;
-    auto compute = [&](const char *A, const char *Bt, int tapoff) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            v4i af[MS];
-#pragma unroll
-            for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const v4i *>(A + atab[ms] + h * 512);
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-                const v4i bf = *reinterpret_cast<const v4i *>(Bt + bbase[ns] + tapoff + h * 2 * PIECEB);
-                int t = sxr[ns];
-                t = __builtin_amdgcn_sdot4(bf[0], 0x01010101, t, false);
-                t = __builtin_amdgcn_sdot4(bf[1], 0x01010101, t, false);
-                t = __builtin_amdgcn_sdot4(bf[2], 0x01010101, t, false);
-                t = __builtin_amdgcn_sdot4(bf[3], 0x01010101, t, false);
-                sxr[ns] = t;
-#pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ms], bf, acc[ms][ns], 0, 0, 0);
-            }
-        }
-    };
     // per channel chunk: every thread reduces cells of the freshly landed B buffer into S
     auto cell_sums = [&](const char *Bt) {
         const int ncells = nrows * RS;
@@ -367,7 +284,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
             const int r = id / RS, c = id - r * RS;
             const char *p0 = Bt + r * rowb + c * 16;
             int t = 0;
-#pragma unroll
+#pragma unroll 1  // one piece (4 registers) at a time: this runs inside the K loop, where ~215 registers hold its state
             for (int p = 0; p < 4; ++p) {
                 const v4i v = *reinterpret_cast<const v4i *>(p0 + p * PIECEB);
                 t = __builtin_amdgcn_sdot4(v[0], 0x01010101, t, false);
@@ -379,162 +296,122 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         }
     };
 
-    if constexpr (KS == 3) {
-        // ---- software-pipelined 3x3 loop.  R = 6 A ring stages, three fragment register sets (one k-half each):
-        //        step g:  wait A(g+1) landed; s_barrier; issue DMA A(g+5) [B(chunk+1) on a chunk's first step]
-        //                 MFMA H0(g)  ||  ds_read H0(g+1)  -> the set H1(g-1) vacated
-        //                 MFMA H1(g)  ||  ds_read H1(g+1)  -> the set H0(g) vacated
-        //      A fragment set is read one whole K-step before its MFMAs, and a DMA is issued four steps (~2 us) before
-        //      its barrier: the in-loop stall profile (tools/conv_microbench.py --waveprof) showed the previous
-        //      two-set / four-stage loop waiting 8% of its time on vmcnt and ~15% on lgkmcnt.
+    {
+        // ---- software-pipelined 3x3 loop.  R = 6 A ring stages; per K-step g:  wait A(g+1) landed; s_barrier; issue DMA A(g+5)
+        //      [B(chunk+1) on a chunk's first steps]; the step's 24 MFMAs with the reads of step g+1's fragments threaded between
+        //      them, IN PLACE: B fragment ni is reloaded right after its four MFMAs, the A fragments during the last two rounds.
         constexpr int R = RA_STAGES;
         static_assert(R == 6 || R == 4, "ring depths the stage bookkeeping below is written for");
+        static_assert(MI == 4 && NI >= 2, "written for 64-row wave tiles");
         constexpr int ROT = 9 % R;  // ring phase advance of one channel chunk (nine K-steps)
-        v4i fa[3][MS], fb[3][NS];
-        // Fragment reads are issued as inline asm so that hipcc does not account for them: its own bookkeeping puts an
-        // s_waitcnt lgkmcnt(0) in front of the first MFMA after ANY ds_read.  We count instead: LDS returns in order,
-        // every k-half issues exactly MS+NS reads, and a k-half starts with lgkmcnt(MS+NS) (the set read during the
-        // previous k-half may still be in flight, the one before has landed).
-        // Fragment addresses live in registers per A ring stage and per tap row, so a K-step issues no address
-        // arithmetic at all: the tap column and the k-half are instruction immediates; once per channel chunk the A
-        // table is rotated (9 K-steps = ring phase + 3) and the B table moves to the other buffer.
-        unsigned aaddr[R][MS], baddr[3][NS];
+        v4i fa[MI], fb[NI];
+        // Fragment reads are issued as inline asm so that hipcc does not account for them (its own bookkeeping puts an
+        // s_waitcnt lgkmcnt(0) in front of the first MFMA after ANY ds_read).  We count instead: LDS returns in order and a
+        // K-step issues its reads in the order B0' .. B(NI-3)', A0' .. A3', B(NI-2)', B(NI-1)'.
+        // Addresses: one register per A ring stage (the fragment index is an immediate), one per B fragment for the tap ROW being
+        // read (moved on by rowb every third step: NI additions, instead of 3 x NI registers).
+        unsigned aaddr[R], baddr[NI];
 #pragma unroll
-        for (int st = 0; st < R; ++st)
+        for (int st = 0; st < R; ++st) aaddr[st] = lds0 + st * (BM * 64) + atab0;
 #pragma unroll
-            for (int ms = 0; ms < MS; ++ms) aaddr[st][ms] = lds0 + st * (BM * 64) + atab[ms];
-#pragma unroll
-        for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-            for (int ns = 0; ns < NS; ++ns) baddr[ty][ns] = lds0 + R * BM * 64 + bbase[ns] + ty * rowb;
+        for (int ni = 0; ni < NI; ++ni) baddr[ni] = lds0 + R * BM * 64 + bbase[ni];
 #define LDS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
-        // One k-half: the MFMAs of the set that has landed, with the ds_reads of a later set (and this step's DMA
-        // issue, `hook`) threaded between them.  A wave issues in order, so a burst of reads in front of the MFMAs
-        // leaves the matrix pipe idle while the LDS queue drains (all 8 waves leave the barrier together and the two
-        // waves of a SIMD stay in phase); interleaved, every read issues under an MFMA of the same wave.
-        // Every sub-tile is computed, also the ones past a narrow tile's last pixel (their results are never stored):
-        // skipping them cost two branches per k-half in every wave and only ever relieved waves off the critical path.
-        auto half = [&](const v4i(&ca)[MS], const v4i(&cb)[NS], v4i(&na)[MS], v4i(&nb)[NS], const unsigned(&aad)[MS],
-                        const unsigned(&bad)[NS], auto tap_c, auto h_c, auto rd_c, auto prev_rd_c, auto &&hook) {
-            constexpr int TAPOFF = decltype(tap_c)::value, H = decltype(h_c)::value;
-            constexpr bool RD = decltype(rd_c)::value, PREV_RD = decltype(prev_rd_c)::value;
-            const bool rd = RD && !DBG(8);
-            if (PREV_RD) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MS + NS) : "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (!DBG(4)) acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[0], cb[0], acc[0][0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            hook();
-            if (rd) {
-#pragma unroll
-                for (int ms = 0; ms < MS; ++ms) LDS_READ128(na[ms], aad[ms], H * 512);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (MS > 1 && !DBG(4)) acc[MS - 1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[MS - 1], cb[0], acc[MS - 1][0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (rd) {
-                LDS_READ128(nb[0], bad[0], TAPOFF + H * 2 * PIECEB);
-                if (NS > 1) LDS_READ128(nb[NS > 1 ? 1 : 0], bad[NS > 1 ? 1 : 0], TAPOFF + H * 2 * PIECEB);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ns = 1; ns < NS; ++ns) {
-                if (!DBG(4)) {
-#pragma unroll
-                    for (int ms = 0; ms < MS; ++ms)
-                        acc[ms][ns] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[ms], cb[ns], acc[ms][ns], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (ns + 1 < NS && rd) LDS_READ128(nb[ns + 1 < NS ? ns + 1 : 0], bad[ns + 1 < NS ? ns + 1 : 0], TAPOFF + H * 2 * PIECEB);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        auto nohook = [] {};
         using std::integral_constant;
         using std::true_type;
         using std::false_type;
         // prologue DMA (issued above): B(0), A(0..4) (ksteps >= 9); here A(0), A(1) (and B(0), older) have to have landed;
-        // then both k-halves of step 0 are put on their way
+        // then step 0's fragments are put on their way in the steady state's order
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * APT) : "memory");
         __builtin_amdgcn_s_barrier();
-        TS(2);
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) LDS_READ128(fa[0][ms], aaddr[0][ms], 0);
+        for (int ni = 0; ni < NI - 2; ++ni) LDS_READ128(fb[ni], baddr[ni], 0);
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) LDS_READ128(fb[0][ns], baddr[0][ns], 0);
-#pragma unroll
-        for (int ms = 0; ms < MS; ++ms) LDS_READ128(fa[1][ms], aaddr[0][ms], 512);
-#pragma unroll
-        for (int ns = 0; ns < NS; ++ns) LDS_READ128(fb[1][ns], baddr[0][ns], 2 * PIECEB);
-        WP_DECL;
-        WP_START();
+        for (int mi = 0; mi < MI; ++mi) LDS_READ128(fa[mi], aaddr[0], mi * 1024);
+        LDS_READ128(fb[NI - 2], baddr[NI - 2], 0);
+        LDS_READ128(fb[NI - 1], baddr[NI - 1], 0);
         // One channel chunk = 9 K-steps, fully unrolled.  LAST selects the variant for the final chunk; in both variants
-        // every "does that slab / chunk still exist" question is answered at compile time, so the steady state carries
-        // no bookkeeping branches (the previous single-variant loop spent ~50 scalar instructions and 13 branches per step).
+        // every "does that slab / chunk still exist" question is answered at compile time.
         auto chunk_body = [&](auto last_c, int chunk) {
             constexpr bool LAST = decltype(last_c)::value;
             const char *Bt = ldsB + (chunk & 1) * bbytes;
             const bool odd = chunk & 1;  // ring stage of tap 0 is (9 * chunk) % 6 = 3 * odd
             auto step = [&](auto t_c) {
                 constexpr int t = decltype(t_c)::value;
-                // fragments read in this step belong to step t+1: tap row table entry TYN + the immediate TAPN, A table
-                // entry SN (aaddr[s] is ring stage (3 * odd + s) % 6); on the chunk's last step they belong to tap 0 of
+                // fragments read in this step belong to step t+1: tap row table entry TYN + the immediate TAPN, A stage
+                // register SN (aaddr[s] is ring stage (3 * odd + s) % 6); on the chunk's last step they belong to tap 0 of
                 // the next chunk, read through the tables rotated for it
-                constexpr int TYN = ((t + 1) % 9) / 3;
                 constexpr int TAPN = ((t + 1) % 3) * 16;
                 constexpr int SN = (t == 8) ? 0 : (t + 1) % R;
-                constexpr int C0 = (2 * t) % 3, C1 = (2 * t + 1) % 3, N0 = (2 * t + 2) % 3, N1 = (2 * t + 3) % 3;
                 constexpr bool RD = (t < 8) || !LAST;            // there is a step t+1 to read fragments for
                 constexpr bool ISSUE_A = !LAST || (t + R - 1 < 9);  // slab g+5 exists
-                // DMA queue when this step waits for A(g+1), issued four steps ago as the last DMA of its step: younger
-                // than it are the DMAs of the three steps in between -- APT A slabs per step while slab s+5 exists, and the
-                // B slots of the next chunk on a chunk's first four steps (steps < 0 are the previous chunk's steps 6..8;
-                // for chunk 0 the prologue issued the same DMAs in the same order)
                 constexpr auto n_b = [](int st) { return (LAST || st < 0 || st >= 4) ? 0 : ((st + 1) * SPS < NBS ? (st + 1) * SPS : NBS) - (st * SPS < NBS ? st * SPS : NBS); };
                 constexpr auto n_a = [](int st) { return (st < 0 || !LAST || st + R - 1 < 9) ? APT : 0; };
                 constexpr int YOUNG = n_a(t - 1) + n_b(t - 1) + (R > 4 ? n_a(t - 2) + n_b(t - 2) + n_a(t - 3) + n_b(t - 3) : 0);
                 constexpr int BLO = t * SPS < NBS ? t * SPS : NBS, BHI = (t + 1) * SPS < NBS ? (t + 1) * SPS : NBS;
                 if (t == 8 && !LAST) {
-                    const int bdelta = odd ? -bbytes : bbytes;
-                    unsigned rot[R][MS];
+                    const int bdelta = (odd ? -bbytes : bbytes) - 2 * rowb;  // the other row image, back to its tap row 0
+                    unsigned rot[R];
 #pragma unroll
-                    for (int st = 0; st < R; ++st)
+                    for (int st = 0; st < R; ++st) rot[st] = aaddr[(st + ROT) % R];
 #pragma unroll
-                        for (int ms = 0; ms < MS; ++ms) rot[st][ms] = aaddr[(st + ROT) % R][ms];
+                    for (int st = 0; st < R; ++st) aaddr[st] = rot[st];
 #pragma unroll
-                    for (int st = 0; st < R; ++st)
-#pragma unroll
-                        for (int ms = 0; ms < MS; ++ms) aaddr[st][ms] = rot[st][ms];
-#pragma unroll
-                    for (int yy = 0; yy < 3; ++yy)
-#pragma unroll
-                        for (int ns = 0; ns < NS; ++ns) baddr[yy][ns] += bdelta;
+                    for (int ni = 0; ni < NI; ++ni) baddr[ni] += bdelta;
                 }
-                WP_MARK(0);  // LDS reads of the previous step drained
+                if (t == 2 || t == 5) {  // the fragments read from this step on belong to the next tap row
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) baddr[ni] += rowb;
+                }
                 if (t > 0 || chunk > 0) {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG) : "memory");
-                    WP_MARK(1);  // DMA wait
-                    if (!DBG(2)) __builtin_amdgcn_s_barrier();
-                    WP_MARK(2);  // barrier
+                    __builtin_amdgcn_s_barrier();
                 }
-                half(fa[C0], fb[C0], fa[N0], fb[N0], aaddr[SN], baddr[TYN], integral_constant<int, TAPN>{},
-                     integral_constant<int, 0>{}, integral_constant<bool, RD>{}, true_type{}, [&] {
-                         if (!LAST && t < 4 && !DBG(1))
-                             issueB_slots(chunk + 1, integral_constant<int, BLO>{}, integral_constant<int, BHI>{});
-                         if (ISSUE_A && !DBG(1)) {  // slab g+R-1 -> ring stage (9 * chunk + t + R - 1) % R
-                             if constexpr (R == 6) {  // (9 * chunk) % 6 = 3 * odd
-                                 constexpr unsigned E = ((t + R - 1) % R) * (BM * 64), O = ((t + R - 1 + 3) % R) * (BM * 64);
-                                 issueA_next(odd ? O : E);
-                             } else {                 // (9 * chunk) % 4 = chunk % 4
-                                 issueA_next((unsigned)((chunk + t + R - 1) & 3) * (BM * 64));
-                             }
-                         }
-                     });
-                WP_MARK(3);  // first k-half
-                half(fa[C1], fb[C1], fa[N1], fb[N1], aaddr[SN], baddr[TYN], integral_constant<int, TAPN>{},
-                     integral_constant<int, 1>{}, integral_constant<bool, RD>{}, integral_constant<bool, RD>{}, nohook);
-                WP_MARK(4);  // second k-half
-                if (t == 1 && !DBG(16)) {
+                auto dma = [&] {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!LAST && t < 4) issueB_slots(chunk + 1, integral_constant<int, BLO>{}, integral_constant<int, BHI>{});
+                    if (ISSUE_A) {  // slab g+R-1 -> ring stage (9 * chunk + t + R - 1) % R
+                        if constexpr (R == 6) {  // (9 * chunk) % 6 = 3 * odd
+                            constexpr unsigned E = ((t + R - 1) % R) * (BM * 64), O = ((t + R - 1 + 3) % R) * (BM * 64);
+                            issueA_next(odd ? O : E);
+                        } else {                 // (9 * chunk) % 4 = chunk % 4
+                            issueA_next((unsigned)((chunk + t + R - 1) & 3) * (BM * 64));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // this step's A fragments and B fragments 0 .. NI-3 have landed (the two reads issued after them may be in flight)
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < NI - 2; ++ni) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+                        if (ni == 0 && mi == 0) dma();  // this step's DMA issue, behind the first MFMA
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (RD) LDS_READ128(fb[ni], baddr[ni], TAPN);  // in place: its MFMAs have been issued
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the last two B fragments of this step (read at the end of the previous one): the reads issued since may be in flight
+                if (RD) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI - 2) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    acc[mi][NI - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[mi], fb[NI - 2], acc[mi][NI - 2], 0, 0, 0);
+                    if (NI == 2 && mi == 0) dma();  // (32-column wave tiles: there is no round in front of these)
+                    acc[mi][NI - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[mi], fb[NI - 1], acc[mi][NI - 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (RD) LDS_READ128(fa[mi], aaddr[SN], mi * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (RD) {
+                    LDS_READ128(fb[NI - 2], baddr[NI - 2], TAPN);
+                    LDS_READ128(fb[NI - 1], baddr[NI - 1], TAPN);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 1) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // our reads are invisible to hipcc's counters
                     cell_sums(Bt);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -548,36 +425,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         for (int chunk = 0; chunk + 1 < a.nchunks; ++chunk) chunk_body(false_type{}, chunk);
         chunk_body(true_type{}, a.nchunks - 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        WP_FLUSH();
 #undef LDS_READ128
-    } else {
-        TS(2);
-        // 1x1: every K-step is one 64-channel chunk; stage g % R1 of both rings holds step g.  A step's DMA group is its
-        // B slots followed by its A slabs (G instructions per wave), issued R1 - 1 steps ahead.
-        constexpr int R1 = RA_STAGES;
-        constexpr int G = NBS + APT;
-        static_assert(RB_STAGES == R1 && (R1 == 3 || R1 == 4), "1x1 loop: common ring depth");
-        for (int g0 = 0; g0 < a.ksteps; g0 += R1) {
-#pragma unroll
-            for (int u = 0; u < R1; ++u) {
-                const int g = g0 + u;
-                if (g < a.ksteps) {
-                    // group g has to have landed; the groups issued after it (at most R1 - 2) may stay in flight
-                    const int young = min(R1 - 2, a.ksteps - 1 - g);
-                    if (young == R1 - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R1 - 2) * G) : "memory");
-                    else if (young == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();  // ... for every wave, and every wave is past step g - 1: its stage is free
-                    if (g + R1 - 1 < a.ksteps) {
-                        issueB(g + R1 - 1);
-                        issueA_next(((u + R1 - 1) % R1) * (BM * 64));
-                    }
-                    const char *Bt = ldsB + u * bbytes;
-                    compute(ldsA + u * (BM * 64), Bt, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
     }
 
     TS(3);
@@ -588,18 +436,19 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     // ---- epilogue
     __syncthreads();  // S complete, all fragment reads done
     int sx[NS];
+    bool nvalid[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
         int t = 0;
-        if (KS == 1) {
-            t = sxr[ns] + __shfl_xor(sxr[ns], 32);  // the two 16-byte k-halves of every K-step
-        } else {
-            const int c0 = prow[ns] * RS + pcol[ns];
+        const int n = n0 + ((ns >> 1) * WNW + wn) * 32 + (ns & 1) * 16 + lj;
+        nvalid[ns] = n < n_end;
+        int gr, x;
+        row16_of_pixel(nvalid[ns] ? n : n_end - 1, a.H, a.W, a.fd_hw, a.fd_w, gr, x);  // idle lanes shadow the tile's last pixel, as in the K loop
+        const int c0 = (gr - grow_first - HALO) * RS + x + 1 - HALO;
 #pragma unroll
-            for (int dy = 0; dy < KS; ++dy)
+        for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < KS; ++dx) t += ldsS[c0 + dy * RS + dx];
-        }
+            for (int dx = 0; dx < KS; ++dx) t += ldsS[c0 + dy * RS + dx];
         sx[ns] = t;
     }
     __syncthreads();  // before the LDS is reused as the [BN][BM+4] uint8 output tile
@@ -610,7 +459,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     int pb_[NS], rem[NS], nl_[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-        const int nl = (ns * WNW + wn) * 32 + lj;
+        const int nl = ((ns >> 1) * WNW + wn) * 32 + (ns & 1) * 16 + lj;
         nl_[ns] = nl;
         const int nn = nvalid[ns] ? n0 + nl : 0;
         const int b = fd_div(nn, a.fd_hw);
@@ -618,7 +467,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         const int y = fd_div(rem0, a.fd_w), xx = rem0 - y * a.W;
         pb_[ns] = b;
         rem[ns] = rem0;
-        if (wm == 0 && kh == 0) {
+        if (wm == 0 && kq == 0) {
             // output cell; with a fused nearest-neighbour upsample (ref: src/upsample_layer.c:96-113) the top-left cell of the
             // pixel's up x up block in the (up*H) x (up*W) tensor
             const int up = a.up;
@@ -634,27 +483,29 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     auto epi_fast = [&](auto act_c, auto sat_c) {
         constexpr int ACT = decltype(act_c)::value;
         constexpr bool SAT = decltype(sat_c)::value != 0;
+        constexpr int NH = (NS % 3 == 0) ? 3 : 2;  // pixels requantised per call: 12 or 8 values in flight (registers)
+        static_assert(NS % NH == 0, "pixel tiles per lane");
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) {
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ocl = wm * TM + mi * 16 + 4 * kq;  // 4 consecutive filters held by this lane
+            const int4 dz4 = *reinterpret_cast<const int4 *>(ldsPI + BM + ocl);
+            const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
+            double mp[4];
 #pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
-                const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;
-                const int4 dz4 = *reinterpret_cast<const int4 *>(ldsPI + BM + ocl);
-                const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
-                int32_t accb[4][NS];
-                double mp[4];
+            for (int r = 0; r < 4; ++r) mp[r] = ldsPM[2 * BM + ocl + r];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    mp[r] = ldsPM[2 * BM + ocl + r];
+            for (int n0h = 0; n0h < NS; n0h += NH) {
+                int32_t accb[4][NH];
 #pragma unroll
-                    for (int ns = 0; ns < NS; ++ns)  // |dz| <= 128, |sx| < 2^23 (K <= 64K): 24-bit multiply, full rate
-                        accb[r][ns] = acc[ms][ns][grp * 4 + r] + __mul24(dzv[r], sx[ns]);
-                }
-                int32_t v[4][NS];
-                requant_values<ACT, SAT, NS>(accb, mp, a.zp_act, v);
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int ns = 0; ns < NS; ++ns)
-                    *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = pack4_biased(v[0][ns], v[1][ns], v[2][ns], v[3][ns]);
+                    for (int k = 0; k < NH; ++k)  // |dz| <= 128, |sx| < 2^23 (K <= 64K): 24-bit multiply, full rate
+                        accb[r][k] = acc[mi][n0h + k][r] + __mul24(dzv[r], sx[n0h + k]);
+                int32_t v[4][NH];
+                requant_values<ACT, SAT, NH>(accb, mp, a.zp_act, v);
+#pragma unroll
+                for (int k = 0; k < NH; ++k)
+                    *reinterpret_cast<uint32_t *>(otile + nl_[n0h + k] * OSTR + ocl) = pack4_biased(v[0][k], v[1][k], v[2][k], v[3][k]);
                 if (a.y_f32) {  // quant_stop tail (ref :752-760) and, fused, the yolo layer's activations
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -662,11 +513,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
                         if (oc < a.n) {
                             const int e = a.yolo_out ? oc % a.yolo_per : 0;
 #pragma unroll
-                            for (int ns = 0; ns < NS; ++ns)
-                                if (nvalid[ns]) {
-                                    const int u8 = v[r][ns] & 0xFF;
+                            for (int k = 0; k < NH; ++k)
+                                if (nvalid[n0h + k]) {
+                                    const int u8 = v[r][k] & 0xFF;
                                     const float f = (float)(u8 - a.zp_act) * a.s_act;
-                                    const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
+                                    const size_t ridx = ((size_t)pb_[n0h + k] * a.n + oc) * hw + rem[n0h + k];
                                     a.y_f32[ridx] = f;
                                     if (a.yolo_out) a.yolo_out[ridx] = (e == 2 || e == 3) ? f : ldsYL[u8];
                                 }
@@ -691,50 +542,47 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
             else epi_fast(integral_constant<int, MI355_ACT_LINEAR>{}, integral_constant<int, 0>{});
         }
     } else {
-    #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) {
-    #pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
-                const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;  // 4 consecutive channels held by this lane
-                const int oc0 = m0 + ocl;
-                if (oc0 >= a.n) {
-    #pragma unroll
-                    for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = 0x80808080u;
-                    continue;
-                }
-                uint32_t packed[NS];
-    #pragma unroll
-                for (int ns = 0; ns < NS; ++ns) packed[ns] = 0;
-    #pragma unroll
-                for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
-                    const int oc = oc0 + r;
-                    const int dzv = ldsPI[BM + ocl + r], biv = ldsPI[2 * BM + ocl + r];
-                    const double mv = ldsPM[ocl + r], sv = ldsPM[BM + ocl + r];
-    #pragma unroll
-                    for (int ns = 0; ns < NS; ++ns) {
-                        const int32_t accv = acc[ms][ns][grp * 4 + r] - biv + dzv * sx[ns];  // acc started at cw + bias
-                        uint32_t u8 = 0;
-                        if (oc < a.n) {
-                            u8 = requant_u8(accv, biv, mv, sv, a.zp_act, a.act, a.store_mode);
-                            if (nvalid[ns] && (a.acc_out || a.y_f32)) {
-                                const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
-                                if (a.acc_out) a.acc_out[ridx] = accv;
-                                if (a.y_f32) {
-                                    const float f = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
-                                    a.y_f32[ridx] = f;
-                                    if (a.yolo_out) {
-                                        const int e = oc % a.yolo_per;
-                                        a.yolo_out[ridx] = (e == 2 || e == 3) ? f : ldsYL[u8];
-                                    }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ocl = wm * TM + mi * 16 + 4 * kq;  // 4 consecutive filters held by this lane
+            const int oc0 = m0 + ocl;
+            if (oc0 >= a.n) {
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = 0x80808080u;
+                continue;
+            }
+            uint32_t packed[NS];
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) packed[ns] = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
+                const int oc = oc0 + r;
+                const int dzv = ldsPI[BM + ocl + r], biv = ldsPI[2 * BM + ocl + r];
+                const double mv = ldsPM[ocl + r], sv = ldsPM[BM + ocl + r];
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    const int32_t accv = acc[mi][ns][r] - biv + dzv * sx[ns];  // acc started at cw + bias
+                    uint32_t u8 = 0;
+                    if (oc < a.n) {
+                        u8 = requant_u8(accv, biv, mv, sv, a.zp_act, a.act, a.store_mode);
+                        if (nvalid[ns] && (a.acc_out || a.y_f32)) {
+                            const size_t ridx = ((size_t)pb_[ns] * a.n + oc) * hw + rem[ns];
+                            if (a.acc_out) a.acc_out[ridx] = accv;
+                            if (a.y_f32) {
+                                const float f = (float)((int)u8 - a.zp_act) * a.s_act;  // ref :757
+                                a.y_f32[ridx] = f;
+                                if (a.yolo_out) {
+                                    const int e = oc % a.yolo_per;
+                                    a.yolo_out[ridx] = (e == 2 || e == 3) ? f : ldsYL[u8];
                                 }
                             }
                         }
-                        packed[ns] |= (u8 ^ 0x80u) << (8 * r);
                     }
+                    packed[ns] |= (u8 ^ 0x80u) << (8 * r);
                 }
-    #pragma unroll
-                for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
             }
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
         }
     }
     __syncthreads();
@@ -789,7 +637,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WMW, int WNW, int RS, int KS>
-static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
+static int rows16_launch_cfg(ConvArgs &a, hipStream_t st)
 {
     constexpr int NW = WMW * WNW, NT = 64 * NW;
     constexpr int DW = (NW == 8 && KS == 3) ? 4 : NW;  // DMA waves, as in the kernel
@@ -800,20 +648,20 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     // rows spanned by BN consecutive pixels: pixel rows + one pad row per image boundary crossed, + halo rows
     a.rows_cap = (BN - 2 + a.W) / a.W + 1 + (BN - 2 + a.H * a.W) / (a.H * a.W) + 2 * HALO;
     const int ndma = a.rows_cap * (RS / 16);
-    if ((ndma + DW - 1) / DW > rows_nb_slots(BN, RS, DW, KS)) return MI355_EINVAL;  // map too narrow for this tile
+    if ((ndma + DW - 1) / DW > rows16_nb_slots(BN, RS, DW, KS)) return MI355_EINVAL;  // map too narrow for this tile
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     a.rowb = RS * 64 + 16 * (a.W & 15);
     a.fd_hw = fastdiv_make((uint32_t)(a.H * a.W)); a.fd_w = fastdiv_make((uint32_t)a.W);
     a.fd_ntn = fastdiv_make((uint32_t)a.ntiles_n); a.fd_nch = fastdiv_make((uint32_t)a.nchunks);
     a.tile_q = a.total_n / a.ntiles_n; a.tile_r = a.total_n % a.ntiles_n;
-    size_t lds = (size_t)ra_stages<KS, BN>() * BM * 64 + (size_t)rb_stages<KS, BN>() * a.rows_cap * a.rowb + (size_t)a.rows_cap * RS * 4;
+    size_t lds = (size_t)ra16_stages<KS, BN>() * BM * 64 + (size_t)rb16_stages<KS, BN>() * a.rows_cap * a.rowb + (size_t)a.rows_cap * RS * 4;
     const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
     if (lds_epi > lds) lds = lds_epi;
     lds = (lds + 15) & ~(size_t)15;
     a.lds_param_off = (int)lds;  // beyond both the K-loop buffers and the epilogue tile
     lds += (size_t)BM * 40 + 1024;
     if (lds > 160 * 1024) return MI355_EINVAL;
-    auto kern = conv_rows_i8_kernel<BM, BN, WMW, WNW, RS, KS>;
+    auto kern = conv_rows16_i8_kernel<BM, BN, WMW, WNW, RS, KS>;
     // per kernel instantiation AND per device (function attributes are per device; `darknet -gpus` drives several devices
     // from one process): raise the dynamic-LDS limit once, not per launch
     static size_t lds_attr_dev[64] = {0};
@@ -845,48 +693,24 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
 
-template <int RS, int KS>
-static int rows_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
+template <int RS>
+static int rows16_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
 {
-    if (bm == 128 && bn == 384) return rows_launch_cfg<128, 384, 2, 4, RS, KS>(a, st);
-    if (bm == 128 && bn == 256) return rows_launch_cfg<128, 256, 2, 4, RS, KS>(a, st);
-    if (bm == 128 && bn == 128) return rows_launch_cfg<128, 128, 2, 2, RS, KS>(a, st);
-    if (bm == 64 && bn == 256) return rows_launch_cfg<64, 256, 1, 4, RS, KS>(a, st);
-    if (bm == 64 && bn == 128) return rows_launch_cfg<64, 128, 1, 4, RS, KS>(a, st);
-    if (bm == 32 && bn == 256) return rows_launch_cfg<32, 256, 1, 4, RS, KS>(a, st);
-    if (bm == 32 && bn == 128) return rows_launch_cfg<32, 128, 1, 4, RS, KS>(a, st);
-    return MI355_EINVAL;
+    if (bm == 128 && bn == 384) return rows16_launch_cfg<128, 384, 2, 4, RS, 3>(a, st);
+    if (bm == 128 && bn == 256) return rows16_launch_cfg<128, 256, 2, 4, RS, 3>(a, st);
+    if (bm == 128 && bn == 128) return rows16_launch_cfg<128, 128, 2, 2, RS, 3>(a, st);
+    if (bm == 64 && bn == 256) return rows16_launch_cfg<64, 256, 1, 4, RS, 3>(a, st);
+    if (bm == 64 && bn == 128) return rows16_launch_cfg<64, 128, 1, 4, RS, 3>(a, st);
+    return MI355_EINVAL;  // 32-filter tiles: conv_rows.hip
 }
 
-// The 3x3 and the 1x1 instantiations live in two translation units (conv_rows.hip, conv_rows_k1.hip = this file
-// compiled with ROWS_TU_KS1) so that they compile in parallel: 21 kernel instantiations each.
-#ifdef ROWS_TU_KS1
-int conv_rows_launch_k1(ConvArgs &a, hipStream_t st, int bm, int bn)
+// 3x3 layers on 64-channel chunks with 64-row wave tiles; MI355_EINVAL -> conv_rows.hip's kernel (1x1, 32-filter tiles)
+int conv_rows16_launch(ConvArgs &a, hipStream_t st, int bm, int bn)
 {
+    if (a.cb != 64 || a.ksize != 3) return MI355_EINVAL;
     const int need = a.W + 2;
-    if (need <= 16) return rows_launch_tile<16, 1>(a, st, bm, bn);
-    if (need <= 32) return rows_launch_tile<32, 1>(a, st, bm, bn);
-    if (need <= 64) return rows_launch_tile<64, 1>(a, st, bm, bn);
+    if (need <= 16) return rows16_launch_tile<16>(a, st, bm, bn);
+    if (need <= 32) return rows16_launch_tile<32>(a, st, bm, bn);
+    if (need <= 64) return rows16_launch_tile<64>(a, st, bm, bn);
     return MI355_EINVAL;
 }
-#else
-int conv_rows_launch_k1(ConvArgs &a, hipStream_t st, int bm, int bn);
-
-// returns MI355_EINVAL when the shape is outside this kernel's domain (caller falls back to conv_igemm.hip)
-int conv_rows16_launch(ConvArgs &a, hipStream_t st, int bm, int bn);  // conv_rows16.hip: the 3x3 kernel on 16x16x64 MFMAs
-
-int conv_rows_launch(ConvArgs &a, hipStream_t st, int bm, int bn)
-{
-    if (a.cb != 64) return MI355_EINVAL;
-    if (a.ksize != 3) return conv_rows_launch_k1(a, st, bm, bn);
-    if (!(a.debug & (1 << 20))) {  // (bit 20: the 32x32x32 kernel below, for A/B runs)
-        const int rc = conv_rows16_launch(a, st, bm, bn);
-        if (rc != MI355_EINVAL) return rc;
-    }
-    const int need = a.W + 2;
-    if (need <= 16) return rows_launch_tile<16, 3>(a, st, bm, bn);
-    if (need <= 32) return rows_launch_tile<32, 3>(a, st, bm, bn);
-    if (need <= 64) return rows_launch_tile<64, 3>(a, st, bm, bn);
-    return MI355_EINVAL;
-}
-#endif
