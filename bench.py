@@ -61,7 +61,7 @@ def pmc_traffic_per_launch():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))  # rNN_vM_...: the name orders them (mtimes do not survive a snapshot)
     if not files:
         return None, None
-    rows = [r for r in json.load(open(files[-1])) if "conv_rows_i8_kernel" in r["kernel"]]
+    rows = [r for r in json.load(open(files[-1])) if "conv_rows_i8_kernel" in r["kernel"] or "conv_rows16_i8_kernel" in r["kernel"]]
     n = sum(r["launches"] for r in rows)
     if not n:
         return None, None
@@ -243,7 +243,7 @@ def main():
             t_unprof = (dt * 1e3 - nprof * t_prof) / (args.steps - nprof)
             ev_cost = min(ev_cost, max((t_prof - t_unprof) / len(ms), 0.0))
         def on_rows_kernel(i, inf):
-            """conv_rows_i8_kernel launches: 64-byte channel chunks, served by the implicit-GEMM family (the host records
+            """conv_rows16_i8_kernel / conv_rows_i8_kernel launches: 64-byte channel chunks, served by the implicit-GEMM family (the host records
             which kernel family took each conv of the last step: conv_small / conv1x1 / conv_ws3 take the others)."""
             return inf["type"] == binding.T_CONV and inf["c"] % 64 == 0 and net.conv_kernel(i) == 5
         mf_ops = mf_ms = all_ops = all_ms = 0.0
@@ -269,7 +269,7 @@ def main():
         nconv = sum(1 for inf in net.info if inf["type"] == binding.T_CONV)
         achieved = mf_ops / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
         traffic, traffic_src = pmc_traffic_per_launch()
-        roof = {"bound": "mfma", "kernel": f"conv_rows_i8_kernel (MFMA implicit GEMM on 64-channel chunks: {nlaunch} of the step's {nconv} conv launches, "
+        roof = {"bound": "mfma", "kernel": f"conv_rows16_i8_kernel / conv_rows_i8_kernel (row-image MFMA implicit GEMM on 64-channel chunks, 3x3 on V_MFMA_I32_16X16X64_I8: {nlaunch} of the step's {nconv} conv launches, "
                           f"{100 * mf_ms / all_ms:.0f}% of its time and {100 * mf_ops / all_ops:.0f}% of its operations)",
                 "achieved": round(achieved, 2), "peak": round(PEAK_INT8_TOPS, 1), "unit": "TOP/s",
                 "frac": round(achieved / PEAK_INT8_TOPS, 4),
