@@ -204,9 +204,14 @@ def main():
     for _ in range(args.warmup):
         net.forward()
     barrier()
-    # per-layer HIP events (launch stream) are recorded on every PROF_STRIDE-th step of the timed region: each event
-    # costs ~3 us of stream time, 13% of a step if all 25 layers of every step carry one
-    prof_stride = max(1, int(os.environ.get("BENCH_PROF_STRIDE", "8")))
+    # per-layer HIP events (launch stream) are recorded on every PROF_STRIDE-th step of the timed region.  An event costs
+    # ~3.9 us of stream time: ~100 us for the 26 of a profiled step.  Measured in one box (400 steps): 0.377 ms / step with every
+    # 8th step profiled, 0.365 with a single profiled step -- 3 % of `value` went into its own instrumentation.  Every 32nd step
+    # (at least one) keeps that below 1 % on long runs (1.4 % at --steps 20).
+    # A short timed region also sees the device's start-up: after any idle phase of more than ~2 ms the first ~25 steps run up
+    # to 8 % slower (tools/dbg/step_curve.py: 0.400 0.388 0.376 0.370 0.368 .. ms per step in groups of five; --warmup 5
+    # --steps 20 gives 0.38, --warmup 50 0.361, --warmup 200 0.355 in the same box).  Nothing is done about that here.
+    prof_stride = max(1, int(os.environ.get("BENCH_PROF_STRIDE", "32")))
     prof_steps = 0 if args.graph else min((args.steps + prof_stride - 1) // prof_stride, 64)
     net.profile_begin(prof_steps, prof_stride)
     barrier()
