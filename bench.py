@@ -212,8 +212,10 @@ def main():
     # to 8 % slower (tools/dbg/step_curve.py: 0.400 0.388 0.376 0.370 0.368 .. ms per step in groups of five; --warmup 5
     # --steps 20 gives 0.38, --warmup 50 0.361, --warmup 200 0.355 in the same box).  Nothing is done about that here.
     prof_stride = max(1, int(os.environ.get("BENCH_PROF_STRIDE", "32")))
-    prof_steps = 0 if args.graph else min((args.steps + prof_stride - 1) // prof_stride, 64)
-    net.profile_begin(prof_steps, prof_stride)
+    # ... counted back from the LAST step of the timed region (the first ones run on a device that is still ramping up)
+    prof_phase = (args.steps - 1) % prof_stride
+    prof_steps = 0 if args.graph else min((args.steps - 1 - prof_phase) // prof_stride + 1, 64)
+    net.profile_begin(prof_steps, prof_stride, prof_phase)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -152,7 +152,8 @@ struct network {
      * ref: src/network.c:244-246) */
     void **prof_ev;      /* [prof_cap][n+2] events */
     int prof_cap, prof_used;
-    int prof_stride, prof_calls; /* events are recorded on every prof_stride-th forward (they cost ~3 us per layer) */
+    int prof_stride, prof_calls; /* events are recorded on every prof_stride-th forward (they cost ~2.4 us per layer) ... */
+    int prof_phase;              /* ... the ones with call index % prof_stride == prof_phase */
 };
 
 /* ---- construction / IO ------------------------------------------------------------------------------------ */
@@ -219,6 +220,7 @@ char **get_labels(char *filename, int *count);
  * launches only), then read the per-layer sums in ms: out[0] = input layout conversion, out[1+i] = layer i. */
 void network_profile_begin(network *net, int max_steps);
 void network_profile_set_stride(network *net, int stride);
+void network_profile_set_phase(network *net, int phase);
 int network_profile_read(network *net, float *ms_sum /* [n+1] */);
 
 /* packed-weight exchange for multi-GPU start-up: rank 0 exports, the bytes travel by RCCL broadcast, the other

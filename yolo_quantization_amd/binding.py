@@ -247,6 +247,7 @@ def host():
         L.network_profile_read.argtypes = [vp, vp]
         L.network_yolo_detections_gpu.argtypes = [vp, ci, ci, ci, C.c_float, ci, vp, ci, vp]
         L.network_profile_set_stride.argtypes = [vp, ci]
+        L.network_profile_set_phase.argtypes = [vp, ci]
         L.network_packed_size.restype = C.c_size_t
         L.network_packed_size.argtypes = [vp]
         L.network_export_packed.argtypes = [vp, vp]
@@ -421,8 +422,10 @@ class Net:
                                            counts.ctypes.data)
         return counts, recs
 
-    def profile_begin(self, max_steps, stride=1):
+    def profile_begin(self, max_steps, stride=1, phase=0):
+        """record per-layer events on the forward passes whose index (from now) % stride == phase, at most max_steps of them"""
         self.H.network_profile_set_stride(self.h, stride)
+        self.H.network_profile_set_phase(self.h, phase)
         self.H.network_profile_begin(self.h, max_steps)
 
     def profile_read(self):

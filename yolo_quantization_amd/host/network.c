@@ -493,6 +493,7 @@ void network_profile_begin(network *net, int max_steps)
 }
 
 void network_profile_set_stride(network *net, int stride) { net->prof_stride = stride < 1 ? 1 : stride; }
+void network_profile_set_phase(network *net, int phase) { net->prof_phase = phase < 0 ? 0 : phase; }
 
 int network_profile_read(network *net, float *ms_sum)
 {
@@ -512,7 +513,7 @@ static void run_layers(network *netp)
 {
     network net = *netp;
     void **ev = NULL;
-    if (netp->prof_ev && netp->prof_used < netp->prof_cap && !netp->use_graph && netp->prof_calls++ % netp->prof_stride == 0)
+    if (netp->prof_ev && netp->prof_used < netp->prof_cap && !netp->use_graph && netp->prof_calls++ % netp->prof_stride == netp->prof_phase % netp->prof_stride)
         ev = netp->prof_ev + (size_t)(netp->prof_used++) * (net.n + 2);
     if (ev) check_mi355(mi355_event_record(ev[0], net.stream), "event");
     /* The first layer reads the reference's [B][3][H][W] planes in place where its kernel can (no conversion pass); else the
