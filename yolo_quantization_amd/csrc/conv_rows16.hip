@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
     constexpr int RB_STAGES = rb16_stages<KS, BN>();
     constexpr int NBS = rows16_nb_slots(BN, RS, DW, KS);  // B DMA slots per (DMA) wave per chunk
     constexpr int SPS = (NBS + 3) / 4;                  // ... issued per K-step over a chunk's first four steps (3x3 loop)
-    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
+    static_assert(TM % 16 == 0 && TN % 32 == 0, "wave tile: 16-row tiles, 32-column sub-tiles");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // smem: [RA_STAGES][BM*64] A ring first
