@@ -429,7 +429,12 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
             WP3_MARK(2);
         }
     }
-    if (PM && !(a.debug & (1 << 22))) {
+#ifdef MI355_ABLATE
+    const bool pool_pass = PM && !(a.debug & (1 << 22));  // timing ablation: no pool pass (the pooled tensor is not written)
+#else
+    const bool pool_pass = PM;
+#endif
+    if (pool_pass) {
         __syncthreads();  // every group's bytes are staged
         // NQ and nset are powers of two (conv_ws3_eligible): no divisions in the loops below
         const int lgND = 3 + __builtin_ctz(NQ), ND = 1 << lgND;  // dwords of a pixel's filters in this workgroup
