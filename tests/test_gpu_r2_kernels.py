@@ -214,3 +214,31 @@ def test_ws3_fused_maxpool_is_refused_outside_its_domain():
         blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv))
         d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT["leaky"], 0, 0, 0, 23, 0.05)
         assert S.mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, None, yp.ref(), None) == -22, (B, c, n, H, W, s1)
+
+
+@pytest.mark.parametrize("B,c,n,H,W,act", [(64, 512, 1024, 13, 13, "leaky"),   # yolov3-tiny layer 12 at the bench's batch: 128 x 384 tiles
+                                           (16, 384, 256, 26, 26, "relu6"),    # layer 21's shape
+                                           (8, 256, 192, 19, 19, "linear"),    # ragged filter count, 19-wide map
+                                           (4, 64, 64, 30, 30, "leaky"),       # 64-filter tiles
+                                           (2, 128, 128, 52, 52, "leaky")])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+def test_row_image_kernel_on_16x16x64_mfma_equals_the_32x32x32_one(B, c, n, H, W, act, store):
+    """conv_rows16.hip (V_MFMA_I32_16X16X64_I8, fragments prefetched in place) against conv_rows.hip (debug switch 2^20 routes the
+    call back to it) on the same launch: identical bytes and float tails; image 0 against the oracle."""
+    rng = np.random.default_rng(B + c + n + H)
+    S = binding.shim()
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3)
+    xt = binding.DevTensor.from_nchw(x, 23)
+    S.mi355_debug_flags(16384)   # keep the weights-stationary kernel out of the way: both runs on the row-image family
+    try:
+        new = binding.conv_forward(xt, wq, zp_w, 3, bias, mv, sv, 23, 31, 0.05, binding.ACT[act], store, binding.ACC_EXACT, want_acc=False, want_f32=True)
+        assert S.mi355_last_conv_kernel() == 5
+        S.mi355_debug_flags(16384 | (1 << 20))
+        old = binding.conv_forward(xt, wq, zp_w, 3, bias, mv, sv, 23, 31, 0.05, binding.ACT[act], store, binding.ACC_EXACT, want_acc=False, want_f32=True)
+        assert S.mi355_last_conv_kernel() == 5
+    finally:
+        S.mi355_debug_flags(0)
+    assert np.array_equal(new["u8"], old["u8"]) and np.array_equal(new["f32"], old["f32"])
+    want = oracle.requant(oracle.conv_acc(x[0], wq, zp_w, 3, 1, 1, 23), bias, mv, sv, 31, oracle.ACT[act], store)
+    assert np.array_equal(new["u8"][0].reshape(n, -1), want.reshape(n, -1))
