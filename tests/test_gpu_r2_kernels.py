@@ -220,7 +220,9 @@ def test_ws3_fused_maxpool_is_refused_outside_its_domain():
                                            (16, 384, 256, 26, 26, "relu6"),    # layer 21's shape
                                            (8, 256, 192, 19, 19, "linear"),    # ragged filter count, 19-wide map
                                            (4, 64, 64, 30, 30, "leaky"),       # 64-filter tiles
-                                           (2, 128, 128, 52, 52, "leaky")])
+                                           (2, 128, 128, 52, 52, "leaky"),
+                                           (32, 512, 1024, 19, 19, "leaky"),   # YOLOv3-608's 19-wide maps: the narrow-map variant (128 x 384 tiles, exact LDS rows, extra DMA slots)
+                                           (24, 256, 128, 20, 17, "relu6")])   # 17 + 2 cells in a 32-slot row, tiles that straddle images
 @pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
 def test_row_image_kernel_on_16x16x64_mfma_equals_the_32x32x32_one(B, c, n, H, W, act, store):
     """conv_rows16.hip (V_MFMA_I32_16X16X64_I8, fragments prefetched in place) against conv_rows.hip (debug switch 2^20 routes the

@@ -668,7 +668,9 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
                 // tiles pay for the empty slots in every B-slab DMA and LDS byte: measured 173 / 114 us with 256-column
                 // tiles against 116 / 88 us with two 128-column workgroups per CU (256->512 @38, 512->1024 @19, batch 32)
                 const int rs = a.W + 2 <= 16 ? 16 : (a.W + 2 <= 32 ? 32 : 64);
-                const double rowpen = (cbn != 128 && a.ksize == 3 && (a.W + 2) < 0.7 * rs) ? 1.5 : 1.0;
+                // (128 x 384 tiles on 32-slot rows have a narrow-map variant in conv_rows16.hip: exact LDS rows, extra DMA slots)
+                const bool narrow_ok = bm == 128 && cbn == 384 && rs == 32 && !(g_debug & (1 << 20));
+                const double rowpen = (cbn != 128 && a.ksize == 3 && (a.W + 2) < 0.7 * rs && !narrow_ok) ? 1.5 : 1.0;
                 // two 4-wave workgroups per CU are scheduled as they finish: count fractional rounds for them
                 const double nrounds = (slots == 512) ? (double)((long)mt * nt) / slots : (double)rounds;
                 const double cost = (nrounds < 1.0 ? 1.0 : nrounds) * (10.0 + a.ksteps * step) * shape * rowpen + 0.005 * cbn;

@@ -62,7 +62,9 @@ __device__ __forceinline__ void row16_of_pixel(int n, int H, int W, FastDiv fd_h
     grow = b * (H + 1) + y + 1;
 }
 
-template <int BM, int BN, int WMW, int WNW, int RS, int KS>
+// NBX: extra B DMA slots per DMA wave, for maps that fill their LDS row image badly (19 + 2 cells in a 32-slot row: a 384-pixel tile
+// then spans more rows than the slot count sized for W >= 3/4 RS covers).  Its own instantiation: the common one keeps its registers.
+template <int BM, int BN, int WMW, int WNW, int RS, int KS, int NBX = 0>
 __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const ConvArgs a)
 {
     constexpr int NW = WMW * WNW, NT = 64 * NW;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
     constexpr int OSTR = BM + 4;
     constexpr int RA_STAGES = ra16_stages<KS, BN>();
     constexpr int RB_STAGES = rb16_stages<KS, BN>();
-    constexpr int NBS = rows16_nb_slots(BN, RS, DW, KS);  // B DMA slots per (DMA) wave per chunk
+    constexpr int NBS = rows16_nb_slots(BN, RS, DW, KS) + NBX;  // B DMA slots per (DMA) wave per chunk
     constexpr int SPS = (NBS + 3) / 4;                  // ... issued per K-step over a chunk's first four steps (3x3 loop)
     static_assert(TM % 16 == 0 && TN % 32 == 0, "wave tile: 16-row tiles, 32-column sub-tiles");
 
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WMW, int WNW, int RS, int KS>
+template <int BM, int BN, int WMW, int WNW, int RS, int KS, int NBX = 0>
 static int rows16_launch_cfg(ConvArgs &a, hipStream_t st)
 {
     constexpr int NW = WMW * WNW, NT = 64 * NW;
@@ -645,15 +647,27 @@ static int rows16_launch_cfg(ConvArgs &a, hipStream_t st)
     if (a.mpad % BM) return MI355_EINVAL;
     a.mtiles = a.mpad / BM;
     if (a.ntiles_n < (a.total_n + BN - 1) / BN) a.ntiles_n = (a.total_n + BN - 1) / BN;  // tiles must fit BN
-    // rows spanned by BN consecutive pixels: pixel rows + one pad row per image boundary crossed, + halo rows
-    a.rows_cap = (BN - 2 + a.W) / a.W + 1 + (BN - 2 + a.H * a.W) / (a.H * a.W) + 2 * HALO;
+    // LDS rows of the row image: the most any tile of THIS plan spans (pixel rows + one pad row per image boundary crossed) + halo
+    // rows -- not the bound for BN arbitrary pixels, which costs narrow maps the LDS their widest tiles need
+    a.tile_q = a.total_n / a.ntiles_n; a.tile_r = a.total_n % a.ntiles_n;
+    {
+        const int hw = a.H * a.W;
+        auto grow = [&](long n) { const long b = n / hw, r = n - b * hw; return (int)(b * (a.H + 1) + r / a.W + 1); };
+        int span = 0;
+        for (int t = 0; t < a.ntiles_n; ++t) {
+            const long n0 = (long)t * a.tile_q + (t < a.tile_r ? t : a.tile_r), n1 = n0 + a.tile_q + (t < a.tile_r ? 1 : 0) - 1;
+            if (n1 < n0) continue;
+            const int sp = grow(n1) - grow(n0) + 1;
+            if (sp > span) span = sp;
+        }
+        a.rows_cap = span + 2 * HALO;
+    }
     const int ndma = a.rows_cap * (RS / 16);
-    if ((ndma + DW - 1) / DW > rows16_nb_slots(BN, RS, DW, KS)) return MI355_EINVAL;  // map too narrow for this tile
+    if ((ndma + DW - 1) / DW > rows16_nb_slots(BN, RS, DW, KS) + NBX) return MI355_EINVAL;  // map too narrow for this tile
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     a.rowb = RS * 64 + 16 * (a.W & 15);
     a.fd_hw = fastdiv_make((uint32_t)(a.H * a.W)); a.fd_w = fastdiv_make((uint32_t)a.W);
     a.fd_ntn = fastdiv_make((uint32_t)a.ntiles_n); a.fd_nch = fastdiv_make((uint32_t)a.nchunks);
-    a.tile_q = a.total_n / a.ntiles_n; a.tile_r = a.total_n % a.ntiles_n;
     size_t lds = (size_t)ra16_stages<KS, BN>() * BM * 64 + (size_t)rb16_stages<KS, BN>() * a.rows_cap * a.rowb + (size_t)a.rows_cap * RS * 4;
     const size_t lds_epi = (size_t)BN * (BM + 4) + (size_t)BN * 4;
     if (lds_epi > lds) lds = lds_epi;
@@ -661,7 +675,7 @@ static int rows16_launch_cfg(ConvArgs &a, hipStream_t st)
     a.lds_param_off = (int)lds;  // beyond both the K-loop buffers and the epilogue tile
     lds += (size_t)BM * 40 + 1024;
     if (lds > 160 * 1024) return MI355_EINVAL;
-    auto kern = conv_rows16_i8_kernel<BM, BN, WMW, WNW, RS, KS>;
+    auto kern = conv_rows16_i8_kernel<BM, BN, WMW, WNW, RS, KS, NBX>;
     // per kernel instantiation AND per device (function attributes are per device; `darknet -gpus` drives several devices
     // from one process): raise the dynamic-LDS limit once, not per launch
     static size_t lds_attr_dev[64] = {0};
@@ -704,13 +718,17 @@ static int rows16_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
     return MI355_EINVAL;  // 32-filter tiles: conv_rows.hip
 }
 
-// 3x3 layers on 64-channel chunks with 64-row wave tiles; MI355_EINVAL -> conv_rows.hip's kernel (1x1, 32-filter tiles)
+// Which 3x3 layers take this kernel is a measured choice (same-box A/B against conv_rows.hip, profiles/r02_v4_ab_and_startup.log):
+// 16-slot row images (maps up to 14 wide: yolov3-tiny's 512 -> 1024 @13, -1 us) and the narrow maps on 32-slot rows that only the
+// variant with exact LDS rows + extra DMA slots can give 128 x 384 tiles (YOLOv3-608's 512 -> 1024 @19: 92.7 -> 66.2 us).  On
+// well-filled 32-slot rows (384 -> 256 @26) the 32x32x32 kernel is ~1 us faster (this kernel's 128 x 384 instantiation sits at the
+// 256-register limit there) and keeps the layer; 64-slot rows were not measured and stay with it too.
+// MI355_EINVAL -> conv_rows.hip's kernel.
 int conv_rows16_launch(ConvArgs &a, hipStream_t st, int bm, int bn)
 {
     if (a.cb != 64 || a.ksize != 3) return MI355_EINVAL;
     const int need = a.W + 2;
     if (need <= 16) return rows16_launch_tile<16>(a, st, bm, bn);
-    if (need <= 32) return rows16_launch_tile<32>(a, st, bm, bn);
-    if (need <= 64) return rows16_launch_tile<64>(a, st, bm, bn);
+    if (need <= 32 && need < 24 && bm == 128 && bn == 384) return rows16_launch_cfg<128, 384, 2, 4, 32, 3, 4>(a, st);  // e.g. 19-wide maps
     return MI355_EINVAL;
 }
