@@ -161,12 +161,12 @@ def main():
     # ---- model: rank 0 reads the weights file, preps and packs; the packed bytes travel by RCCL broadcast
     if rank == 0:
         synth.synth_weights(args.cfg, wts, seed=1234)
-        net = binding.Net(args.cfg, wts, batch=B, gpu=local_rank, use_graph=args.graph)
+        net = binding.Net(args.cfg, wts, batch=B, gpu=local_rank, use_graph=args.graph, keep_head_float=False)
         net.prepare_fixed(1.0 / 255.0, 0)
         packed = net.export_packed()
         size_t = torch.tensor([packed.size], dtype=torch.int64, device=dev)
     else:
-        net = binding.Net(args.cfg, None, batch=B, gpu=local_rank, use_graph=args.graph)
+        net = binding.Net(args.cfg, None, batch=B, gpu=local_rank, use_graph=args.graph, keep_head_float=False)
         size_t = torch.zeros(1, dtype=torch.int64, device=dev)
     bcast_ms = 0.0
     if world > 1 or force_dist:
@@ -184,7 +184,7 @@ def main():
         if rank != 0 or force_dist:
             if force_dist and rank == 0:  # single-rank self test: re-import what was exported
                 net.close()
-                net = binding.Net(args.cfg, None, batch=B, gpu=local_rank, use_graph=args.graph)
+                net = binding.Net(args.cfg, None, batch=B, gpu=local_rank, use_graph=args.graph, keep_head_float=False)
             net.import_packed_gpu(blob.data_ptr(), nbytes)
 
     if os.environ.get("BENCH_NO_DIRECT_INPUT") == "1":  # A/B: layer 0 through the 4-byte-cell conversion pass instead of reading the planes

@@ -134,6 +134,8 @@ struct network {
     /* knobs (CLI: -accum exact|ref-f32, -parity wrap|saturate) */
     int accum_mode, store_mode;
     int dump_int32; /* keep int32 accumulators of every conv (parity runs) */
+    int keep_head_float; /* 0 (default): a head conv fused with its yolo layer does not store its own float tensor (l.output: an
+                            intermediate only the yolo layer reads); 1: it does (per-layer parity dumps) */
     int fuse_maxpool; /* 1 (default): conv + following 2x2/2 maxpool fused, the pre-pool tensor is not stored.
                          0: every layer writes its own tensor like the reference (per-layer parity dumps) */
     const mi355_tensor *fused_up_t;   /* run-time: upsampled tensor the conv being run has to fill, or NULL */

@@ -158,7 +158,9 @@ int mi355_conv_pool_forward(const mi355_conv_desc *desc, const mi355_tensor *x, 
 /* A quant_stop head convolution fused with the yolo layer that follows it (ref: forward_yolo_layer, src/yolo_layer.c:132-146):
  * writes y (uint8), y_f32 (== l.output of the conv, ref :752-760) and yolo_out (== l.output of the yolo layer: logistic on
  * x, y, objectness and class scores of every anchor) from one kernel.  desc.n must be a multiple of classes + 5; exact
- * accumulation mode.  Results are identical to mi355_conv_forward + mi355_yolo_forward. */
+ * accumulation mode.  Results are identical to mi355_conv_forward + mi355_yolo_forward.  y_f32 may be NULL (the conv's own float
+ * tensor is an intermediate only the yolo layer reads): the 1x1 heads then write yolo_out alone -- MI355_EINVAL where the kernel
+ * that serves the shape cannot (pass the buffer then). */
 int mi355_conv_yolo_forward(const mi355_conv_desc *desc, const mi355_tensor *x, const void *blob, const mi355_tensor *y,
                             float *y_f32, float *yolo_out, int classes, void *stream);
 

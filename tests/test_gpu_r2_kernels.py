@@ -244,3 +244,40 @@ def test_row_image_kernel_on_16x16x64_mfma_equals_the_32x32x32_one(B, c, n, H, W
     assert np.array_equal(new["u8"], old["u8"]) and np.array_equal(new["f32"], old["f32"])
     want = oracle.requant(oracle.conv_acc(x[0], wq, zp_w, 3, 1, 1, 23), bias, mv, sv, 31, oracle.ACT[act], store)
     assert np.array_equal(new["u8"][0].reshape(n, -1), want.reshape(n, -1))
+
+
+def test_heads_without_their_own_float_tensor(cfg_dir, tmp_path):
+    """The library's default: a quant_stop head conv fused with its yolo layer stores the yolo layer's l.output only (its own
+    l.output is an intermediate nothing else reads; mi355_conv_yolo_forward with y_f32 == NULL).  Same yolo outputs and uint8
+    tensors as the net that keeps them; the C-ABI entry refuses the NULL where no kernel has that form."""
+    cfg = os.path.join(cfg_dir, "yolov3-tiny_quant.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=1234)
+    xs = synth.synth_image_u8(3, 416, 416, seed=5, batch=2)
+    outs = {}
+    for keep in (True, False):
+        net = binding.Net(cfg, wts, batch=2, keep_head_float=keep)
+        net.prepare_fixed(1.0 / 255.0, 0)
+        net.push_input(xs)
+        net.forward(); net.sync()
+        outs[keep] = [net.pull(i) for i in range(net.n)]
+        heads = [i for i, inf in enumerate(net.info) if inf["type"] == binding.T_CONV and inf["quant_stop"]]
+        assert heads == [15, 22] and all(net.fuses_next(i) for i in heads)
+        net.close()
+    for i in range(len(outs[True])):
+        for k, v in outs[False][i].items():
+            if k != "int32":
+                assert np.array_equal(v, outs[True][i][k]), (i, k)
+    assert "f32" in outs[True][15] and "f32" not in outs[False][15] and "f32" in outs[False][16]
+    # a 3x3 head (row-image kernel) cannot drop the tensor: MI355_EINVAL, nothing launched
+    S = binding.shim()
+    S.mi355_conv_yolo_forward.argtypes = [C.POINTER(binding.ConvDesc), C.POINTER(binding.Tensor), C.c_void_p, C.POINTER(binding.Tensor), C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 256, (1, 64, 13, 13), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, 30, 64, 3)
+    xt = binding.DevTensor.from_nchw(x, 0); yt = binding.DevTensor(1, 13, 13, 30, 0)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, 64, 3, bias, mv, sv))
+    yo = binding.DevBuf(4 * 30 * 169)
+    d = binding.ConvDesc(30, 64, 3, 1, 1, binding.ACT["linear"], 0, 0, 0, 23, 0.05)
+    assert S.mi355_conv_yolo_forward(C.byref(d), xt.ref(), blob.ptr, yt.ref(), None, yo.ptr, 5, None) == -22

@@ -291,7 +291,9 @@ class Net:
     """The darknet host network (libdarknet_q.so): load_network -> prep -> forward_network_gpu."""
 
     def __init__(self, cfg, weights=None, batch=1, gpu=0, accum=ACC_EXACT, store=STORE_WRAP, dump_int32=False,
-                 use_graph=False, fuse_maxpool=True):
+                 use_graph=False, fuse_maxpool=True, keep_head_float=True):
+        """keep_head_float: the head convs fused with their yolo layers also store their own float tensors (the library's default is
+        not to: nothing but the yolo layer reads them; parity pulls want them)"""
         H = host()
         self.H = H
         self.h = H.load_network(cfg.encode(), weights.encode() if weights else None, 0)
@@ -301,6 +303,8 @@ class Net:
         H.dnq_net_set(self.h, b"dump_int32", int(dump_int32))
         H.dnq_net_set(self.h, b"use_graph", int(use_graph))
         H.dnq_net_set(self.h, b"fuse_maxpool", int(fuse_maxpool))
+        H.dnq_net_set(self.h, b"keep_head_float", int(keep_head_float))
+        self.keep_head_float = bool(keep_head_float)
         if batch != H.dnq_net_batch(self.h):
             H.set_batch_network(self.h, batch)
         self.n = H.dnq_net_n(self.h)
@@ -389,7 +393,7 @@ class Net:
             out["u8"] = _as(self.H.dnq_layer_u8(self.h, i), cnt, C.c_uint8).copy()
         if ty == T_CONV:
             out["int32"] = _as(self.H.dnq_layer_int32(self.h, i), cnt, C.c_int32).copy()
-        if ty == T_YOLO or self.info[i]["quant_stop"]:
+        if ty == T_YOLO or (self.info[i]["quant_stop"] and (self.keep_head_float or ty != T_CONV or not self.fuses_next(i))):
             out["f32"] = _as(self.H.dnq_layer_f32(self.h, i), cnt, C.c_float).copy()
         return out
 

@@ -149,7 +149,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
                         for (int ux = 0; ux < up; ++ux)
                             *reinterpret_cast<uint32_t *>(a.y + (size_t)(ocell + uy * rowc + ux) * a.out_cs + ch0) = packed;
                 }
-                if (a.y_f32) {  // quant_stop tail (ref :752-760) and, fused, the yolo layer's activations
+                if (a.y_f32 || a.yolo_out) {  // quant_stop tail (ref :752-760) and, fused, the yolo layer's activations (y_f32 may be
+                                              // null then: the head's own float tensor is an intermediate nobody reads)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int oc = ch0 + r;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
                             const int u8 = v[r][0] & 0xFF;
                             const float f = (float)(u8 - a.zp_act) * a.s_act;
                             const size_t ridx = ((size_t)b * a.n + oc) * hw + rem;
-                            a.y_f32[ridx] = f;
+                            if (a.y_f32) a.y_f32[ridx] = f;
                             if (a.yolo_out) {
                                 const int e = oc % a.yolo_per;
                                 a.yolo_out[ridx] = (e == 2 || e == 3) ? f : ldsYL[u8];

@@ -516,6 +516,8 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     if (rc == MI355_EINVAL && !ypool && y && a.ws && d->ksize == 3 && up == 1 && !acc_out && !y_f32 && !yolo_out &&
         (d->c == 16 || d->c == 32 || d->c == 64) && !(mi355_debug_flags_get() & 1024)) { rc = conv_small_pool_launch(a, st); g_last_kernel = 2; }
     if (rc == MI355_EINVAL && a.ws && d->ksize == 1 && !(mi355_debug_flags_get() & 8192)) { rc = conv1x1_ws_launch(a, st); g_last_kernel = 3; }  // 1x1 layers
+    // a fused yolo head WITHOUT the conv's own float tensor (y_f32 == NULL) exists in conv1x1.hip only: the caller passes the buffer otherwise
+    if (rc == MI355_EINVAL && yolo_out && !y_f32) return einval("conv_yolo_forward: this shape needs y_f32");
     if (rc == MI355_EINVAL && a.ws && d->ksize == 3 && !ypool && !(mi355_debug_flags_get() & 16384)) { rc = conv_ws3_launch(a, st); g_last_kernel = 4; }  // mid layers
     if (rc == MI355_EINVAL) { rc = conv_igemm_launch(a, st); g_last_kernel = 5; }
     if (rc == MI355_EINVAL && res) return einval("conv_shortcut_forward: no kernel fuses the residual add for this shape");
@@ -533,7 +535,7 @@ int mi355_conv_forward(const mi355_conv_desc *d, const mi355_tensor *x, const vo
 int mi355_conv_yolo_forward(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const mi355_tensor *y,
                             float *y_f32, float *yolo_out, int classes, void *stream)
 {
-    if (!d || !y_f32 || !yolo_out || classes < 0 || d->n % (classes + 5)) return einval("conv_yolo_forward: need y_f32, yolo_out and n % (classes + 5) == 0");
+    if (!d || !yolo_out || classes < 0 || d->n % (classes + 5)) return einval("conv_yolo_forward: need yolo_out and n % (classes + 5) == 0");
     if (d->accum_mode != MI355_ACC_EXACT || d->c % 16) return einval("conv_yolo_forward: exact mode, c % 16 == 0 only");
     return conv_forward_impl(d, x, blob, nullptr, nullptr, y, nullptr, nullptr, y_f32, stream, yolo_out, classes);
 }

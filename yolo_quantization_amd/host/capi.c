@@ -20,6 +20,7 @@ int dnq_net_set(network *net, const char *key, int val)
     else if (!strcmp(key, "use_graph")) net->use_graph = val;
     else if (!strcmp(key, "gpu_index")) net->gpu_index = val;
     else if (!strcmp(key, "verbose")) net->verbose = val;
+    else if (!strcmp(key, "keep_head_float")) net->keep_head_float = val;
     else if (!strcmp(key, "input_direct")) net->input_direct = val; /* 0: always convert the input to 4-byte cells (A/B runs) */
     else return -1;
     return 0;

@@ -77,8 +77,11 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
         self->fuse_next_shortcut = 0;
     }
     if (net.fused_yolo_out) { /* quant_stop head + the yolo layer after it (ref: src/yolo_layer.c:132-146) in one kernel */
-        const int rc = mi355_conv_yolo_forward(&d, net.cur_t, l.blob_gpu, &l.out_t, l.output_gpu, net.fused_yolo_out,
-                                               net.fused_yolo_classes, net.stream);
+        int rc = MI355_EINVAL;
+        if (!net.keep_head_float && !net.dump_int32) /* the head's own float tensor is not stored; MI355_EINVAL: this kernel needs it */
+            rc = mi355_conv_yolo_forward(&d, net.cur_t, l.blob_gpu, &l.out_t, NULL, net.fused_yolo_out, net.fused_yolo_classes, net.stream);
+        if (rc == MI355_EINVAL)
+            rc = mi355_conv_yolo_forward(&d, net.cur_t, l.blob_gpu, &l.out_t, l.output_gpu, net.fused_yolo_out, net.fused_yolo_classes, net.stream);
         if (rc != MI355_EINVAL) { check_mi355(rc, "mi355_conv_yolo_forward"); return; }
         self->fuse_next_yolo = 0;
     }
