@@ -225,7 +225,8 @@ int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
     a.lds_param_off = (int)lds;
     const int n32 = (a.n + 31) & ~31;
     lds += (size_t)n32 * 16 + 1024 + (size_t)a.sm_ncell * 16 * 12;  // parameters, logistic table, the three per-pixel tables
-    if (lds > 96 * 1024) return MI355_EINVAL;  // two workgroups per CU when a layer needs more than one round
+    // two workgroups per CU when a layer needs more than one round; a single round may take the whole LDS
+    if (lds > (rounds == 1 && ntiles <= 256 ? 160 : 96) * 1024) return MI355_EINVAL;
     const int nq = n32 / 32;
     const int sets = 8 / nq > 0 ? 8 / nq : 1;  // at most 8 waves per workgroup
     const int threads = sets * nq * 64;
