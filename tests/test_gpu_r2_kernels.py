@@ -281,3 +281,31 @@ def test_heads_without_their_own_float_tensor(cfg_dir, tmp_path):
     yo = binding.DevBuf(4 * 30 * 169)
     d = binding.ConvDesc(30, 64, 3, 1, 1, binding.ACT["linear"], 0, 0, 0, 23, 0.05)
     assert S.mi355_conv_yolo_forward(C.byref(d), xt.ref(), blob.ptr, yt.ref(), None, yo.ptr, 5, None) == -22
+
+
+@pytest.mark.parametrize("B,c,n,H,W,act", [(32, 1024, 512, 19, 19, "leaky"),   # YOLOv3-608's necks: two filter tiles of 256
+                                           (16, 256, 512, 13, 13, "relu6"),
+                                           (8, 512, 768, 10, 10, "linear"),    # three filter tiles
+                                           (4, 64, 1024, 9, 7, "leaky")])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+def test_conv1x1_ws_with_more_than_256_filters(B, c, n, H, W, act, store):
+    """conv1x1.hip with the filters split over workgroups (tiles of 256): the same bytes as the row-image kernel on the same call
+    (debug switch 8192 routes around conv1x1.hip) and as the oracle on image 0."""
+    rng = np.random.default_rng(B + c + n + H)
+    S = binding.shim()
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 1)
+    zp_w[0], zp_w[n - 1] = 0, 255
+    xt = binding.DevTensor.from_nchw(x, 23)
+    args = (xt, wq, zp_w, 1, bias, mv, sv, 23, 31, 0.05, binding.ACT[act], store, binding.ACC_EXACT)
+    new = binding.conv_forward(*args, want_acc=False)
+    assert S.mi355_last_conv_kernel() == 3
+    S.mi355_debug_flags(8192)
+    try:
+        old = binding.conv_forward(*args, want_acc=False)
+        assert S.mi355_last_conv_kernel() == 5
+    finally:
+        S.mi355_debug_flags(0)
+    assert np.array_equal(new["u8"], old["u8"])
+    want = oracle.requant(oracle.conv_acc(x[0], wq, zp_w, 1, 1, 0, 23), bias, mv, sv, 31, oracle.ACT[act], store)
+    assert np.array_equal(new["u8"][0].reshape(n, -1), want.reshape(n, -1))

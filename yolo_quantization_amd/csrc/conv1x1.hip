@@ -22,7 +22,12 @@ template <int KST, int ACT, bool SAT>
 __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N32 = (a.n + 31) & ~31;
+    // filter tiles: layers with more than 256 filters (YOLOv3's 1024 -> 512 necks) split them over a.mtiles workgroups per pixel
+    // tile, 256 each (workgroup = tile * mtiles + filter tile: the filter tiles of a pixel tile run next to each other and share
+    // its input lines in L2).  f0 = first filter of this workgroup, N32 = its filter count rounded up to a quad
+    const int mtl = a.mtiles > 1 ? a.mtiles : 1;
+    const int f0 = (int)(blockIdx.x % mtl) * 256;
+    const int N32 = min(256, ((a.n + 31) & ~31) - f0);
     const int chunks = a.sm_ncell;               // 16-pixel chunks of the tile image (2 per group)
     const int qb = chunks * 1024;                // bytes of one 64-channel chunk plane
     double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N32] folded multiplier
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
     const int wq = wave % nq, wset = wave / nq, nset = nwave / nq;
     const int W1 = a.W + 1, hw = a.H * a.W;
     const int TP = a.sm_tp, G = (TP + 31) >> 5;
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x / mtl;
     const int n0 = tile * TP, n1 = min(n0 + TP, a.total_n);  // this tile's pixels [n0, n1)
     const bool pow2 = a.hdr->pow2 == 1;
 
@@ -77,15 +82,15 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
     }
     // ---- parameters and this wave's A fragments (overlap the DMA)
     for (int i = tid; i < N32; i += NT) {
-        ldsMP[i] = a.mprime[i];
-        ldsDZ[i] = a.dzp[i];
-        ldsCB[i] = a.cwb[i];
+        ldsMP[i] = a.mprime[f0 + i];
+        ldsDZ[i] = a.dzp[f0 + i];
+        ldsCB[i] = a.cwb[f0 + i];
     }
     if (a.yolo_out)
         for (int i = tid; i < 256; i += NT) ldsYL[i] = yolo_entry_act((float)(i - a.zp_act) * a.s_act, 0);
     v4i wf[KST];
 #pragma unroll
-    for (int s = 0; s < KST; ++s) wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(wq * KST + s) * 64 + lane) * 16);
+    for (int s = 0; s < KST; ++s) wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(((f0 >> 5) + wq) * KST + s) * 64 + lane) * 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -136,24 +141,24 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
             } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    v[r][0] = (int32_t)requant_u8(accb[r][0], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
+                    v[r][0] = (int32_t)requant_u8(accb[r][0], 0, a.mval[f0 + ch0 + r], a.sval[f0 + ch0 + r], a.zp_act, ACT,
                                                   SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
             }
-            if (valid && ch0 < a.out_w) {
+            if (valid && f0 + ch0 < a.out_w) {
                 const uint32_t packed = pack4_biased(v[0][0], v[1][0], v[2][0], v[3][0]);
                 if (up == 1) {
-                    *reinterpret_cast<uint32_t *>(a.y + (size_t)ocell * a.out_cs + ch0) = packed;
+                    *reinterpret_cast<uint32_t *>(a.y + (size_t)ocell * a.out_cs + f0 + ch0) = packed;
                 } else {
                     const int rowc = up * a.W + 1;
                     for (int uy = 0; uy < up; ++uy)
                         for (int ux = 0; ux < up; ++ux)
-                            *reinterpret_cast<uint32_t *>(a.y + (size_t)(ocell + uy * rowc + ux) * a.out_cs + ch0) = packed;
+                            *reinterpret_cast<uint32_t *>(a.y + (size_t)(ocell + uy * rowc + ux) * a.out_cs + f0 + ch0) = packed;
                 }
                 if (a.y_f32 || a.yolo_out) {  // quant_stop tail (ref :752-760) and, fused, the yolo layer's activations (y_f32 may be
                                               // null then: the head's own float tensor is an intermediate nobody reads)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int oc = ch0 + r;
+                        const int oc = f0 + ch0 + r;
                         if (oc < a.n) {
                             const int u8 = v[r][0] & 0xFF;
                             const float f = (float)(u8 - a.zp_act) * a.s_act;
@@ -199,7 +204,7 @@ static int c1_launch_act(ConvArgs &a, hipStream_t st, int grid, int threads, siz
 // shapes whose blob carries the weights-stationary plane (off_ws) for this kernel
 bool conv1x1_ws_eligible(int n, int c, int ksize)
 {
-    return ksize == 1 && (c == 64 || c == 128 || c == 256 || c == 512 || c == 1024) && n >= 1 && n <= 256;
+    return ksize == 1 && (c == 64 || c == 128 || c == 256 || c == 512 || c == 1024) && n >= 1 && (n <= 256 || (n <= 1024 && n % 256 == 0));
 }
 
 // returns MI355_EINVAL when the shape is outside this kernel's domain (the caller falls back to conv_rows / conv_igemm)
@@ -214,8 +219,11 @@ int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
     // few input channels: a pixel costs little LDS, and layers with millions of pixels (64 -> 32 at 304 x 304) are bound
     // by the per-workgroup latencies unless a workgroup streams a long tile
     const int gmax = c <= 64 ? 32 : (c == 128 ? 16 : P1_GMAX);
-    const long rounds = (total + 256L * gmax * 32 - 1) / (256L * gmax * 32);
-    int tp = (int)((total + 256 * rounds - 1) / (256 * rounds));
+    const int n32 = (a.n + 31) & ~31;
+    const int mtiles = n32 > 256 ? (n32 + 255) / 256 : 1;  // filter tiles of 256 (conv1x1_ws_eligible: n % 256 == 0 then)
+    const int want = 256 / mtiles;                         // pixel tiles per round of the chip
+    const long rounds = (total + (long)want * gmax * 32 - 1) / ((long)want * gmax * 32);
+    int tp = (int)((total + want * rounds - 1) / (want * rounds));
     if (tp < 16) tp = 16;
     const int ntiles = (int)((total + tp - 1) / tp);
     const int G = (tp + 31) / 32;
@@ -223,18 +231,20 @@ int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
     a.sm_ncell = 2 * G;  // 16-pixel chunks
     size_t lds = (size_t)(c / 64) * a.sm_ncell * 1024;
     a.lds_param_off = (int)lds;
-    const int n32 = (a.n + 31) & ~31;
-    lds += (size_t)n32 * 16 + 1024 + (size_t)a.sm_ncell * 16 * 12;  // parameters, logistic table, the three per-pixel tables
+    const int nfw = n32 < 256 ? n32 : 256;  // filters of a workgroup
+    lds += (size_t)nfw * 16 + 1024 + (size_t)a.sm_ncell * 16 * 12;  // parameters, logistic table, the three per-pixel tables
     // two workgroups per CU when a layer needs more than one round; a single round may take the whole LDS
-    if (lds > (rounds == 1 && ntiles <= 256 ? 160 : 96) * 1024) return MI355_EINVAL;
-    const int nq = n32 / 32;
+    if (lds > (rounds == 1 && (long)ntiles * mtiles <= 256 ? 160 : 96) * 1024) return MI355_EINVAL;
+    if (mtiles > 1 && (a.y_f32 || a.yolo_out || a.up != 1)) return MI355_EINVAL;  // (heads / fused upsample: single filter tile only)
+    a.mtiles = mtiles;
+    const int nq = nfw / 32;
     const int sets = 8 / nq > 0 ? 8 / nq : 1;  // at most 8 waves per workgroup
     const int threads = sets * nq * 64;
     switch (c) {
-    case 64: return c1_launch_act<2>(a, st, ntiles, threads, lds);
-    case 128: return c1_launch_act<4>(a, st, ntiles, threads, lds);
-    case 256: return c1_launch_act<8>(a, st, ntiles, threads, lds);
-    case 512: return c1_launch_act<16>(a, st, ntiles, threads, lds);
-    default: return c1_launch_act<32>(a, st, ntiles, threads, lds);
+    case 64: return c1_launch_act<2>(a, st, ntiles * mtiles, threads, lds);
+    case 128: return c1_launch_act<4>(a, st, ntiles * mtiles, threads, lds);
+    case 256: return c1_launch_act<8>(a, st, ntiles * mtiles, threads, lds);
+    case 512: return c1_launch_act<16>(a, st, ntiles * mtiles, threads, lds);
+    default: return c1_launch_act<32>(a, st, ntiles * mtiles, threads, lds);
     }
 }
