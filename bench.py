@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--cpu-omp", action="store_true", help="also time the reference's OpenMP build on all host cores (extra JSON key)")
     ap.add_argument("--no-ref-f32", action="store_true", help="skip the extra leg that times the bit-faithful MI355_ACC_REF_F32 mode")
     ap.add_argument("--ref-f32-steps", type=int, default=2)
+    ap.add_argument("--selfcheck-passes", type=int, default=48,
+                    help="determinism self-check before the warmup steps: that many passes over the input, yolo-output checksums compared (0: off)")
     return ap.parse_args()
 
 
@@ -201,6 +203,13 @@ def main():
         torch.cuda.synchronize()
         net.sync()
 
+    # ---- determinism self-check (a race detector for kernels scheduled by hand: counted waits, registers reloaded in place): N passes
+    # over the resident input, a device-side checksum of the yolo outputs after each; compared after the timed region, a mismatch
+    # fails the run.  Nothing is synchronised here, so the passes also leave the device at its steady clocks when the warmup steps
+    # start: after any idle phase of >= 20 ms (the host-side set-up above is one) the first ~40 steps of the net run up to 8 %
+    # slower (tools/dbg/step_curve.py) -- without this a `--warmup 5 --steps 20` region measures mostly that.
+    if args.selfcheck_passes > 0 and not args.graph:
+        net.selfcheck(args.selfcheck_passes)
     for _ in range(args.warmup):
         net.forward()
     barrier()
@@ -228,6 +237,12 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
+    selfcheck = None
+    if args.selfcheck_passes > 0 and not args.graph:
+        bad = net.selfcheck_result()
+        selfcheck = {"passes": args.selfcheck_passes, "passes_differing_from_the_first": bad}
+        if bad:
+            raise SystemExit(f"bench.py: determinism self-check FAILED: {bad} of {args.selfcheck_passes} passes over the same input gave other yolo outputs")
 
     # ---- roofline of the dominant kernel (the MFMA implicit-GEMM conv), from HIP events on the launch stream
     roof = None
@@ -336,7 +351,7 @@ def main():
                           "global_batch": world * B, "parallelism": f"image-sharded x{world}, RCCL weight broadcast once",
                           "launch": "hipGraph replay" if args.graph else f"eager; per-layer HIP events on every {prof_stride}th step of the timed region",
                           "weight_broadcast_ms": round(bcast_ms, 3)},
-               "roofline": roof, "cpu_baseline": cpu, "accum_ref_f32_mode": ref_f32}
+               "roofline": roof, "cpu_baseline": cpu, "accum_ref_f32_mode": ref_f32, "selfcheck": selfcheck}
         if cpu_omp:
             out["cpu_baseline_allcores"] = cpu_omp
         if layers:

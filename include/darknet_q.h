@@ -148,6 +148,8 @@ struct network {
     int prepared;
     int has_host_weights; /* load_weights ran: raw weights_uint8 / biases / scales of every layer are on the host */
     int has_l0_weights;   /* imported from a packed exchange: blobs only, plus layer 0's raw record (re-prep on a new input scale) */
+    uint64_t *selfcheck_gpu; /* [passes] checksums of the pending self-check */
+    int selfcheck_passes;
     void *graph; /* hipGraph of the layer loop, built lazily when use_graph */
     int use_graph;
     /* per-layer HIP-event timing on net->stream (replaces the commented what_time_is_it_now() probes of
@@ -222,6 +224,12 @@ char **get_labels(char *filename, int *count);
  * launches only), then read the per-layer sums in ms: out[0] = input layout conversion, out[1+i] = layer i. */
 void network_profile_begin(network *net, int max_steps);
 void network_profile_set_stride(network *net, int stride);
+/* Determinism self-check (a race detector for the hand-scheduled kernels: counted waits, in-place register reuse): `passes` forward
+ * passes over the input that is on the device, a device-side checksum of every yolo layer's output after each; nothing is synchronised.
+ * network_selfcheck_result() waits, reads the checksums back and returns the number of passes that differ from the first (0 = all
+ * identical, -1 = no self-check pending). */
+void network_selfcheck(network *net, int passes);
+int network_selfcheck_result(network *net);
 void network_profile_set_phase(network *net, int phase);
 int network_profile_read(network *net, float *ms_sum /* [n+1] */);
 

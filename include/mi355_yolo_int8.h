@@ -228,6 +228,9 @@ int mi355_letterbox_forward(const float *im_f32, int imw, int imh, int c, float 
  * (double)zero_point), 0, 255), the reference's evaluation order (:160-165). */
 int mi355_image_minmax(const float *x_f32, long count, float *minmax, void *stream);
 int mi355_image_quantize(const float *x_f32, long count, float scale, int zero_point, uint8_t *out_u8, void *stream);
+/* *sum_dev += an order-independent 64-bit checksum of `dwords` 32-bit words at buf (device pointers; zero *sum_dev first).  The
+ * host's determinism self-check compares it between passes over the same input (network_selfcheck, darknet_q.h). */
+int mi355_checksum_u32(const void *buf, long dwords, uint64_t *sum_dev, void *stream);
 /* yolo head activations (ref: src/yolo_layer.c:132-146) on the float head tensor [B][n*(classes+5)][H*W] */
 int mi355_yolo_forward(const float *in, float *out, int B, int n, int classes, int H, int W, void *stream);
 

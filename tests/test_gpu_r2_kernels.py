@@ -309,3 +309,29 @@ def test_conv1x1_ws_with_more_than_256_filters(B, c, n, H, W, act, store):
     assert np.array_equal(new["u8"], old["u8"])
     want = oracle.requant(oracle.conv_acc(x[0], wq, zp_w, 1, 1, 0, 23), bias, mv, sv, 31, oracle.ACT[act], store)
     assert np.array_equal(new["u8"][0].reshape(n, -1), want.reshape(n, -1))
+
+
+def test_determinism_selfcheck(cfg_dir, tmp_path):
+    """network_selfcheck: repeated passes over the same input give the same device-side checksums of the yolo outputs (the bench runs
+    it before its warmup steps); the checksum itself separates different outputs."""
+    cfg = os.path.join(cfg_dir, "yolov3-tiny_quant.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfg, wts, seed=1234)
+    net = binding.Net(cfg, wts, batch=4, keep_head_float=False)
+    net.prepare_fixed(1.0 / 255.0, 0)
+    net.push_input(synth.synth_image_u8(3, 416, 416, seed=5, batch=4))
+    assert net.selfcheck_result() == -1
+    net.selfcheck(6)
+    assert net.selfcheck_result() == 0 and net.selfcheck_result() == -1
+    net.close()
+    S = binding.shim()
+    S.mi355_checksum_u32.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+    a = np.arange(5000, dtype=np.uint32); b = a.copy(); b[4321] ^= 1
+    sums = []
+    for v in (a, a[::-1].copy(), b):
+        dv = binding.DevBuf.from_numpy(v); ds = binding.DevBuf.from_numpy(np.zeros(1, np.uint64))
+        binding.check(S.mi355_checksum_u32(dv.ptr, v.size, ds.ptr, None), "checksum")
+        binding.check(S.mi355_stream_sync(None), "sync")
+        sums.append(int(ds.to_numpy(np.uint64, 1)[0]))
+    want = int((a.astype(object) * (2 * np.arange(5000).astype(object) + 1)).sum() % (1 << 64))
+    assert sums[0] == want and sums[1] != sums[0] and sums[2] != sums[0]

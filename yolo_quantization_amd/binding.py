@@ -248,6 +248,8 @@ def host():
         L.network_yolo_detections_gpu.argtypes = [vp, ci, ci, ci, C.c_float, ci, vp, ci, vp]
         L.network_profile_set_stride.argtypes = [vp, ci]
         L.network_profile_set_phase.argtypes = [vp, ci]
+        L.network_selfcheck.argtypes = [vp, ci]
+        L.network_selfcheck_result.argtypes = [vp]
         L.network_packed_size.restype = C.c_size_t
         L.network_packed_size.argtypes = [vp]
         L.network_export_packed.argtypes = [vp, vp]
@@ -425,6 +427,14 @@ class Net:
         self.H.network_yolo_detections_gpu(self.h, i, imw, imh, C.c_float(thresh), int(relative), recs.ctypes.data, max_recs,
                                            counts.ctypes.data)
         return counts, recs
+
+    def selfcheck(self, passes):
+        """queue `passes` forward passes over the resident input with a device-side checksum of the yolo outputs after each
+        (nothing is synchronised); selfcheck_result() -> number of passes that differ from the first"""
+        self.H.network_selfcheck(self.h, passes)
+
+    def selfcheck_result(self):
+        return int(self.H.network_selfcheck_result(self.h))
 
     def profile_begin(self, max_steps, stride=1, phase=0):
         """record per-layer events on the forward passes whose index (from now) % stride == phase, at most max_steps of them"""

@@ -426,6 +426,25 @@ int image_quantize_launch(const float *x, long count, float scale, int zp, uint8
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
 
+// Order-independent 64-bit checksum of a device buffer (dwords; sum of value * (odd multiplier of the index)): two runs of the
+// same kernels on the same input must give the same number -- the determinism self-check of the host (network_selfcheck).
+__global__ __launch_bounds__(256) void checksum_u32_kernel(const uint32_t *p, long n, unsigned long long *out)
+{
+    unsigned long long s = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        s += (unsigned long long)p[i] * (unsigned long long)(2 * i + 1);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+int checksum_u32_launch(const uint32_t *p, long n, unsigned long long *out, hipStream_t st)
+{
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(checksum_u32_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, p, n, out);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
+
 int yolo_logistic_launch(const float *in, float *out, int B, int n, int classes, int hw, hipStream_t st)
 {
     const long total = (long)B * n * (classes + 5) * hw;

@@ -141,3 +141,4 @@ int letterbox_launch(const float *im, int imw, int imh, int c, float *out, int w
 int image_minmax_launch(const float *x, long count, uint32_t *mm, hipStream_t st);
 int image_quantize_launch(const float *x, long count, float scale, int zp, uint8_t *out, hipStream_t st);
 int yolo_logistic_launch(const float *in, float *out, int B, int n, int classes, int hw, hipStream_t st);
+int checksum_u32_launch(const uint32_t *p, long n, unsigned long long *out, hipStream_t st);

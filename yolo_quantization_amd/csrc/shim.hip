@@ -667,6 +667,12 @@ int mi355_image_quantize(const float *x_f32, long count, float scale, int zero_p
     return image_quantize_launch(x_f32, count, scale, zero_point, out_u8, (hipStream_t)stream);
 }
 
+int mi355_checksum_u32(const void *buf, long dwords, uint64_t *sum_dev, void *stream)
+{
+    if (!buf || !sum_dev || dwords < 0) return einval("checksum: null");
+    return checksum_u32_launch((const uint32_t *)buf, dwords, (unsigned long long *)sum_dev, (hipStream_t)stream);
+}
+
 int mi355_yolo_forward(const float *in, float *out, int B, int n, int classes, int H, int W, void *stream)
 {
     if (!in || !out) return einval("yolo: null");

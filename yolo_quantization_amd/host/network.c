@@ -607,6 +607,42 @@ void forward_network_gpu(network *netp)
 
 void forward_network(network *net) { forward_network_gpu(net); }
 
+void network_selfcheck(network *net, int passes)
+{
+    if (passes < 2) passes = 2;
+    if (net->selfcheck_gpu) mi355_free(net->selfcheck_gpu);
+    check_mi355(mi355_alloc((void **)&net->selfcheck_gpu, (size_t)passes * sizeof(uint64_t)), "alloc selfcheck");
+    uint64_t *zeros = calloc((size_t)passes, sizeof(uint64_t));
+    check_mi355(mi355_h2d(net->selfcheck_gpu, zeros, (size_t)passes * sizeof(uint64_t), net->stream), "zero selfcheck");
+    check_mi355(mi355_stream_sync(net->stream), "sync");
+    free(zeros);
+    net->selfcheck_passes = passes;
+    for (int p = 0; p < passes; ++p) {
+        forward_network_gpu(net);
+        for (int i = 0; i < net->n; ++i) {
+            const layer *l = &net->layers[i];
+            if (l->type != YOLO || !l->output_gpu) continue;
+            check_mi355(mi355_checksum_u32(l->output_gpu, (long)net->batch * l->outputs, net->selfcheck_gpu + p, net->stream), "checksum");
+        }
+    }
+}
+
+int network_selfcheck_result(network *net)
+{
+    if (!net->selfcheck_gpu || net->selfcheck_passes < 1) return -1;
+    const int passes = net->selfcheck_passes;
+    uint64_t *sums = calloc((size_t)passes, sizeof(uint64_t));
+    check_mi355(mi355_d2h(sums, net->selfcheck_gpu, (size_t)passes * sizeof(uint64_t), net->stream), "pull selfcheck");
+    check_mi355(mi355_stream_sync(net->stream), "sync");
+    int bad = 0;
+    for (int p = 1; p < passes; ++p) bad += sums[p] != sums[0];
+    free(sums);
+    mi355_free(net->selfcheck_gpu);
+    net->selfcheck_gpu = NULL;
+    net->selfcheck_passes = 0;
+    return bad;
+}
+
 float *network_predict(network *net, float *input)
 {
     /* ref src/network.c:570-581; the integer path ignores `input` after the prep quantised it (examples/detector.c
@@ -895,6 +931,7 @@ void free_network(network *net)
     if (net->input_t.data) mi355_free(net->input_t.data);
     if (net->input_gpu) mi355_free(net->input_gpu);
     if (net->quant_mm_gpu) mi355_free(net->quant_mm_gpu);
+    if (net->selfcheck_gpu) mi355_free(net->selfcheck_gpu);
     if (net->stream) mi355_stream_destroy(net->stream);
     free(net->layers); free(net->input); free(net->input_uint8); free(net->seen);
     free(net);
