@@ -8,6 +8,14 @@ A step = one pass of the hot path (the plain-C darknet host's forward_network_gp
 layer.forward_gpu launches) over one batch of 64 synthetic uint8 416x416 images that are already resident in HBM in
 the reference's [B][C][H][W] layout.  Images shard embarrassingly over the ranks (weak scaling, 64 per GPU); the only
 collective is a one-time RCCL broadcast of the packed quantized weights at start-up.  Rank 0 prints ONE JSON line.
+
+Batches in flight (--inflight, default 3): the K timed steps are dealt round-robin to that many instances of the prepared
+network on the same GPU (network_replica: own activation tensors, own input batch, own HIP stream; ONE copy of the packed
+weights).  Every step is still one complete forward pass over its own 64 images and all K finish inside the timed region; what
+changes is that the device may run kernels of neighbouring steps side by side (one batch's launch gaps, pipeline fills and
+VALU-bound first layers under another batch's MFMA-bound layers).  Per-kernel figures (roofline, --layers) are taken in a serial
+leg right after the timed region (one batch at a time, the kernel alone on the device) and the serial throughput is reported
+next to `value` ("serial"); --inflight 1 makes the timed region itself serial, as in rounds 1 and 2.
 """
 import argparse
 import ctypes
@@ -37,6 +45,10 @@ def parse_args():
     ap.add_argument("--cpu-omp", action="store_true", help="also time the reference's OpenMP build on all host cores (extra JSON key)")
     ap.add_argument("--no-ref-f32", action="store_true", help="skip the extra leg that times the bit-faithful MI355_ACC_REF_F32 mode")
     ap.add_argument("--ref-f32-steps", type=int, default=2)
+    ap.add_argument("--serial-steps", type=int, default=64, help="steps of the serial leg that follows the timed region when --inflight > 1")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BENCH_INFLIGHT", "3")),
+                    help="batches in flight per GPU: that many network instances (own activations, own HIP stream, same packed weights); "
+                         "step i runs on instance i %% inflight, so kernels of consecutive steps overlap on the device")
     ap.add_argument("--selfcheck-passes", type=int, default=48,
                     help="determinism self-check before the warmup steps: that many passes over the input, yolo-output checksums compared (0: off)")
     return ap.parse_args()
@@ -197,11 +209,20 @@ def main():
     net.push_input(x)
     net.sync()
 
+    # ---- further batches in flight: instances built from the same packed bytes, each with its own batch of images
+    nets = [net]
+    for k in range(1, max(1, args.inflight)):
+        nk = net.replica()
+        nk.push_input(synth.synth_image_u8(in_c, in_h, in_w, seed=1000 + rank + 7919 * k, batch=B))
+        nk.sync()
+        nets.append(nk)
+
     def barrier():
         if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        net.sync()
+        for nk in nets:
+            nk.sync()
 
     # ---- determinism self-check (a race detector for kernels scheduled by hand: counted waits, registers reloaded in place): N passes
     # over the resident input, a device-side checksum of the yolo outputs after each; compared after the timed region, a mismatch
@@ -209,9 +230,10 @@ def main():
     # start: after any idle phase of >= 20 ms (the host-side set-up above is one) the first ~40 steps of the net run up to 8 %
     # slower (tools/dbg/step_curve.py) -- without this a `--warmup 5 --steps 20` region measures mostly that.
     if args.selfcheck_passes > 0 and not args.graph:
-        net.selfcheck(args.selfcheck_passes)
-    for _ in range(args.warmup):
-        net.forward()
+        for nk in nets:  # every instance checks itself; with several in flight their passes overlap on the device like the timed steps
+            nk.selfcheck(args.selfcheck_passes)
+    for i in range(args.warmup):
+        nets[i % len(nets)].forward()
     barrier()
     # per-layer HIP events (launch stream) are recorded on every PROF_STRIDE-th step of the timed region.  An event costs
     # ~3.9 us of stream time: ~100 us for the 26 of a profiled step.  Measured in one box (400 steps): 0.377 ms / step with every
@@ -221,14 +243,21 @@ def main():
     # to 8 % slower (tools/dbg/step_curve.py: 0.400 0.388 0.376 0.370 0.368 .. ms per step in groups of five; --warmup 5
     # --steps 20 gives 0.38, --warmup 50 0.361, --warmup 200 0.355 in the same box).  Nothing is done about that here.
     prof_stride = max(1, int(os.environ.get("BENCH_PROF_STRIDE", "32")))
-    # ... counted back from the LAST step of the timed region (the first ones run on a device that is still ramping up)
-    prof_phase = (args.steps - 1) % prof_stride
-    prof_steps = 0 if args.graph else min((args.steps - 1 - prof_phase) // prof_stride + 1, 64)
-    net.profile_begin(prof_steps, prof_stride, prof_phase)
+    ninfl = len(nets)
+
+    def arm_events(nsteps_of_net0):
+        """per-layer events on every prof_stride-th forward of nets[0], counted back from its LAST forward of the coming region (the
+        first ones run on a device that is still ramping up); returns the number of profiled steps"""
+        phase = (nsteps_of_net0 - 1) % prof_stride
+        n = 0 if (args.graph or nsteps_of_net0 < 1) else min((nsteps_of_net0 - 1 - phase) // prof_stride + 1, 64)
+        net.profile_begin(n, prof_stride, phase)
+        return n
+
+    prof_steps = arm_events((args.steps + ninfl - 1) // ninfl)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        net.forward()
+    for i in range(args.steps):
+        nets[i % ninfl].forward()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -237,18 +266,36 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
+    flight_prof = net.profile_read() if (prof_steps and rank == 0) else None
+
+    # ---- serial leg (only with several batches in flight): the same steps on ONE instance, nothing else on the device.  A kernel that
+    # shares the CUs with another batch's kernels runs longer than alone, so per-kernel durations -- the roofline, the per-layer
+    # table, and what rocprofv3's kernel trace of `--inflight 1` shows -- are taken here; never part of `value`.
+    serial = None
+    ser_dt = dt
+    ser_steps = args.steps
+    if ninfl > 1:
+        ser_steps = max(args.serial_steps, 2)
+        prof_steps = arm_events(ser_steps)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(ser_steps):
+            net.forward()
+        barrier()
+        ser_dt = time.perf_counter() - t0
+        serial = {"ms_per_step": round(ser_dt / ser_steps * 1e3, 4), "value": round(B * ser_steps / ser_dt, 1), "steps": ser_steps,
+                  "note": "one batch at a time on one stream (per GPU), run right after the timed region; per-kernel figures (roofline, --layers) come from here"}
+
     selfcheck = None
     if args.selfcheck_passes > 0 and not args.graph:
-        bad = net.selfcheck_result()
-        selfcheck = {"passes": args.selfcheck_passes, "passes_differing_from_the_first": bad}
+        bad = sum(nk.selfcheck_result() for nk in nets)
+        selfcheck = {"passes": args.selfcheck_passes, "instances": ninfl, "passes_differing_from_the_first": bad}
         if bad:
-            raise SystemExit(f"bench.py: determinism self-check FAILED: {bad} of {args.selfcheck_passes} passes over the same input gave other yolo outputs")
+            raise SystemExit(f"bench.py: determinism self-check FAILED: {bad} of {ninfl} x {args.selfcheck_passes} passes over the same input gave other yolo outputs")
 
-    # ---- roofline of the dominant kernel (the MFMA implicit-GEMM conv), from HIP events on the launch stream
-    roof = None
-    layers = []
-    if prof_steps and rank == 0:
-        nprof, ms = net.profile_read()
+    def layer_table(nprof, ms, region_dt, region_steps):
+        """per-layer ms from the event intervals of `nprof` profiled steps (nets[0]); region_dt / region_steps calibrate the cost of an
+        event when the region ran this instance alone (None: several batches were in flight, only the empty-interval cost is known)"""
         # An event pair with no launch in between (the fused / elided layers: maxpools after fused convs, elided routes, the
         # yolo layers written by their head conv) measures what recording an event costs on this stream; that cost is
         # taken out of every layer's interval (rocprofv3's kernel durations in profiles/ are the cross-check).
@@ -260,33 +307,46 @@ def main():
         # empty-interval cost from every interval under-reports the layers (their sum would fall short of a step).  The
         # steps without events give the truth for the sum: T_unprofiled = (dt - nprof * T_profiled) / (steps - nprof),
         # and the per-interval cost that makes the profiled steps' intervals add up to it is what gets subtracted.
-        if args.steps > nprof > 0:
+        if region_dt is not None and region_steps > nprof > 0:
             t_prof = float(sum(ms)) / nprof                       # ms of one profiled step, events included
-            t_unprof = (dt * 1e3 - nprof * t_prof) / (args.steps - nprof)
+            t_unprof = (region_dt * 1e3 - nprof * t_prof) / (region_steps - nprof)
             ev_cost = min(ev_cost, max((t_prof - t_unprof) / len(ms), 0.0))
-        def on_rows_kernel(i, inf):
-            """conv_rows16_i8_kernel / conv_rows_i8_kernel launches: 64-byte channel chunks, served by the implicit-GEMM family (the host records
-            which kernel family took each conv of the last step: conv_small / conv1x1 / conv_ws3 take the others)."""
-            return inf["type"] == binding.T_CONV and inf["c"] % 64 == 0 and net.conv_kernel(i) == 5
-        mf_ops = mf_ms = all_ops = all_ms = 0.0
+        rows = []
         for i, inf in enumerate(net.info):
             t_ms = max(float(ms[i + 1]) / nprof - ev_cost, 1e-6)
             row = {"i": i, "type": inf["type"], "ms": round(t_ms, 5)}
             if inf["type"] == binding.T_CONV:
                 ops, byt = conv_layer_work(inf, B)
                 row.update(tops=round(ops / (t_ms * 1e-3) / 1e12, 2), gbs=round(byt / (t_ms * 1e-3) / 1e9, 1),
-                           k=inf["size"], c=inf["c"], n=inf["n"], hw=inf["out_h"])
-                all_ops += ops
-                if on_rows_kernel(i, inf):
-                    mf_ops += ops
-                    mf_ms += t_ms
-            all_ms += t_ms
-            layers.append(row)
-        # the north-star target is quoted on the 3x3 stride-1 layers: their aggregate MFMA rate, whichever kernel serves them
-        s33_ops = sum(conv_layer_work(inf, B)[0] for i, inf in enumerate(net.info)
-                      if inf["type"] == binding.T_CONV and inf["size"] == 3 and inf["stride"] == 1 and inf["c"] > 3)
-        s33_ms = sum(layers[i]["ms"] for i, inf in enumerate(net.info)
-                     if inf["type"] == binding.T_CONV and inf["size"] == 3 and inf["stride"] == 1 and inf["c"] > 3)
+                           k=inf["size"], c=inf["c"], n=inf["n"], hw=inf["out_h"], ops=ops)
+            rows.append(row)
+        return rows, ev_cost, max(float(ms[0]) / nprof - ev_cost, 0.0)
+
+    def on_rows_kernel(i, inf):
+        """conv_rows16_i8_kernel / conv_rows_i8_kernel launches: 64-byte channel chunks, served by the implicit-GEMM family (the host records
+        which kernel family took each conv of the last step: conv_small / conv1x1 / conv_ws3 take the others)."""
+        return inf["type"] == binding.T_CONV and inf["c"] % 64 == 0 and net.conv_kernel(i) == 5
+
+    def rows_rate(rows):
+        ops = sum(r["ops"] for i, r in enumerate(rows) if on_rows_kernel(i, net.info[i]))
+        ms_ = sum(r["ms"] for i, r in enumerate(rows) if on_rows_kernel(i, net.info[i]))
+        return ops, ms_
+
+    def s33_rate(rows):
+        sel = [r for i, r in enumerate(rows) if net.info[i]["type"] == binding.T_CONV and net.info[i]["size"] == 3
+               and net.info[i]["stride"] == 1 and net.info[i]["c"] > 3]
+        return sum(r["ops"] for r in sel), sum(r["ms"] for r in sel)
+
+    # ---- roofline of the dominant kernel (the MFMA implicit-GEMM conv), from HIP events on the launch stream
+    roof = None
+    layers = []
+    if prof_steps and rank == 0:
+        nprof, ms = net.profile_read()
+        layers, ev_cost, in_layout_ms = layer_table(nprof, ms, ser_dt, ser_steps)
+        mf_ops, mf_ms = rows_rate(layers)
+        s33_ops, s33_ms = s33_rate(layers)
+        all_ops = sum(r.get("ops", 0.0) for r in layers)
+        all_ms = sum(r["ms"] for r in layers)
         nlaunch = sum(1 for i, inf in enumerate(net.info) if on_rows_kernel(i, inf))
         nconv = sum(1 for inf in net.info if inf["type"] == binding.T_CONV)
         achieved = mf_ops / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
@@ -295,6 +355,8 @@ def main():
                           f"{100 * mf_ms / all_ms:.0f}% of its time and {100 * mf_ops / all_ops:.0f}% of its operations)",
                 "achieved": round(achieved, 2), "peak": round(PEAK_INT8_TOPS, 1), "unit": "TOP/s",
                 "frac": round(achieved / PEAK_INT8_TOPS, 4),
+                "measured_on": ("the serial leg after the timed region (one batch at a time: the kernel alone on the device, as in rocprofv3's trace of --inflight 1)"
+                                if ninfl > 1 else "the timed region"),
                 "traffic": traffic if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg" else None,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                 "traffic_source": f"committed profile {traffic_src} -- not measured in this run" if traffic_src else None,
@@ -307,8 +369,18 @@ def main():
                 # (tools/ubench/mfma_data_power.hip, profiles/r02_v3_ubench_mfma_data_power.log).  `peak` / `frac` stay nominal.
                 "mfma_only_loop_random_operands": {"tops": 3490.0, "frac_of_it": round(achieved / 3490.0, 4),
                                                    "source": "profiles/r02_v3_ubench_mfma_data_power.log -- not measured in this run"},
-                "input_layout_ms": round(max(float(ms[0]) / nprof - ev_cost, 0.0), 5),
+                "input_layout_ms": round(in_layout_ms, 5),
                 "event_overhead_ms": round(ev_cost, 5)}
+        if flight_prof and ninfl > 1:  # the same kernels while other batches' kernels share the CUs (timed region)
+            f_rows, _, _ = layer_table(flight_prof[0], flight_prof[1], None, 0)
+            f_ops, f_ms = rows_rate(f_rows)
+            roof["in_flight"] = {"achieved": round(f_ops / (f_ms * 1e-3) / 1e12, 2) if f_ms else None,
+                                 "frac": round(f_ops / (f_ms * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4) if f_ms else None,
+                                 "ms_per_launch_avg": round(f_ms / max(nlaunch, 1), 5),
+                                 "note": f"event intervals of the same launches inside the timed region, {ninfl} batches in flight: the kernel shares the "
+                                         "CUs with other batches' kernels, its duration is no longer a measure of the kernel"}
+        for r in layers:
+            r.pop("ops", None)
         if args.layers:
             for r in layers:
                 print("[layer]", json.dumps(r), file=sys.stderr)
@@ -341,7 +413,9 @@ def main():
 
     if rank == 0:
         out = {"metric": METRICS.get(os.path.basename(args.cfg), f"images/sec {os.path.basename(args.cfg)} INT8"), "value": round(value, 1), "unit": "images/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "warmup_passes_effective": args.warmup + (ninfl * args.selfcheck_passes if selfcheck else 0),  # the self-check passes are queued right in front of the warmup steps
+               "ms_per_step": round(ms_per_step, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x s8 -> int32 (f64 requant)",
                "data": "synthetic",
                "config": {"workload": "yolov3-tiny full net (cfg/yolov3-tiny_quant.cfg, leaky, per-channel quant), "
@@ -349,21 +423,26 @@ def main():
                                       if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg" else
                                       f"{os.path.basename(args.cfg)}, batch {B}/GPU synthetic uint8 {in_h}x{in_w}, inputs resident in HBM (NCHW uint8)",
                           "global_batch": world * B, "parallelism": f"image-sharded x{world}, RCCL weight broadcast once",
-                          "launch": "hipGraph replay" if args.graph else f"eager; per-layer HIP events on every {prof_stride}th step of the timed region",
+                          "batches_in_flight": ninfl,
+                          "launch": (f"{ninfl} batches in flight per GPU: step i runs on network instance i % {ninfl} (network_replica: own activations, input and "
+                                     "HIP stream; one copy of the packed weights), so the device overlaps the kernels of consecutive steps; every step is one "
+                                     f"forward pass over its own batch of {B} images; " if ninfl > 1 else "one batch at a time on one stream; ")
+                                    + ("hipGraph replay" if args.graph else f"eager launches, per-layer HIP events on every {prof_stride}th forward of instance 0"),
                           "weight_broadcast_ms": round(bcast_ms, 3)},
-               "roofline": roof, "cpu_baseline": cpu, "accum_ref_f32_mode": ref_f32, "selfcheck": selfcheck}
+               "roofline": roof, "serial": serial, "cpu_baseline": cpu, "accum_ref_f32_mode": ref_f32, "selfcheck": selfcheck}
         if cpu_omp:
             out["cpu_baseline_allcores"] = cpu_omp
         if layers:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            json.dump({"ms_per_step": ms_per_step, "layers": layers},
+            json.dump({"ms_per_step": serial["ms_per_step"] if serial else ms_per_step, "layers": layers},
                       open(os.path.join(ROOT, "gpurun_out", f"bench_layers_n{world}.json" if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg"
                                         else f"bench_layers_{os.path.splitext(os.path.basename(args.cfg))[0]}_n{world}.json"), "w"), indent=1)
     try:
         os.remove(wts)
     except OSError:
         pass
-    net.close()
+    for nk in reversed(nets):  # replicas before their parent
+        nk.close()
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

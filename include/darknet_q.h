@@ -91,6 +91,7 @@ struct layer {
     int out_view;                  /* out_t.data is a channel window of a later route layer's buffer (not owned) */
     int route_elided;              /* route: every input already writes into out_t (see plan_views) -- no copy at run time */
     void *blob_gpu;                /* packed weights + per-channel params (mi355_conv_pack) */
+    int blob_shared;               /* 1: blob_gpu belongs to the network this one is a replica of (network_replica): never freed / re-uploaded here */
     size_t blob_bytes;
     void *blob_host;
     uint8_t *weights_uint8_gpu;    /* raw weights / zero points for the ref-f32 verification mode */
@@ -128,6 +129,7 @@ struct network {
     mi355_tensor input_nchw_t; /* input_uint8_gpu described as it is (planar): layer 0 reads it in place where its kernel can */
     int *input_direct_p;      /* executor -> layer 0: where to clear input_direct (the network travels by value) */
     int input_direct;         /* 1: layer 0 is fed input_nchw_t, no conversion pass; cleared by the first MI355_EINVAL */
+    int input_direct_off;     /* user knob (dnq_net_set "input_direct" 0): never feed the planes directly, whatever is re-allocated */
     const mi355_tensor *cur_t; /* uint8 hand-off: the reference's `net.input_uint8 = l.output_uint8_final` */
     const float *cur_f32_gpu;  /* float hand-off: `net.input = l.output` */
 
@@ -148,6 +150,8 @@ struct network {
     int prepared;
     int has_host_weights; /* load_weights ran: raw weights_uint8 / biases / scales of every layer are on the host */
     int has_l0_weights;   /* imported from a packed exchange: blobs only, plus layer 0's raw record (re-prep on a new input scale) */
+    char *cfg_path;       /* the cfg this network was parsed from (network_replica parses it again) */
+    struct network *replica_of; /* non-NULL: a replica (network_replica): packed weights on the device are the parent's */
     uint64_t *selfcheck_gpu; /* [passes] checksums of the pending self-check */
     int selfcheck_passes;
     void *graph; /* hipGraph of the layer loop, built lazily when use_graph */
@@ -184,6 +188,14 @@ void network_letterbox_input_gpu(network *net, int slot, const float *im_gpu, in
 void network_quantize_input_gpu(network *net);
 /* the host half of the prep only (per-channel integers + packed blobs, no device needed) */
 void quantization_prep_host(network *net, float in_scale, uint8_t in_zp);
+
+/* Batches in flight (serving throughput): a replica is a second executor of the SAME prepared model on the same device --
+ * its own activation tensors, network input and HIP stream, the parent's packed weights in HBM (read-only in every kernel).
+ * forward_network_gpu on parent and replicas in turn puts independent batches on separate streams, so that the device
+ * overlaps one batch's launch gaps, pipeline fills and VALU-bound layers with another batch's MFMA-bound layers
+ * (measured: DESIGN.md 4.3).  The parent must be prepared and must outlive its replicas; a replica cannot re-derive
+ * layer 0 for another input scale, serve MI355_ACC_REF_F32 or be re-batched (error()). */
+network *network_replica(network *parent);
 
 /* ---- execution ----------------------------------------------------------------------------------------------- */
 void forward_network(network *net);     /* == forward_network_gpu; dies if no device */

@@ -231,6 +231,8 @@ def host():
         L.parse_network_cfg.restype = vp
         L.parse_network_cfg.argtypes = [C.c_char_p, ci]
         L.set_batch_network.argtypes = [vp, ci]
+        L.network_replica.restype = vp
+        L.network_replica.argtypes = [vp]
         L.free_network.argtypes = [vp]
         L.quantization_weights_and_activations.argtypes = [vp]
         L.quantization_weights_and_activations_fixed_input.argtypes = [vp, C.c_float, C.c_uint8]
@@ -320,6 +322,17 @@ class Net:
 
     def set(self, key, val):
         assert self.H.dnq_net_set(self.h, key.encode(), int(val)) == 0
+
+    def replica(self):
+        """network_replica: a second executor of this prepared model on the same device (own activations, input and HIP
+        stream; this network's packed weights).  This network must outlive it."""
+        r = object.__new__(Net)
+        r.H = self.H
+        r.h = self.H.network_replica(self.h)
+        r.keep_head_float = self.keep_head_float
+        r.n, r.batch, r.inputs, r.info = self.n, self.batch, self.inputs, self.info
+        r._parent = self  # keeps the parent alive
+        return r
 
     def prepare_fixed(self, in_scale=1.0 / 255.0, in_zp=0):
         self.H.quantization_weights_and_activations_fixed_input(self.h, np.float32(in_scale), in_zp)

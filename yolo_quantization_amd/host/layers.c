@@ -318,7 +318,7 @@ void free_layer_device(layer *l)
 {
     if (l->out_t.data && !l->out_view) mi355_free(l->out_t.data);
     l->out_view = 0; l->route_elided = 0;
-    if (l->blob_gpu) mi355_free(l->blob_gpu);
+    if (l->blob_gpu && !l->blob_shared) mi355_free(l->blob_gpu);
     if (l->weights_uint8_gpu) mi355_free(l->weights_uint8_gpu);
     if (l->weight_zero_point_gpu) mi355_free(l->weight_zero_point_gpu);
     if (l->output_int32_gpu) mi355_free(l->output_int32_gpu);

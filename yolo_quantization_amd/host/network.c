@@ -145,7 +145,9 @@ static void prep_conv_layer(network *net, int i)
 static void alloc_layer_device(network *net, int i)
 {
     layer *l = &net->layers[i];
+    void *shared_blob = l->blob_shared ? l->blob_gpu : NULL; /* a replica's weights are its parent's: survive the re-allocation */
     free_layer_device(l);
+    l->blob_gpu = shared_blob;
     const int B = net->batch;
     l->batch = B;
     if (l->type != YOLO) {
@@ -168,6 +170,7 @@ static void alloc_layer_device(network *net, int i)
 static void upload_conv(network *net, int i, int with_raw)
 {
     layer *l = &net->layers[i];
+    if (l->blob_shared) error("upload_conv on a replica (its packed weights belong to the parent network)");
     if (l->blob_gpu) { mi355_free(l->blob_gpu); l->blob_gpu = NULL; }
     check_mi355(mi355_alloc(&l->blob_gpu, l->blob_bytes), "alloc blob");
     check_mi355(mi355_h2d(l->blob_gpu, l->blob_host, l->blob_bytes, net->stream), "upload blob");
@@ -258,7 +261,7 @@ static void alloc_network_device(network *net)
     check_mi355(mi355_tensor_fill(&net->input_t, net->layers[0].input_data_uint8_zero_point[0], net->stream), "fill input");
     mi355_tensor_describe_nchw(&net->input_nchw_t, net->batch, net->h, net->w, net->c);
     net->input_nchw_t.data = net->input_uint8_gpu;
-    net->input_direct = net->c == 3 && !net->dump_int32;
+    net->input_direct = net->c == 3 && !net->dump_int32 && !net->input_direct_off;
     for (int i = 0; i < net->n; ++i) alloc_layer_device(net, i);
     plan_views(net);
     if (net->graph) { mi355_graph_destroy(net->graph); net->graph = NULL; }
@@ -415,6 +418,7 @@ void quantization_weights_and_activations_gpu(network *net, const float *input_g
     if (!net->prepared) {
         quantization_weights_and_activations_fixed_input(net, s, zp);
     } else if (l0->input_data_uint8_scales[0] != s || l0->input_data_uint8_zero_point[0] != zp) {
+        if (net->replica_of) error("the input scale changed: a replica shares its parent's layer-0 blob and cannot re-derive it");
         if (!net->has_host_weights && !net->has_l0_weights)
             error("the input scale changed but this network holds no raw layer-0 weights to re-derive layer 0 from");
         const int zp_changed = l0->input_data_uint8_zero_point[0] != zp;
@@ -426,6 +430,9 @@ void quantization_weights_and_activations_gpu(network *net, const float *input_g
         check_mi355(mi355_h2d(l0->blob_gpu, l0->blob_host, l0->blob_bytes, net->stream), "upload blob 0");
         if (zp_changed) check_mi355(mi355_tensor_fill(&net->input_t, zp, net->stream), "fill input");  /* pad cells = zero point */
         check_mi355(mi355_stream_sync(net->stream), "sync");  /* blob_host may be repacked by the next call */
+        /* a captured graph holds layer 0's kernel arguments by value: the planar first-layer kernels take the pad value
+         * (the input zero point) from there, not from pad cells in memory -> re-capture on the next forward */
+        if (net->graph) { mi355_graph_destroy(net->graph); net->graph = NULL; }
     }
     check_mi355(mi355_image_quantize(input_gpu, (long)net->batch * net->inputs, s, zp, net->input_uint8_gpu, net->stream),
                 "mi355_image_quantize");
@@ -452,6 +459,7 @@ void set_batch_network(network *net, int b)
 {
     if (b < 1) error("set_batch_network: batch < 1");
     if (b == net->batch && net->prepared) return;
+    if (net->replica_of) error("set_batch_network on a replica: re-batch the parent and make new replicas");
     net->batch = b;
     free(net->input); free(net->input_uint8);
     net->input = calloc((size_t)net->inputs * b, sizeof(float));
@@ -462,6 +470,7 @@ void set_batch_network(network *net, int b)
         net->input_gpu = NULL;
     }
     if (net->prepared) { /* re-size the device buffers, keep the packed weights */
+        plan_fusion(net); /* launcher acceptance depends on the batch: flags an earlier EINVAL fallback cleared are re-derived */
         alloc_network_device(net);
         for (int i = 0; i < net->n; ++i)
             if (net->layers[i].type == CONVOLUTIONAL) upload_conv(net, i, net->has_host_weights);
@@ -792,6 +801,9 @@ void network_import_packed_host(network *net, const void *buf, size_t bytes)
     if (bytes < sizeof(h)) error("network_import_packed: truncated");
     memcpy(&h, p, sizeof(h)); p += sizeof(h);
     if (h.magic != PACK_MAGIC || h.nlayers != net->n || h.total != bytes) error("network_import_packed: header mismatch (different cfg or format version?)");
+    /* the size is a pure function of the cfg: a buffer of any other length (truncated / corrupt file) is refused before
+     * anything is read through the offsets below */
+    if (bytes != network_packed_size(net)) error("network_import_packed: size does not match this cfg (truncated or corrupt packed data)");
     const pack_rec *recs = (const pack_rec *)p;
     p = (const char *)buf + ((sizeof(pack_head) + (size_t)net->n * sizeof(pack_rec) + 15) & ~(size_t)15);
     for (int i = 0; i < net->n; ++i) {
@@ -911,6 +923,54 @@ void network_bcast_packed(network *net, void *comm, int rank, int root)
     mi355_free(dev);
 }
 
+/* A second executor of the same prepared model (darknet_q.h).  The cfg is parsed again (layer geometry, host-side arrays),
+ * the per-layer quantisation records and the fusion plan's inputs are copied from the parent, every conv layer borrows the
+ * parent's packed blob on the device; activations, input buffers and the stream are the replica's own. */
+network *network_replica(network *parent)
+{
+    if (!parent || !parent->prepared) error("network_replica: the parent network is not prepared");
+    if (!parent->cfg_path) error("network_replica: the parent network was not parsed from a cfg file");
+    network *net = parse_network_cfg(parent->cfg_path, 0);
+    if (net->n != parent->n) error("network_replica: the cfg changed on disk");
+    net->gpu_index = parent->gpu_index;
+    net->accum_mode = parent->accum_mode; net->store_mode = parent->store_mode;
+    net->fuse_maxpool = parent->fuse_maxpool; net->keep_head_float = parent->keep_head_float;
+    net->use_graph = parent->use_graph; net->input_direct_off = parent->input_direct_off;
+    net->dump_int32 = 0;
+    if (parent->accum_mode == MI355_ACC_REF_F32) error("network_replica: MI355_ACC_REF_F32 reads raw weights, which a replica does not hold");
+    net->replica_of = parent;
+    net->batch = parent->batch;
+    free(net->input); free(net->input_uint8);
+    net->input = calloc((size_t)net->inputs * net->batch, sizeof(float));
+    net->input_uint8 = calloc((size_t)net->inputs * net->batch, sizeof(uint8_t));
+    for (int i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        const layer *p = &parent->layers[i];
+        if (l->type != p->type || l->outputs != p->outputs) error("network_replica: the cfg changed on disk");
+        l->batch = net->batch;
+        if (l->activ_data_uint8_scales && p->activ_data_uint8_scales) {
+            l->activ_data_uint8_scales[0] = p->activ_data_uint8_scales[0];
+            l->activ_data_uint8_zero_point[0] = p->activ_data_uint8_zero_point[0];
+        }
+        if (l->type == CONVOLUTIONAL) {
+            l->input_data_uint8_scales[0] = p->input_data_uint8_scales[0];
+            l->input_data_uint8_zero_point[0] = p->input_data_uint8_zero_point[0];
+            l->blob_gpu = p->blob_gpu;
+            l->blob_bytes = p->blob_bytes;
+            l->blob_shared = 1;
+            l->prepared = 1;
+        }
+    }
+    prep_shortcut_layers(net);
+    net->has_host_weights = 0;
+    net->has_l0_weights = 0;
+    plan_fusion(net);
+    alloc_network_device(net);
+    check_mi355(mi355_stream_sync(net->stream), "sync");
+    net->prepared = 1;
+    return net;
+}
+
 void free_network(network *net)
 {
     if (!net) return;
@@ -933,6 +993,6 @@ void free_network(network *net)
     if (net->quant_mm_gpu) mi355_free(net->quant_mm_gpu);
     if (net->selfcheck_gpu) mi355_free(net->selfcheck_gpu);
     if (net->stream) mi355_stream_destroy(net->stream);
-    free(net->layers); free(net->input); free(net->input_uint8); free(net->seen);
+    free(net->layers); free(net->input); free(net->input_uint8); free(net->seen); free(net->cfg_path);
     free(net);
 }

@@ -265,6 +265,7 @@ network *parse_network_cfg(char *filename, int close_quantization)
     net->inputs = option_find_int(o, "inputs", net->h * net->w * net->c);
     if (!net->inputs && !(net->h && net->w && net->c)) error("No input parameters supplied");
     net->close_quantization = close_quantization;
+    net->cfg_path = strdup(filename);
 
     size_params p = {net->batch, net->inputs, net->h, net->w, net->c, 0, close_quantization};
     for (int i = 0; i < net->n; ++i) {
@@ -363,7 +364,8 @@ void load_weights(network *net, char *filename)
         if (l.type == UPSAMPLE && l.layer_quant_flag) { /* ref :1185-1199 */
             if (!l.fisrt_time_train_fag) load_act_record(l, fp);
         }
-        if (l.type == SHORTCUT) load_act_record(l, fp); /* builder-specified: the sum's own (scale, zero point), like a maxpool's record */
+        if (l.type == SHORTCUT && l.layer_quant_flag && !l.fisrt_time_train_fag)
+            load_act_record(l, fp); /* builder-specified: the sum's own (scale, zero point), under the upsample record's conditions */
     }
     long here = ftell(fp);
     fseek(fp, 0, SEEK_END);
