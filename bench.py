@@ -169,6 +169,9 @@ def main():
     binding.init(local_rank)
     if os.environ.get("BENCH_DEBUG_FLAGS"):  # A/B switches between equivalent kernel variants (mi355_debug_flags)
         binding.shim().mi355_debug_flags(int(os.environ["BENCH_DEBUG_FLAGS"]))
+    if os.environ.get("BENCH_FORCE_TILE"):  # A/B: "bm,bn[,nt]" for every conv_rows launch (mi355_conv_set_tile)
+        t = [int(v) for v in os.environ["BENCH_FORCE_TILE"].split(",")]
+        binding.shim().mi355_conv_set_tile(t[0] | ((t[2] if len(t) > 2 else 0) << 16), t[1])
     B = args.batch
     wts = f"/tmp/bench_yolov3_tiny_{os.getpid()}.weights"
 
@@ -216,6 +219,13 @@ def main():
         nk.push_input(synth.synth_image_u8(in_c, in_h, in_w, seed=1000 + rank + 7919 * k, batch=B))
         nk.sync()
         nets.append(nk)
+
+    plan = 1 if len(nets) > 1 else 0  # network_replica switched parent and replicas to the throughput plan
+    if os.environ.get("BENCH_PLAN"):  # A/B: 0 = latency plan (whole-chip kernels) although batches are in flight, 1 = throughput plan
+        plan = int(os.environ["BENCH_PLAN"])
+        for nk in nets:
+            nk.set("plan", plan)
+    plan_name = "throughput (kernels of which two workgroups share a CU)" if plan else "latency (every launch sized to fill the chip alone)"
 
     def barrier():
         if world > 1 or force_dist:
@@ -423,7 +433,7 @@ def main():
                                       if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg" else
                                       f"{os.path.basename(args.cfg)}, batch {B}/GPU synthetic uint8 {in_h}x{in_w}, inputs resident in HBM (NCHW uint8)",
                           "global_batch": world * B, "parallelism": f"image-sharded x{world}, RCCL weight broadcast once",
-                          "batches_in_flight": ninfl,
+                          "batches_in_flight": ninfl, "kernel_plan": plan_name,
                           "launch": (f"{ninfl} batches in flight per GPU: step i runs on network instance i % {ninfl} (network_replica: own activations, input and "
                                      "HIP stream; one copy of the packed weights), so the device overlaps the kernels of consecutive steps; every step is one "
                                      f"forward pass over its own batch of {B} images; " if ninfl > 1 else "one batch at a time on one stream; ")

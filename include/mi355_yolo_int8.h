@@ -135,7 +135,16 @@ typedef struct mi355_conv_desc {
     int accum_mode;               /* MI355_ACC_* */
     uint8_t zp_in, zp_act;        /* input / activation zero points */
     float s_act;                  /* activation scale (only for y_f32) */
+    int plan;                     /* MI355_PLAN_*: which kernel / tile the launcher should prefer (results are identical) */
 } mi355_conv_desc;
+/* MI355_PLAN_LATENCY (0, default): one batch at a time -- every launch is sized to fill the whole chip on its own (one big
+ * workgroup per CU: 128 x 384 row-image tiles, the weights-stationary 3x3 kernel with up to 160 KB of LDS).
+ * MI355_PLAN_THROUGHPUT: several independent batches are in flight on separate streams (darknet_q.h network_replica) --
+ * prefer kernels of which TWO workgroups fit a CU (<= 80 KB of LDS, 4 waves), so that a workgroup of another batch's
+ * layer can move in next to it: a launch that needs an empty CU waits until every small workgroup of the other streams
+ * has drained from one.  Measured in DESIGN.md 4.3. */
+#define MI355_PLAN_LATENCY 0
+#define MI355_PLAN_THROUGHPUT 1
 
 /* forward_convolutional_layer_quant_inputi_outputi (ref: src/convolutional_layer.c:694-761) for a whole batch,
  * "apply the batch-1 function independently per image".

@@ -720,6 +720,7 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
     if (a.ypool ? (a.y != nullptr || a.stride != 1) : (a.y == nullptr || a.out_w < a.n || a.up != 1)) return MI355_EINVAL;
     a.debug = mi355_debug_flags_get();
     if ((a.H & 1) || (a.W & 1) || a.in_cs != c) return MI355_EINVAL;
+    if (c == 64 && (a.debug & (1 << 26))) return MI355_EINVAL;  // A/B switch (tools/dbg): the 64-channel layer on the row-image kernel
     // no fused residual add here: measured (YOLOv3 @608, batch 32) 412 us fused against 150 us + an 88 us stand-alone add for
     // 32 -> 64 @304 -- these kernels' stores are already their bottleneck, the add's loads queue in front of them
     if (a.res) return MI355_EINVAL;
@@ -746,6 +747,8 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
         int tp = SM_PPB;
         if (a.tiles_x == 0) {
             // flat tiles: as few rounds of 256 workgroups as the 256-pixel tile limit allows, tiles of equal size
+            // (half-size tiles -- two workgroups per CU -- measured slower alone (r02) and with three batches in flight (r03:
+            // 0.2820 -> 0.2865 ms per step): every workgroup loads its own copy of the A fragments)
             const long rounds = (total_p + 256L * SM_GMAX * 32 - 1) / (256L * SM_GMAX * 32);
             tp = (int)((total_p + 256 * rounds - 1) / (256 * rounds));
             if (tp < 32) tp = 32;

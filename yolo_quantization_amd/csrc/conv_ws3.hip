@@ -538,6 +538,13 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
 {
     const int c = a.cb * a.nchunks;
     if (!conv_ws3_eligible(a.n, c, a.ksize) || !a.ws || a.acc_out || a.y_f32 || a.yolo_out) return MI355_EINVAL;
+    // A/B switches (tools/dbg): bit 22 / 23 send the 256- / 128-channel layers to the row-image kernel
+    if ((c == 256 && (mi355_debug_flags_get() & (1 << 22))) || (c == 128 && (mi355_debug_flags_get() & (1 << 23)))) return MI355_EINVAL;
+    // throughput plan: the 256-channel form needs the whole LDS of a CU (image + 96 KB of parked K-part sums) -- with other
+    // batches' small workgroups trickling onto every CU its launch starves (89 us average per launch against 22 alone,
+    // profiles/r03_overlap_*.md); the row-image kernel's 128 x 128 tiles share a CU and take its place
+    // (the 128-channel form, 122 KB: in-flight step 0.2836 -> 0.2786 ms without it, one box, profiles/r03_plan_ab.log)
+    if (a.plan == MI355_PLAN_THROUGHPUT && !(mi355_debug_flags_get() & (1 << 27))) return MI355_EINVAL;
     if (!a.ypool) a.pool_mode = 0;
     const int pm = a.pool_mode;
     if (!a.y && !pm) return MI355_EINVAL;

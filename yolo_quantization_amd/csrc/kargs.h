@@ -51,6 +51,7 @@ struct ConvArgs {
     const uint8_t *res;
     int res_cs, res_delta;
     int sc_ka, sc_kb, sc_k0;
+    int plan;                // MI355_PLAN_*: throughput plan = prefer kernels of which two workgroups fit a CU
 };
 
 struct AuxArgs {

@@ -496,6 +496,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     a.ws = h.off_ws ? (const int8_t *)(base + h.off_ws) : nullptr;
     a.yolo_out = yolo_out; a.yolo_per = yolo_classes + 5;
     a.up = up;
+    a.plan = d->plan;
     if (res) {
         a.res = (const uint8_t *)res->data; a.res_cs = res->cs; a.res_delta = res->lead - y->lead;
         a.sc_ka = sc_ka; a.sc_kb = sc_kb; a.sc_k0 = sc_k0;

@@ -37,6 +37,7 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
     memset(&d, 0, sizeof(d));
     d.n = l.n; d.c = l.c; d.ksize = l.size; d.stride = l.stride; d.pad = l.pad;
     d.activation = l.activation;
+    d.plan = net.plan;
     d.store_mode = net.store_mode;
     d.accum_mode = net.accum_mode;
     d.zp_in = l.input_data_uint8_zero_point[0];

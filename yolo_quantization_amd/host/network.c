@@ -939,6 +939,10 @@ network *network_replica(network *parent)
     net->dump_int32 = 0;
     if (parent->accum_mode == MI355_ACC_REF_F32) error("network_replica: MI355_ACC_REF_F32 reads raw weights, which a replica does not hold");
     net->replica_of = parent;
+    /* more than one batch in flight from here on: both executors ask the launchers for kernels that share a CU */
+    parent->plan = MI355_PLAN_THROUGHPUT;
+    if (parent->graph) { mi355_graph_destroy(parent->graph); parent->graph = NULL; } /* captured with the other plan's kernels */
+    net->plan = MI355_PLAN_THROUGHPUT;
     net->batch = parent->batch;
     free(net->input); free(net->input_uint8);
     net->input = calloc((size_t)net->inputs * net->batch, sizeof(float));
