@@ -59,3 +59,38 @@ def test_replica_equals_parent_and_runs_concurrently(tmp_path, cfg, batch, hw):
         assert np.array_equal(parent.pull(i)["u8"], reps[0].pull(i)["u8"]), f"layer {i}"
     for nk in reversed(nets):
         nk.close()
+
+
+def test_throughput_plan_same_bytes_other_kernels(tmp_path):
+    """mi355_conv_desc.plan only chooses kernels: yolov3-tiny at batch 64 under the throughput plan (row-image 128 x 128 tiles
+    for the one-round 3x3 layers) stores the bytes of the latency plan (weights-stationary 3x3 kernel, 128 x 384 tiles)."""
+    binding.init(0)
+    cfgp = os.path.join(ROOT, "cfg", "yolov3-tiny_quant.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfgp, wts, seed=5)
+    x = synth.synth_image_u8(3, 416, 416, seed=77, batch=64)
+    res = {}
+    for plan in (0, 1):
+        net = binding.Net(cfgp, wts, batch=64)
+        net.set("plan", plan)
+        net.prepare_fixed(1.0 / 255.0, 0)
+        net.push_input(x)
+        net.forward()
+        net.sync()
+        kern = {i: net.conv_kernel(i) for i, inf in enumerate(net.info) if inf["type"] == binding.T_CONV}
+        tens = {}
+        for i, inf in enumerate(net.info):
+            if inf["type"] == binding.T_YOLO:
+                tens[i] = net.pull(i)["f32"]
+            elif not net.is_fused(i):
+                tens[i] = net.pull(i)["u8"]
+        res[plan] = (kern, tens)
+        net.close()
+    k0, t0 = res[0]
+    k1, t1 = res[1]
+    assert k0[8] == 4 and k0[10] == 4 and k0[14] == 4, k0          # conv_ws3 (whole-LDS workgroups) alone on the device
+    assert k1[8] == 5 and k1[10] == 5 and k1[14] == 5 and k1[12] == 5 and k1[21] == 5, k1  # row-image kernel, half-CU workgroups
+    common = sorted(set(t0) & set(t1))
+    assert len(common) >= 12
+    for i in common:
+        assert np.array_equal(t0[i], t1[i]), f"layer {i}: the plans disagree"

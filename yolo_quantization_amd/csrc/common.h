@@ -200,6 +200,43 @@ __device__ __forceinline__ void requant_values_mp(const int32_t (&accb)[NV], con
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// LEAKY through a byte table.  After q = trunc(acc * M') the rest of the epilogue -- activation, zero point, uint8 wrap,
+// the ^0x80 bias of the stored byte -- is a function of q and of two per-LAYER constants only (zp_act and the store mode):
+// ref src/convolutional_layer.c:737  q < 0 ? round(q * 0.1) + zp : q + zp.  A 4 KiB table over q in [-LUTQ_OFF, LUTQ_N -
+// LUTQ_OFF) in LDS, filled with the arithmetic below once per workgroup, turns the 6 VALU instructions of the branch-free
+// form (+ the running minimum of its fallback test) into one 2-clock add and one ds_read_u8.  Values of q outside the table
+// (only possible where bytes wrap: |q| in the thousands) must take the arithmetic path: the pooled kernels know from their
+// safe-range test that no byte of the window wraps, i.e. zp + q <= 255 and 10 zp + 4 >= -q: always inside the table.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LUTQ_OFF = 3072, LUTQ_N = 4096;
+template <bool SAT>
+__device__ __forceinline__ uint32_t leaky_byte_biased(int32_t q, int zp_act)
+{
+    const uint32_t x = (0u - (uint32_t)q) + 5u;
+    int32_t v = q < 0 ? zp_act - (int32_t)(x / 10u) : q + zp_act;
+    if (SAT) v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    return ((uint32_t)v & 0xFFu) ^ 0x80u;
+}
+// all `nthreads` threads of the workgroup; the caller puts a barrier between this and the first lookup
+template <bool SAT>
+__device__ __forceinline__ void leaky_lut_build(uint8_t *lut, int zp_act, int tid, int nthreads)
+{
+    for (int i = tid; i < LUTQ_N / 4; i += nthreads) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w |= leaky_byte_biased<SAT>(4 * i + e - LUTQ_OFF, zp_act) << (8 * e);
+        reinterpret_cast<uint32_t *>(lut)[i] = w;
+    }
+}
+// four table bytes (each in the low byte of its dword) -> one packed dword
+__device__ __forceinline__ uint32_t pack4_bytes(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+    const uint32_t p01 = __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u);
+    const uint32_t p23 = __builtin_amdgcn_perm(b3, b2, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Wrap-safe accumulator ranges: max-pooling commutes with the requantisation where no stored byte wraps.
 // ---------------------------------------------------------------------------------------------------------
 // activation + zero point of a requantised value, unwrapped (the byte is this & 0xFF or its clamp)

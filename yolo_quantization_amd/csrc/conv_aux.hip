@@ -263,6 +263,9 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
 {
     constexpr int ROWC = first_stage_rowc(PLANAR), XO = PLANAR ? 4 : 0;
     __shared__ __attribute__((aligned(16))) uint32_t img[2][18 * ROWC];
+    // LEAKY, wrapping store: windows inside the safe range take activation + zero point + bias from a byte table (common.h)
+    constexpr bool LUT = ACT == MI355_ACT_LEAKY && !SAT;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LUT ? LUTQ_N : 16];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile rows and output rows stay on the scalar unit
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + 7) >> 3, tpi = tiles_x * tiles_y;
     const int ntiles = a.B * tpi;
     const bool pow2 = a.hdr->pow2 == 1;
+    if constexpr (LUT) leaky_lut_build<false>(lut, a.zp_act, tid, 256);  // visible after the __syncthreads_or below
 
     // ---- per-lane constants: A fragments (row = channel 16*mt + pc, k-group g), channel parameters of the lane's four
     //      accumulator rows 16*mt + 4*g + r
@@ -470,11 +474,34 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                     amax[r][0] = (int32_t)(u + (uint32_t)lo[mt][r]);
                 }
                 int32_t m[4];
+                uint32_t packed = 0;
+                bool packed_done = false;
                 if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {
-                    int32_t v1[4][1];
-                    requant_values<ACT, SAT, 1>(amax, mp[mt], a.zp_act, v1);
+                    if constexpr (LUT) {  // q of a window inside the safe range lies inside the table (common.h)
+                        // four independent chains, issued pass by pass: left alone the compiler threads all four conversions through
+                        // one register pair and every FP64 instruction waits out the latency of the one before it
+                        uint32_t bt[4];
+                        double dd[4];
+                        int32_t qq[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m[r] = v1[r][0];
+                        for (int r = 0; r < 4; ++r) dd[r] = (double)amax[r][0];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dd[r] = dd[r] * mp[mt][r];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) qq[r] = (int32_t)dd[r];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bt[r] = lut[qq[r] + LUTQ_OFF];
+                        packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
+                        packed_done = true;
+                    } else {
+                        int32_t v1[4][1];
+                        requant_values<ACT, SAT, 1>(amax, mp[mt], a.zp_act, v1);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) m[r] = v1[r][0];
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -498,7 +525,8 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                         }
                     }
                 }
-                if (valid) *reinterpret_cast<uint32_t *>(outp + chq[mt]) = pack4_biased(m[0], m[1], m[2], m[3]);
+                if (!packed_done) packed = pack4_biased(m[0], m[1], m[2], m[3]);
+                if (valid) *reinterpret_cast<uint32_t *>(outp + chq[mt]) = packed;
             }
         }
         if (more) stash(buf ^ 1, nxt);

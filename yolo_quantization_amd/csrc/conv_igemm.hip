@@ -644,7 +644,7 @@ int conv_igemm_launch(ConvArgs &a, hipStream_t st)
             const int cands[3] = {384, 256, 128};
             // throughput plan (several batches in flight): 128-column tiles only -- 4 waves, <= 80 KB of LDS, two workgroups
             // (of any two launches) per CU; the wide tiles remain the fallback for shapes the narrow one cannot serve
-            const bool thr = a.plan == MI355_PLAN_THROUGHPUT && a.ksize == 3 && !(g_debug & (1 << 28));
+            const bool thr = plan_one_round(a) && a.ksize == 3 && !(g_debug & (1 << 28));
             for (int ci = thr ? 2 : 0; ci < 3; ++ci) {
                 const int cbn = cands[ci];
                 if (cbn == 384 && bm != 128) continue;

@@ -544,7 +544,7 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
     // batches' small workgroups trickling onto every CU its launch starves (89 us average per launch against 22 alone,
     // profiles/r03_overlap_*.md); the row-image kernel's 128 x 128 tiles share a CU and take its place
     // (the 128-channel form, 122 KB: in-flight step 0.2836 -> 0.2786 ms without it, one box, profiles/r03_plan_ab.log)
-    if (a.plan == MI355_PLAN_THROUGHPUT && !(mi355_debug_flags_get() & (1 << 27))) return MI355_EINVAL;
+    if (plan_one_round(a) && !(mi355_debug_flags_get() & (1 << 27))) return MI355_EINVAL;
     if (!a.ypool) a.pool_mode = 0;
     const int pm = a.pool_mode;
     if (!a.y && !pm) return MI355_EINVAL;

@@ -125,6 +125,17 @@ bool conv1x1_ws_eligible(int n, int c, int ksize);
 int conv_ws3_launch(ConvArgs &a, hipStream_t st);
 bool conv_ws3_eligible(int n, int c, int ksize);
 int mi355_debug_flags_get();
+// Throughput plan (mi355_conv_desc.plan): does this launch fit ONE round of whole-CU workgroups (128 x 384 output tiles, one
+// per CU)?  Only such launches are re-planned into half-CU workgroups that share a CU with another batch's layer; a launch of
+// several rounds keeps the whole-chip kernels, which are the more efficient ones and have their own tail to overlap
+// (YOLOv3-608, batch 32: 128 -> 256 @76 83 -> 116 us, 256 -> 512 @38 84 -> 113 us when re-planned; profiles/r03_v3_plan_layers.log).
+static inline bool plan_one_round(const ConvArgs &a)
+{
+    // ... and only maps that fill the row image of the 128-column kernel well (19-wide maps in 32-slot rows do not: YOLOv3's
+    // 512 -> 1024 @19 layers 82 -> 100 us alone, 4.58 -> 4.64 ms per step with three batches in flight)
+    const int rs = a.W + 2 <= 16 ? 16 : (a.W + 2 <= 32 ? 32 : 64);
+    return a.plan == MI355_PLAN_THROUGHPUT && (long)((a.mpad + 127) / 128) * ((a.total_n + 383) / 384) <= 256 && 10 * (a.W + 2) >= 7 * rs;
+}
 int conv_first_launch(AuxArgs &a, hipStream_t st);
 int conv_first_pool_launch(AuxArgs &a, hipStream_t st);
 int conv_first_mfma_pool_launch(AuxArgs &a, hipStream_t st);
