@@ -1,0 +1,55 @@
+#!/bin/bash
+# Round-3 evidence session: everything lands in gpurun_out/r03/, to be copied into profiles/r03_<tag>_*.
+# usage: tools/gpu_r3.sh [tests] [bench] [prof] [pmc] [sq] [bench608] [dist]
+set -uo pipefail
+cd "$(dirname "$0")/.."
+O=gpurun_out/r03; mkdir -p $O
+export TMPDIR=/tmp
+R=$PWD
+for what in "$@"; do
+case $what in
+tests)
+  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $O/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $O/smoke.log ;;
+bench)
+  # the driver's command, then long runs: batches in flight (default) and one batch at a time, with the per-layer table
+  timeout 600 python bench.py --steps 20 --warmup 5 2>$O/bench_driver_cmd.err | tee $O/bench_driver_cmd.json
+  timeout 600 python bench.py --steps 300 --warmup 30 --layers 2>$O/bench.err | tee $O/bench.json
+  cp gpurun_out/bench_layers_n1.json $O/bench_layers_throughput_plan.json
+  timeout 600 python bench.py --steps 300 --warmup 30 --inflight 1 --layers --no-cpu-baseline --no-ref-f32 2>$O/bench_if1.err | tee $O/bench_inflight1.json
+  cp gpurun_out/bench_layers_n1.json $O/bench_layers_latency_plan.json ;;
+prof)
+  # kernel-trace statistics: the driver's command (in-flight region + serial leg mixed), one batch at a time under each plan
+  # (clean per-kernel durations), and the overlap table of an in-flight region
+  for tag in default inflight1_latency_plan inflight1_throughput_plan overlap; do
+    extra=""; unset BENCH_PLAN
+    [[ $tag == inflight1_latency_plan ]] && extra="--inflight 1"
+    [[ $tag == inflight1_throughput_plan ]] && extra="--inflight 1" && export BENCH_PLAN=1
+    [[ $tag == overlap ]] && extra="--steps 60 --selfcheck-passes 0 --serial-steps 2"
+    rm -rf $O/prof_$tag
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_$tag" -o r03 -- \
+        python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-ref-f32 $extra > "$R/$O/prof_$tag.json" 2> "$R/$O/prof_$tag.err" )
+    db=$(find $O/prof_$tag -name "*results.db" | head -1)
+    if [[ $tag == overlap ]]; then
+      [ -n "$db" ] && python tools/rocpd_overlap.py "$db" $O/overlap_inflight3.md --last 700 | head -8
+    else
+      [ -n "$db" ] && python tools/rocpd_summary.py "$db" $O/kernel_stats_$tag.md | grep "^| \*\*" | head -8
+    fi
+    rm -rf $O/prof_$tag
+  done
+  unset BENCH_PLAN ;;
+pmc)
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $O/pmc_$ctr
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$R/$O/pmc_$ctr" -o p -- \
+        python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-ref-f32 --selfcheck-passes 0 --serial-steps 2 > "$R/$O/pmc_$ctr.json" 2> "$R/$O/pmc_$ctr.err" )
+  done
+  python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_traffic.json | head -8
+  rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE ;;
+bench608)
+  timeout 900 python bench.py --cfg cfg/yolov3_quant.cfg --batch 32 --steps 30 --warmup 3 --layers --selfcheck-passes 4 --serial-steps 8 2>$O/bench608.err > $O/bench608.json; python -c "import json; d=json.load(open('$O/bench608.json')); print('yolov3-608', d['value'], d['ms_per_step'], d['serial'])"
+  grep "\[layer\]" $O/bench608.err > $O/bench608_layers.log; tail -3 $O/bench608.err ;;
+dist)
+  BENCH_FORCE_DIST=1 timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-ref-f32 2>$O/bench_dist1.err > $O/bench_dist1.json; python -c "import json; d=json.load(open('$O/bench_dist1.json')); print('force-dist', d['value'], d['config']['weight_broadcast_ms'])" ;;
+esac
+done
