@@ -296,6 +296,29 @@ def main():
         serial = {"ms_per_step": round(ser_dt / ser_steps * 1e3, 4), "value": round(B * ser_steps / ser_dt, 1), "steps": ser_steps,
                   "note": "one batch at a time on one stream (per GPU), run right after the timed region; per-kernel figures (roofline, --layers) come from here"}
 
+    serial_prof = net.profile_read() if (prof_steps and rank == 0) else None
+    rows_layers = [i for i, inf in enumerate(net.info) if inf["type"] == binding.T_CONV and inf["c"] % 64 == 0 and net.conv_kernel(i) == 5]
+
+    # ---- latency-plan leg (rank 0, only when the timed region ran the throughput plan): the same net one batch at a time with the
+    # whole-chip kernels of rounds 1-2 (128 x 384 row-image tiles, conv_ws3), so that their roofline stays on record next to
+    # the half-CU kernels'.  Never part of `value`.
+    latency_leg = None
+    if ninfl > 1 and plan == 1 and rank == 0 and not args.graph:
+        net.set("plan", 0)
+        for _ in range(4):
+            net.forward()
+        n_lat = arm_events(32)
+        net.sync()
+        t0 = time.perf_counter()
+        for _ in range(32):
+            net.forward()
+        net.sync()
+        lat_dt = time.perf_counter() - t0
+        lat_prof = net.profile_read()
+        lat_rows = [i for i, inf in enumerate(net.info) if inf["type"] == binding.T_CONV and inf["c"] % 64 == 0 and net.conv_kernel(i) == 5]
+        net.set("plan", 1)
+        latency_leg = (n_lat, lat_prof, lat_dt, lat_rows)
+
     selfcheck = None
     if args.selfcheck_passes > 0 and not args.graph:
         bad = sum(nk.selfcheck_result() for nk in nets)
@@ -332,14 +355,14 @@ def main():
             rows.append(row)
         return rows, ev_cost, max(float(ms[0]) / nprof - ev_cost, 0.0)
 
-    def on_rows_kernel(i, inf):
+    def on_rows_kernel(i, inf, rows=None):
         """conv_rows16_i8_kernel / conv_rows_i8_kernel launches: 64-byte channel chunks, served by the implicit-GEMM family (the host records
         which kernel family took each conv of the last step: conv_small / conv1x1 / conv_ws3 take the others)."""
-        return inf["type"] == binding.T_CONV and inf["c"] % 64 == 0 and net.conv_kernel(i) == 5
+        return i in (rows_layers if rows is None else rows)
 
-    def rows_rate(rows):
-        ops = sum(r["ops"] for i, r in enumerate(rows) if on_rows_kernel(i, net.info[i]))
-        ms_ = sum(r["ms"] for i, r in enumerate(rows) if on_rows_kernel(i, net.info[i]))
+    def rows_rate(rows, which=None):
+        ops = sum(r["ops"] for i, r in enumerate(rows) if on_rows_kernel(i, net.info[i], which))
+        ms_ = sum(r["ms"] for i, r in enumerate(rows) if on_rows_kernel(i, net.info[i], which))
         return ops, ms_
 
     def s33_rate(rows):
@@ -351,7 +374,7 @@ def main():
     roof = None
     layers = []
     if prof_steps and rank == 0:
-        nprof, ms = net.profile_read()
+        nprof, ms = serial_prof
         layers, ev_cost, in_layout_ms = layer_table(nprof, ms, ser_dt, ser_steps)
         mf_ops, mf_ms = rows_rate(layers)
         s33_ops, s33_ms = s33_rate(layers)
@@ -389,6 +412,20 @@ def main():
                                  "ms_per_launch_avg": round(f_ms / max(nlaunch, 1), 5),
                                  "note": f"event intervals of the same launches inside the timed region, {ninfl} batches in flight: the kernel shares the "
                                          "CUs with other batches' kernels, its duration is no longer a measure of the kernel"}
+        if latency_leg and latency_leg[0]:
+            n_lat, lat_prof, lat_dt, lat_rows = latency_leg
+            l_rows, _, _ = layer_table(lat_prof[0], lat_prof[1], lat_dt, 32)
+            l_ops, l_ms = rows_rate(l_rows, lat_rows)
+            l33_ops, l33_ms = s33_rate(l_rows)
+            roof["latency_plan"] = {"kernel": "conv_rows16_i8_kernel<128, 384, ...> / conv_rows_i8_kernel<128, 384, ...> (one whole-CU workgroup per CU: the kernels of rounds 1-2), "
+                                              f"{len(lat_rows)} launches per step",
+                                    "achieved": round(l_ops / (l_ms * 1e-3) / 1e12, 2) if l_ms else None,
+                                    "frac": round(l_ops / (l_ms * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4) if l_ms else None,
+                                    "ms_per_launch_avg": round(l_ms / max(len(lat_rows), 1), 5), "ms_per_step": round(lat_dt / 32 * 1e3, 4),
+                                    "conv3x3_s1_aggregate_frac": round(l33_ops / (l33_ms * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4) if l33_ms else None,
+                                    "note": "the same net one batch at a time under MI355_PLAN_LATENCY, 32 steps after the serial leg; not the kernels that produced `value`"}
+            for r in l_rows:
+                r.pop("ops", None)
         for r in layers:
             r.pop("ops", None)
         if args.layers:
