@@ -148,6 +148,8 @@ struct network {
     const struct layer *fused_shortcut; /* executor -> conv forward_gpu: the [shortcut] layer whose add this conv performs, or NULL */
     int verbose;
     int prepared;
+    int range_lo, range_hi; /* diagnostic (tools/layer_flood.py): forward_network_gpu runs layers [range_lo, range_hi) only, on the tensors the
+                               last full pass left behind; 0, 0 = the whole network */
     int plan;             /* MI355_PLAN_*: handed to every conv launch; network_replica switches parent and replica to the throughput plan */
     int has_host_weights; /* load_weights ran: raw weights_uint8 / biases / scales of every layer are on the host */
     int has_l0_weights;   /* imported from a packed exchange: blobs only, plus layer 0's raw record (re-prep on a new input scale) */

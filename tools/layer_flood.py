@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""What does a layer cost with batches in flight?  For every conv layer of the net (with the layers fused into it):
+  serial  -- the launch repeated back to back on ONE stream (each waits for the one before: launch gap, pipeline fill and tail
+             are paid every time),
+  flood   -- the same launch repeated on N network instances / streams at once (independent batches): time per launch when the
+             device may overlap the launches with each other.
+The sum of the flood column is what a step would cost if mixing different layers bought nothing beyond overlapping a layer
+with itself; the in-flight step of bench.py sits next to it.
+usage: tools/layer_flood.py [--cfg ...] [--batch 64] [--inflight 3] [--plan 1] [--reps 60]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, ROOT)
+from yolo_quantization_amd import binding, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cfg", default=os.path.join(ROOT, "cfg", "yolov3-tiny_quant.cfg"))
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--inflight", type=int, default=3)
+ap.add_argument("--plan", type=int, default=1)
+ap.add_argument("--reps", type=int, default=60)
+a = ap.parse_args()
+binding.init(0)
+if os.environ.get("BENCH_FORCE_TILE"):  # "bm,bn[,nt]" for every conv_rows launch
+    t = [int(v) for v in os.environ["BENCH_FORCE_TILE"].split(",")]
+    binding.shim().mi355_conv_set_tile(t[0] | ((t[2] if len(t) > 2 else 0) << 16), t[1])
+if os.environ.get("BENCH_DEBUG_FLAGS"):
+    binding.shim().mi355_debug_flags(int(os.environ["BENCH_DEBUG_FLAGS"]))
+wts = f"/tmp/flood_{os.getpid()}.weights"
+synth.synth_weights(a.cfg, wts, seed=1234)
+net = binding.Net(a.cfg, wts, batch=a.batch, keep_head_float=False)
+net.prepare_fixed(1.0 / 255.0, 0)
+nets = [net] + [net.replica() for _ in range(a.inflight - 1)]
+info = net.info
+for k, nk in enumerate(nets):
+    nk.set("plan", a.plan)
+    nk.push_input(synth.synth_image_u8(info[0]["c"], info[0]["h"], info[0]["w"], seed=100 + k, batch=a.batch))
+    for _ in range(3):
+        nk.forward()
+    nk.sync()
+
+
+def timed(ns, reps):
+    for nk in ns:
+        nk.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for nk in ns:
+            nk.forward()
+    for nk in ns:
+        nk.sync()
+    return (time.perf_counter() - t0) / (reps * len(ns)) * 1e6
+
+
+# layer groups: a conv and everything up to the next conv (fused pools / yolo / upsample, elided routes)
+convs = [i for i, inf in enumerate(info) if inf["type"] == binding.T_CONV]
+groups = [(c, (convs[k + 1] if k + 1 < len(convs) else len(info))) for k, c in enumerate(convs)]
+tot_s = tot_f = 0.0
+print(f"plan {a.plan}, {a.inflight} instances, batch {a.batch}")
+print("| layers | conv | serial us | flood us per launch | flood / serial |")
+print("|---|---|---|---|---|")
+for lo, hi in groups:
+    for nk in nets:
+        nk.set("range_lo", lo); nk.set("range_hi", hi)
+    timed(nets, 5)
+    ts = timed(nets[:1], a.reps)
+    tf = timed(nets, a.reps)
+    tot_s += ts; tot_f += tf
+    inf = info[lo]
+    print(f"| {lo}..{hi - 1} | {inf['size']}x{inf['size']} {inf['c']}->{inf['n']} @{inf['out_h']} | {ts:.1f} | {tf:.1f} | {tf / ts:.2f} |")
+for nk in nets:
+    nk.set("range_lo", 0); nk.set("range_hi", 0)
+timed(nets, 10)
+step_s = timed(nets[:1], a.reps)
+step_f = timed(nets, a.reps)
+print(f"| sum | | {tot_s:.1f} | {tot_f:.1f} | {tot_f / tot_s:.2f} |")
+print(f"| whole step | | {step_s:.1f} | {step_f:.1f} | {step_f / step_s:.2f} |")
+for nk in reversed(nets):
+    nk.close()
+os.remove(wts)

@@ -528,12 +528,15 @@ static void run_layers(network *netp)
     /* The first layer reads the reference's [B][3][H][W] planes in place where its kernel can (no conversion pass); else the
      * input goes through the 4-byte-cell tensor.  The conv's forward_gpu falls back itself on MI355_EINVAL and clears the flag. */
     const int direct = netp->input_direct && net.accum_mode == MI355_ACC_EXACT && !net.dump_int32;
-    if (!direct) check_mi355(mi355_nchw_to_tensor(netp->input_uint8_gpu, &netp->input_t, net.stream), "input layout");
+    const int lo = (netp->range_hi > netp->range_lo) ? netp->range_lo : 0, hi = (netp->range_hi > netp->range_lo) ? netp->range_hi : net.n;
+    if (lo < 0 || hi > net.n) error("forward_network_gpu: bad layer range");
+    if (!direct && lo == 0) check_mi355(mi355_nchw_to_tensor(netp->input_uint8_gpu, &netp->input_t, net.stream), "input layout");
     if (ev) check_mi355(mi355_event_record(ev[1], net.stream), "event");
     net.cur_t = direct ? &netp->input_nchw_t : &netp->input_t;
     net.input_direct_p = &netp->input_direct;
     net.cur_f32_gpu = NULL;
-    for (int i = 0; i < net.n; ++i) {
+    if (lo > 0) net.cur_t = &netp->layers[lo - 1].out_t;
+    for (int i = lo; i < hi; ++i) {
         net.index = i;
         layer l = net.layers[i];
         const int fuse0 = l.fuse_next_pool && net.fuse_maxpool && !net.dump_int32 && net.accum_mode == MI355_ACC_EXACT;
