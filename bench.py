@@ -319,6 +319,40 @@ def main():
         net.set("plan", 1)
         latency_leg = (n_lat, lat_prof, lat_dt, lat_rows)
 
+    # ---- sustained rate of the dominant kernel (rank 0, batches in flight only): every row-image launch of the step repeated on all
+    # instances at once (the layer range knob of the host: forward_network_gpu runs that one layer on the tensors the last pass left),
+    # wall time / number of launches = what one launch costs the chip when the chip is kept full of this kernel -- no launch gap, fill or
+    # tail between dependent launches, which is how the kernel runs in the timed region.  (tools/layer_flood.py does this for every layer.)
+    sustained = None
+    if ninfl > 1 and rank == 0 and not args.graph and rows_layers:
+        tot_ops = tot_us = 0.0
+        per = []
+        for i in rows_layers:
+            for nk in nets:
+                nk.set("range_lo", i); nk.set("range_hi", i + 1)
+            for _ in range(4):
+                for nk in nets:
+                    nk.forward()
+            for nk in nets:
+                nk.sync()
+            reps = 40
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for nk in nets:
+                    nk.forward()
+            for nk in nets:
+                nk.sync()
+            us = (time.perf_counter() - t0) / (reps * ninfl) * 1e6
+            ops = conv_layer_work(net.info[i], B)[0]
+            per.append({"layer": i, "us_per_launch": round(us, 2), "tops": round(ops / us / 1e6, 1)})
+            tot_ops += ops; tot_us += us
+        for nk in nets:
+            nk.set("range_lo", 0); nk.set("range_hi", 0)
+        sustained = {"achieved": round(tot_ops / tot_us / 1e6, 1), "frac": round(tot_ops / tot_us / 1e6 / PEAK_INT8_TOPS, 4), "launches": per,
+                     "note": f"each row-image launch of the step repeated 40 times on all {ninfl} instances at once; host wall time / launches (no events: "
+                             "the launches overlap).  `frac` above is the strict per-launch figure (one launch alone on the device, launch gap, fill and "
+                             "tail included); this is the rate the kernel sustains when the chip is kept full of it, as in the timed region"}
+
     selfcheck = None
     if args.selfcheck_passes > 0 and not args.graph:
         bad = sum(nk.selfcheck_result() for nk in nets)
@@ -412,6 +446,8 @@ def main():
                                  "ms_per_launch_avg": round(f_ms / max(nlaunch, 1), 5),
                                  "note": f"event intervals of the same launches inside the timed region, {ninfl} batches in flight: the kernel shares the "
                                          "CUs with other batches' kernels, its duration is no longer a measure of the kernel"}
+        if sustained:
+            roof["sustained"] = sustained
         if latency_leg and latency_leg[0]:
             n_lat, lat_prof, lat_dt, lat_rows = latency_leg
             l_rows, _, _ = layer_table(lat_prof[0], lat_prof[1], lat_dt, 32)

@@ -225,6 +225,10 @@ int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
     const long rounds = (total + (long)want * gmax * 32 - 1) / ((long)want * gmax * 32);
     int tp = (int)((total + want * rounds - 1) / (want * rounds));
     if (tp < 16) tp = 16;
+    // throughput plan (batches in flight): whole groups of 32 pixels per workgroup instead of one round of the chip -- a tile of 43
+    // pixels pays for two groups (LDS, MFMAs, the workgroup's copy of the A fragments) anyway; fewer, full workgroups cost the chip
+    // less and the other batches' launches fill the CUs this one leaves free (layer 13: 252 -> 169 workgroups)
+    if (a.plan == MI355_PLAN_THROUGHPUT && !(mi355_debug_flags_get() & (1 << 29))) tp = (tp + 31) & ~31;
     const int ntiles = (int)((total + tp - 1) / tp);
     const int G = (tp + 31) / 32;
     a.sm_tp = tp;

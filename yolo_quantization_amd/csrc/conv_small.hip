@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     // which does not fit an int8) -- instead of per-cell sums, a 3x3 box sum per pixel and a multiply-add per
     // accumulator on the VALU, which is the bottleneck of this kernel.  With 32 input channels the extra MFMAs (72 per
     // wave and tile) would cost more than they save.
+#ifdef SMALL_NO_DZM
+    constexpr bool DZM = false;
+#else
     constexpr bool DZM = (C == 16);
+#endif
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ncell = a.sm_ncell;     // cells of an LDS image row (flat tiles: W + 2, x = -1 .. W; patches: 34)
