@@ -146,8 +146,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     // per-channel epilogue parameters of this M tile, staged once (the epilogue would otherwise issue 5 dependent
     // global loads per output channel per lane): doubles first (8-byte aligned), then the three int planes
     double *ldsPM = reinterpret_cast<double *>(smem + a.lds_param_off);  // [BM] M_value, [BM] shift_value
-    int *ldsPI = reinterpret_cast<int *>(ldsPM + 3 * BM);                  // [BM] cw, dzp, bias, cw+bias
-    float *ldsYL = reinterpret_cast<float *>(ldsPI + 4 * BM);              // [256] fused yolo head: logistic of every byte's dequantised value
+    int *ldsPI = reinterpret_cast<int *>(ldsPM + 3 * BM);                  // [BM] dzp, [BM] bias
+    float *ldsYL = reinterpret_cast<float *>(ldsPI + 2 * BM);              // [256] fused yolo head: logistic of every byte's dequantised value
     // ldsPM: [BM] M_value, [BM] shift_value, [BM] M_value*shift_value
 
     const int tid = threadIdx.x;
@@ -329,10 +329,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         const int oc = mtile * BM + i;  // parameter arrays are padded to mpad
         ldsPM[i] = a.mval[oc];
         ldsPM[BM + i] = a.sval[oc];
-        ldsPI[i] = a.cw[oc];
-        ldsPI[BM + i] = a.dzp[oc];
-        ldsPI[2 * BM + i] = a.bias[oc];
-        ldsPI[3 * BM + i] = a.cwb[oc];
+        ldsPI[i] = a.dzp[oc];
+        ldsPI[BM + i] = a.bias[oc];
         ldsPM[2 * BM + i] = a.mprime[oc];
     }
 
@@ -639,7 +637,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
                 const int ocl = wm * TM + ms * 32 + 8 * grp + 4 * kh;
-                const int4 dz4 = *reinterpret_cast<const int4 *>(ldsPI + BM + ocl);
+                const int4 dz4 = *reinterpret_cast<const int4 *>(ldsPI + ocl);
                 const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
                 int32_t accb[4][NS];
                 double mp[4];
@@ -708,7 +706,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     #pragma unroll
                 for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
                     const int oc = oc0 + r;
-                    const int dzv = ldsPI[BM + ocl + r], biv = ldsPI[2 * BM + ocl + r];
+                    const int dzv = ldsPI[ocl + r], biv = ldsPI[BM + ocl + r];
                     const double mv = ldsPM[ocl + r], sv = ldsPM[BM + ocl + r];
     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns) {
@@ -811,7 +809,7 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     if (lds_epi > lds) lds = lds_epi;
     lds = (lds + 15) & ~(size_t)15;
     a.lds_param_off = (int)lds;  // beyond both the K-loop buffers and the epilogue tile
-    lds += (size_t)BM * 40 + 1024;
+    lds += (size_t)BM * 32 + (a.yolo_out ? 1024 : 0);  // the logistic table only when a yolo head is fused (three 64 x 128 workgroups then fit a CU on 13-wide maps)
     if (lds > 160 * 1024) return MI355_EINVAL;
     auto kern = conv_rows_i8_kernel<BM, BN, WMW, WNW, RS, KS>;
     // per kernel instantiation AND per device (function attributes are per device; `darknet -gpus` drives several devices

@@ -101,8 +101,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
     // per-channel epilogue parameters of this M tile, staged once (the epilogue would otherwise issue 5 dependent
     // global loads per output channel per lane): doubles first (8-byte aligned), then the three int planes
     double *ldsPM = reinterpret_cast<double *>(smem + a.lds_param_off);  // [BM] M_value, [BM] shift_value
-    int *ldsPI = reinterpret_cast<int *>(ldsPM + 3 * BM);                  // [BM] cw, dzp, bias, cw+bias
-    float *ldsYL = reinterpret_cast<float *>(ldsPI + 4 * BM);              // [256] fused yolo head: logistic of every byte's dequantised value
+    int *ldsPI = reinterpret_cast<int *>(ldsPM + 3 * BM);                  // [BM] dzp, [BM] bias
+    float *ldsYL = reinterpret_cast<float *>(ldsPI + 2 * BM);              // [256] fused yolo head: logistic of every byte's dequantised value
     // ldsPM: [BM] M_value, [BM] shift_value, [BM] M_value*shift_value
 
     const int tid = threadIdx.x;
@@ -272,10 +272,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
         const int oc = mtile * BM + i;  // parameter arrays are padded to mpad
         ldsPM[i] = a.mval[oc];
         ldsPM[BM + i] = a.sval[oc];
-        ldsPI[i] = a.cw[oc];
-        ldsPI[BM + i] = a.dzp[oc];
-        ldsPI[2 * BM + i] = a.bias[oc];
-        ldsPI[3 * BM + i] = a.cwb[oc];
+        ldsPI[i] = a.dzp[oc];
+        ldsPI[BM + i] = a.bias[oc];
         ldsPM[2 * BM + i] = a.mprime[oc];
     }
 
@@ -490,7 +488,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int ocl = wm * TM + mi * 16 + 4 * kq;  // 4 consecutive filters held by this lane
-            const int4 dz4 = *reinterpret_cast<const int4 *>(ldsPI + BM + ocl);
+            const int4 dz4 = *reinterpret_cast<const int4 *>(ldsPI + ocl);
             const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
             double mp[4];
 #pragma unroll
@@ -559,7 +557,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {  // per-channel parameters (arrays are padded to mpad: in-bounds for oc >= n)
                 const int oc = oc0 + r;
-                const int dzv = ldsPI[BM + ocl + r], biv = ldsPI[2 * BM + ocl + r];
+                const int dzv = ldsPI[ocl + r], biv = ldsPI[BM + ocl + r];
                 const double mv = ldsPM[ocl + r], sv = ldsPM[BM + ocl + r];
 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns) {
@@ -673,7 +671,7 @@ static int rows16_launch_cfg(ConvArgs &a, hipStream_t st)
     if (lds_epi > lds) lds = lds_epi;
     lds = (lds + 15) & ~(size_t)15;
     a.lds_param_off = (int)lds;  // beyond both the K-loop buffers and the epilogue tile
-    lds += (size_t)BM * 40 + 1024;
+    lds += (size_t)BM * 32 + (a.yolo_out ? 1024 : 0);  // the logistic table only when a yolo head is fused (three 64 x 128 workgroups then fit a CU on 13-wide maps)
     if (lds > 160 * 1024) return MI355_EINVAL;
     auto kern = conv_rows16_i8_kernel<BM, BN, WMW, WNW, RS, KS, NBX>;
     // per kernel instantiation AND per device (function attributes are per device; `darknet -gpus` drives several devices

@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t pool_requant_quad(const int32_t (&accb)[4][4
 // MODE 0: conv + 2x2/2 maxpool.  1: no pool, the four window positions of a lane are four output pixels.  2: stride-2
 // convolution = the stride-1 output at the even positions = window position 0 only (a quarter of the MFMAs), stored on the
 // pooled geometry (the output map of a stride-2 3x3 pad-1 convolution on an even map is the pooled map).
-template <int C, int NM, int ACT, bool SAT, int MODE = 0>
+template <int C, int NM, int ACT, bool SAT, int MODE = 0, bool VDZ = false>
 __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs a)
 {
     constexpr bool POOL = MODE == 0;
@@ -90,11 +90,10 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     // which does not fit an int8) -- instead of per-cell sums, a 3x3 box sum per pixel and a multiply-add per
     // accumulator on the VALU, which is the bottleneck of this kernel.  With 32 input channels the extra MFMAs (72 per
     // wave and tile) would cost more than they save.
-#ifdef SMALL_NO_DZM
-    constexpr bool DZM = false;
-#else
-    constexpr bool DZM = (C == 16);
-#endif
+    // VDZ (throughput plan): the correction on the VALU after all, one multiply-add per accumulator.  Alone on the device the
+    // kernel is bound by its VALU stream and the MFMA form is faster (layer 2: 37.6 vs 38.7 us); with other batches in flight what
+    // counts is the sum of both pipes' time, and the second MFMA pass costs 0.16 clk per output against 0.06 (flood 34.9 -> 33.1 us)
+    constexpr bool DZM = (C == 16) && !VDZ;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ncell = a.sm_ncell;     // cells of an LDS image row (flat tiles: W + 2, x = -1 .. W; patches: 34)
@@ -679,6 +678,13 @@ static int mid_launch_sat(ConvArgs &a, hipStream_t st, int grid, int threads, si
 template <int C, int NM, int ACT, int POOL>
 static int small_launch_sat2(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 {
+    if (C == 16 && POOL == 0 && a.plan == MI355_PLAN_THROUGHPUT && a.store_mode != MI355_STORE_SATURATE) {
+        auto kern = conv_small_pool_kernel<C, NM, ACT, false, POOL, (C == 16)>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MI355_EHIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+        return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+    }
     if (a.store_mode == MI355_STORE_SATURATE) {
         auto kern = conv_small_pool_kernel<C, NM, ACT, true, POOL>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
