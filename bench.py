@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--cpu-omp", action="store_true", help="also time the reference's OpenMP build on all host cores (extra JSON key)")
     ap.add_argument("--no-ref-f32", action="store_true", help="skip the extra leg that times the bit-faithful MI355_ACC_REF_F32 mode")
     ap.add_argument("--ref-f32-steps", type=int, default=2)
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the latency-plan leg and the sustained-rate leg (profiling runs)")
     ap.add_argument("--serial-steps", type=int, default=64, help="steps of the serial leg that follows the timed region when --inflight > 1")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("BENCH_INFLIGHT", "3")),
                     help="batches in flight per GPU: that many network instances (own activations, own HIP stream, same packed weights); "
@@ -303,7 +304,7 @@ def main():
     # whole-chip kernels of rounds 1-2 (128 x 384 row-image tiles, conv_ws3), so that their roofline stays on record next to
     # the half-CU kernels'.  Never part of `value`.
     latency_leg = None
-    if ninfl > 1 and plan == 1 and rank == 0 and not args.graph:
+    if ninfl > 1 and plan == 1 and rank == 0 and not args.graph and not args.no_extra_legs:
         net.set("plan", 0)
         for _ in range(4):
             net.forward()
@@ -324,7 +325,7 @@ def main():
     # wall time / number of launches = what one launch costs the chip when the chip is kept full of this kernel -- no launch gap, fill or
     # tail between dependent launches, which is how the kernel runs in the timed region.  (tools/layer_flood.py does this for every layer.)
     sustained = None
-    if ninfl > 1 and rank == 0 and not args.graph and rows_layers:
+    if ninfl > 1 and rank == 0 and not args.graph and rows_layers and not args.no_extra_legs:
         tot_ops = tot_us = 0.0
         per = []
         for i in rows_layers:

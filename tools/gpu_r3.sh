@@ -25,7 +25,7 @@ prof)
     extra=""; unset BENCH_PLAN
     [[ $tag == inflight1_latency_plan ]] && extra="--inflight 1"
     [[ $tag == inflight1_throughput_plan ]] && extra="--inflight 1" && export BENCH_PLAN=1
-    [[ $tag == overlap ]] && extra="--steps 60 --selfcheck-passes 0 --serial-steps 2"
+    [[ $tag == overlap ]] && extra="--steps 60 --selfcheck-passes 0 --serial-steps 2 --no-extra-legs"
     rm -rf $O/prof_$tag
     ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_$tag" -o r03 -- \
         python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-ref-f32 $extra > "$R/$O/prof_$tag.json" 2> "$R/$O/prof_$tag.err" )
@@ -42,7 +42,7 @@ pmc)
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/pmc_$ctr
     ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$R/$O/pmc_$ctr" -o p -- \
-        python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-ref-f32 --selfcheck-passes 0 --serial-steps 2 > "$R/$O/pmc_$ctr.json" 2> "$R/$O/pmc_$ctr.err" )
+        python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-ref-f32 --selfcheck-passes 0 --serial-steps 2 --no-extra-legs > "$R/$O/pmc_$ctr.json" 2> "$R/$O/pmc_$ctr.err" )
   done
   python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_traffic.json | head -8
   rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE ;;
@@ -50,6 +50,6 @@ bench608)
   timeout 900 python bench.py --cfg cfg/yolov3_quant.cfg --batch 32 --steps 30 --warmup 3 --layers --selfcheck-passes 4 --serial-steps 8 2>$O/bench608.err > $O/bench608.json; python -c "import json; d=json.load(open('$O/bench608.json')); print('yolov3-608', d['value'], d['ms_per_step'], d['serial'])"
   grep "\[layer\]" $O/bench608.err > $O/bench608_layers.log; tail -3 $O/bench608.err ;;
 dist)
-  BENCH_FORCE_DIST=1 timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-ref-f32 2>$O/bench_dist1.err > $O/bench_dist1.json; python -c "import json; d=json.load(open('$O/bench_dist1.json')); print('force-dist', d['value'], d['config']['weight_broadcast_ms'])" ;;
+  BENCH_FORCE_DIST=1 timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-ref-f32 2>$O/bench_dist1.err > $O/bench_dist1.json; python -c "import json; d=json.loads(open('$O/bench_dist1.json').read().strip().splitlines()[-1]); print('force-dist', d['value'], d['config']['weight_broadcast_ms'])" ;;
 esac
 done
