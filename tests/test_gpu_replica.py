@@ -94,3 +94,30 @@ def test_throughput_plan_same_bytes_other_kernels(tmp_path):
     assert len(common) >= 12
     for i in common:
         assert np.array_equal(t0[i], t1[i]), f"layer {i}: the plans disagree"
+
+
+def test_layer_range_reruns_one_layer_in_place(tmp_path):
+    """the diagnostic layer range (tools/layer_flood.py, bench.py's sustained leg): forward_network_gpu over [lo, hi) only, on the tensors
+    the last full pass left behind, writes the same bytes again and touches nothing else"""
+    binding.init(0)
+    cfgp = os.path.join(ROOT, "cfg", "yolov3-tiny_quant.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfgp, wts, seed=9)
+    net = binding.Net(cfgp, wts, batch=4)
+    net.prepare_fixed(1.0 / 255.0, 0)
+    net.push_input(synth.synth_image_u8(3, 416, 416, seed=3, batch=4))
+    net.forward()
+    net.sync()
+    keep = {i: net.pull(i)["u8"].copy() for i, inf in enumerate(net.info) if inf["type"] != binding.T_YOLO and not net.is_fused(i)}
+    yolo = {i: net.pull(i)["f32"].copy() for i, inf in enumerate(net.info) if inf["type"] == binding.T_YOLO}
+    for lo, hi in ((12, 13), (14, 17), (21, 24), (0, 2)):
+        net.set("range_lo", lo); net.set("range_hi", hi)
+        for _ in range(2):
+            net.forward()
+        net.sync()
+    net.set("range_lo", 0); net.set("range_hi", 0)
+    for i, v in keep.items():
+        assert np.array_equal(net.pull(i)["u8"], v), f"layer {i}"
+    for i, v in yolo.items():
+        assert np.array_equal(net.pull(i)["f32"], v), f"yolo {i}"
+    net.close()

@@ -36,6 +36,9 @@
 // A(g), A(g+1) are being read while A(g+2) .. A(g+5) are in flight) -- 4 in the 128-column configurations, whose LDS
 // then lets two workgroups share a CU (one's epilogue under the other's K loop); 4 (3 for the widest tiles: LDS) for the plain 1x1
 // loop, which then has its DMA two or three K-steps ahead instead of one -- its K-steps took 0.7 us each, the DMA latency
+// (round 3: the K loop also takes FIVE stages -- a slab issued three K-steps ahead instead of two; measured on the 128-column tiles,
+// 80 448 bytes of LDS on 13-wide maps, two workgroups per CU still: L12 44.6 vs 44.2-45.3 us per launch with three batches in flight,
+// 360 parity tests green -- the 128 x 128 K loop at 58 % of the matrix pipe is not waiting for its DMA.  Back to four.)
 template <int KS, int BN> constexpr int ra16_stages() { return KS == 3 ? (BN <= 128 ? 4 : 6) : (BN <= 128 ? 4 : 3); }
 // B buffers: two per-chunk row images for 3x3 (a chunk lasts nine K-steps); for 1x1 every K-step is a new chunk and the
 // row image rides the same ring as the weights
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
         //      [B(chunk+1) on a chunk's first steps]; the step's 24 MFMAs with the reads of step g+1's fragments threaded between
         //      them, IN PLACE: B fragment ni is reloaded right after its four MFMAs, the A fragments during the last two rounds.
         constexpr int R = RA_STAGES;
-        static_assert(R == 6 || R == 4, "ring depths the stage bookkeeping below is written for");
+        static_assert(R >= 4 && R <= 6, "ring depths the stage bookkeeping below is written for");
         static_assert(MI == 4 && NI >= 2, "written for 64-row wave tiles");
         constexpr int ROT = 9 % R;  // ring phase advance of one channel chunk (nine K-steps)
         v4i fa[MI], fb[NI];
@@ -311,6 +314,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
         // Addresses: one register per A ring stage (the fragment index is an immediate), one per B fragment for the tap ROW being
         // read (moved on by rowb every third step: NI additions, instead of 3 x NI registers).
         unsigned aaddr[R], baddr[NI];
+        unsigned sst[R];  // (R == 5) byte offset of ring stage (9 * chunk + s) % R: wave-uniform, rotated with aaddr once per chunk
+#pragma unroll
+        for (int st = 0; st < R; ++st) sst[st] = st * (BM * 64);
 #pragma unroll
         for (int st = 0; st < R; ++st) aaddr[st] = lds0 + st * (BM * 64) + atab0;
 #pragma unroll
@@ -346,7 +352,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
                 constexpr bool ISSUE_A = !LAST || (t + R - 1 < 9);  // slab g+5 exists
                 constexpr auto n_b = [](int st) { return (LAST || st < 0 || st >= 4) ? 0 : ((st + 1) * SPS < NBS ? (st + 1) * SPS : NBS) - (st * SPS < NBS ? st * SPS : NBS); };
                 constexpr auto n_a = [](int st) { return (st < 0 || !LAST || st + R - 1 < 9) ? APT : 0; };
-                constexpr int YOUNG = n_a(t - 1) + n_b(t - 1) + (R > 4 ? n_a(t - 2) + n_b(t - 2) + n_a(t - 3) + n_b(t - 3) : 0);
+                // A(g+1) was issued R - 2 steps ago as the last DMA of its step: younger than it are the DMAs of the R - 3 steps in between
+                constexpr int YOUNG = n_a(t - 1) + n_b(t - 1) + (R > 4 ? n_a(t - 2) + n_b(t - 2) : 0) + (R > 5 ? n_a(t - 3) + n_b(t - 3) : 0);
                 constexpr int BLO = t * SPS < NBS ? t * SPS : NBS, BHI = (t + 1) * SPS < NBS ? (t + 1) * SPS : NBS;
                 if (t == 8 && !LAST) {
                     const int bdelta = (odd ? -bbytes : bbytes) - 2 * rowb;  // the other row image, back to its tap row 0
@@ -355,6 +362,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
                     for (int st = 0; st < R; ++st) rot[st] = aaddr[(st + ROT) % R];
 #pragma unroll
                     for (int st = 0; st < R; ++st) aaddr[st] = rot[st];
+                    if constexpr (R == 5) {
+                        unsigned srot[R];
+#pragma unroll
+                        for (int st = 0; st < R; ++st) srot[st] = sst[(st + ROT) % R];
+#pragma unroll
+                        for (int st = 0; st < R; ++st) sst[st] = srot[st];
+                    }
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) baddr[ni] += bdelta;
                 }
@@ -373,6 +387,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
                         if constexpr (R == 6) {  // (9 * chunk) % 6 = 3 * odd
                             constexpr unsigned E = ((t + R - 1) % R) * (BM * 64), O = ((t + R - 1 + 3) % R) * (BM * 64);
                             issueA_next(odd ? O : E);
+                        } else if constexpr (R == 5) {
+                            // (on a chunk's last step the table has already been rotated for the next chunk: 9 steps further on)
+                            issueA_next(sst[t == 8 ? (t + R - 1 - 9) % R : (t + R - 1) % R]);
                         } else {                 // (9 * chunk) % 4 = chunk % 4
                             issueA_next((unsigned)((chunk + t + R - 1) & 3) * (BM * 64));
                         }
