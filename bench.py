@@ -9,9 +9,9 @@ layer.forward_gpu launches) over one batch of 64 synthetic uint8 416x416 images 
 the reference's [B][C][H][W] layout.  Images shard embarrassingly over the ranks (weak scaling, 64 per GPU); the only
 collective is a one-time RCCL broadcast of the packed quantized weights at start-up.  Rank 0 prints ONE JSON line.
 
-Batches in flight (--inflight, default 3): the K timed steps are dealt round-robin to that many instances of the prepared
-network on the same GPU (network_replica: own activation tensors, own input batch, own HIP stream; ONE copy of the packed
-weights).  Every step is still one complete forward pass over its own 64 images and all K finish inside the timed region; what
+Batches in flight (--inflight, default 4): the K timed steps are dealt round-robin to that many instances of the prepared
+network on the same GPU (network_replica: own activation tensors, own input batch, own HIP stream -- the fourth on the device's
+default stream, which owns the fourth hardware queue; ONE copy of the packed weights).  Every step is still one complete forward pass over its own 64 images and all K finish inside the timed region; what
 changes is that the device may run kernels of neighbouring steps side by side (one batch's launch gaps, pipeline fills and
 VALU-bound first layers under another batch's MFMA-bound layers).  Per-kernel figures (roofline, --layers) are taken in a serial
 leg right after the timed region (one batch at a time, the kernel alone on the device) and the serial throughput is reported
@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--ref-f32-steps", type=int, default=2)
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the latency-plan leg and the sustained-rate leg (profiling runs)")
     ap.add_argument("--serial-steps", type=int, default=64, help="steps of the serial leg that follows the timed region when --inflight > 1")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BENCH_INFLIGHT", "3")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BENCH_INFLIGHT", "4")),
                     help="batches in flight per GPU: that many network instances (own activations, own HIP stream, same packed weights); "
                          "step i runs on instance i %% inflight, so kernels of consecutive steps overlap on the device")
     ap.add_argument("--selfcheck-passes", type=int, default=48,
@@ -165,6 +165,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getppid() % 2000))  # the launcher sets it; this default only serves BENCH_FORCE_DIST
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # the barriers that bracket the timed region run on the host (gloo): an RCCL barrier is an all-reduce kernel + its launch and
+        # wait, ~0.6 ms measured on one rank -- 10 % of a 20-step region -- and it says nothing a host barrier between ranks that have
+        # each synchronised their device does not
+        try:
+            tgroup = dist.new_group(backend="gloo")
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] gloo group unavailable ({e}); timing barriers stay on RCCL", file=sys.stderr)
+            tgroup = None
 
     from yolo_quantization_amd import binding, synth
     binding.init(local_rank)
@@ -173,6 +181,9 @@ def main():
     if os.environ.get("BENCH_FORCE_TILE"):  # A/B: "bm,bn[,nt]" for every conv_rows launch (mi355_conv_set_tile)
         t = [int(v) for v in os.environ["BENCH_FORCE_TILE"].split(",")]
         binding.shim().mi355_conv_set_tile(t[0] | ((t[2] if len(t) > 2 else 0) << 16), t[1])
+    for _ in range(int(os.environ.get("BENCH_DUMMY_STREAMS", "0"))):  # experiment: streams created before ours shift the stream -> hardware-queue mapping
+        _s = ctypes.c_void_p()
+        binding.shim().mi355_stream_create(ctypes.byref(_s))
     B = args.batch
     wts = f"/tmp/bench_yolov3_tiny_{os.getpid()}.weights"
 
@@ -216,7 +227,9 @@ def main():
     # ---- further batches in flight: instances built from the same packed bytes, each with its own batch of images
     nets = [net]
     for k in range(1, max(1, args.inflight)):
-        nk = net.replica()
+        # the fourth instance runs on the device's default stream: HIP maps every created stream onto three of the device's four
+        # hardware queues and keeps the fourth for that one (a fourth created stream shares a queue: 0.272 -> 0.30 ms per step)
+        nk = net.replica(default_stream=(k == 3 and not args.graph))
         nk.push_input(synth.synth_image_u8(in_c, in_h, in_w, seed=1000 + rank + 7919 * k, batch=B))
         nk.sync()
         nets.append(nk)
@@ -229,11 +242,15 @@ def main():
     plan_name = "throughput (kernels of which two workgroups share a CU)" if plan else "latency (every launch sized to fill the chip alone)"
 
     def barrier():
-        if world > 1 or force_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+        # this rank's own work first (every instance's stream, then the whole device), THEN the cross-rank barrier and a last
+        # device synchronise: the collective's kernel must not run beside the tail of the timed steps (it spins on CUs), and a
+        # rank only enters the barrier when it is done -- the time after it is the slowest rank's
         for nk in nets:
             nk.sync()
+        torch.cuda.synchronize()
+        if world > 1 or force_dist:
+            dist.barrier(group=tgroup) if tgroup is not None else dist.barrier()
+            torch.cuda.synchronize()
 
     # ---- determinism self-check (a race detector for kernels scheduled by hand: counted waits, registers reloaded in place): N passes
     # over the resident input, a device-side checksum of the yolo outputs after each; compared after the timed region, a mismatch
@@ -509,7 +526,7 @@ def main():
                           "global_batch": world * B, "parallelism": f"image-sharded x{world}, RCCL weight broadcast once",
                           "batches_in_flight": ninfl, "kernel_plan": plan_name,
                           "launch": (f"{ninfl} batches in flight per GPU: step i runs on network instance i % {ninfl} (network_replica: own activations, input and "
-                                     "HIP stream; one copy of the packed weights), so the device overlaps the kernels of consecutive steps; every step is one "
+                                     "HIP stream -- the fourth on the default stream, i.e. the fourth hardware queue; one copy of the packed weights), so the device overlaps the kernels of consecutive steps; every step is one "
                                      f"forward pass over its own batch of {B} images; " if ninfl > 1 else "one batch at a time on one stream; ")
                                     + ("hipGraph replay" if args.graph else f"eager launches, per-layer HIP events on every {prof_stride}th forward of instance 0"),
                           "weight_broadcast_ms": round(bcast_ms, 3)},

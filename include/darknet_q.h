@@ -150,6 +150,12 @@ struct network {
     int prepared;
     int range_lo, range_hi; /* diagnostic (tools/layer_flood.py): forward_network_gpu runs layers [range_lo, range_hi) only, on the tensors the
                                last full pass left behind; 0, 0 = the whole network */
+    int on_default_stream; /* this executor launches on the device's default (NULL) stream and owns no stream of its own */
+    int replica_default_stream; /* set before network_replica(): the NEXT replica runs on the default stream.  HIP keeps one of the
+                                   device's four hardware queues for that stream and maps every created stream onto the other three:
+                                   a fourth batch in flight only runs beside the other three from there (bench: 0.2719 -> 0.2671 ms
+                                   per step; a fourth created stream shares a queue with the first: 0.2719 -> 0.30).  Only for hosts
+                                   that put nothing else on the default stream. */
     int plan;             /* MI355_PLAN_*: handed to every conv launch; network_replica switches parent and replica to the throughput plan */
     int has_host_weights; /* load_weights ran: raw weights_uint8 / biases / scales of every layer are on the host */
     int has_l0_weights;   /* imported from a packed exchange: blobs only, plus layer 0's raw record (re-prep on a new input scale) */

@@ -69,6 +69,12 @@ int mi355_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int mi355_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int mi355_stream_create(void **stream);
 int mi355_stream_destroy(void *stream);
+/* A stream that was MEASURED to run side by side with the default stream and with every other acquired stream of the device
+ * (HIP deals created streams round-robin onto the device's four hardware queues, the default stream owns one; streams on one
+ * queue serialise, and which created stream shares whose queue depends on every stream the process created before).  The first
+ * three acquisitions per device come from the measured pool, later ones are plain streams.  Release instead of destroy. */
+int mi355_stream_acquire(void **stream);
+int mi355_stream_release(void *stream);
 int mi355_stream_sync(void *stream);              /* stream == NULL: device synchronize */
 /* HIP events on the launch stream (bench.py times kernels with these, not with torch.cuda.Event) */
 int mi355_event_create(void **ev);

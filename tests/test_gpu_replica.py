@@ -26,7 +26,7 @@ def test_replica_equals_parent_and_runs_concurrently(tmp_path, cfg, batch, hw):
     parent = binding.Net(cfgp, wts, batch=batch)
     parent.prepare_fixed(1.0 / 255.0, 0)
     c, h, w = parent.info[0]["c"], parent.info[0]["h"], parent.info[0]["w"]
-    xs = [synth.synth_image_u8(c, h, w, seed=50 + k, batch=batch) for k in range(3)]
+    xs = [synth.synth_image_u8(c, h, w, seed=50 + k, batch=batch) for k in range(4)]
     # reference results: the parent alone, one input after the other
     want = []
     for x in xs:
@@ -34,12 +34,12 @@ def test_replica_equals_parent_and_runs_concurrently(tmp_path, cfg, batch, hw):
         parent.forward()
         parent.sync()
         want.append(_outputs(parent))
-    reps = [parent.replica(), parent.replica()]
+    reps = [parent.replica(), parent.replica(), parent.replica(default_stream=True)]  # the fourth executor on the default stream
     nets = [parent] + reps
     for nk, x in zip(nets, xs):
         nk.push_input(x)
         nk.sync()
-    for _ in range(6):  # several rounds queued on three streams without synchronisation in between
+    for _ in range(6):  # several rounds queued on four streams without synchronisation in between
         for nk in nets:
             nk.forward()
     for nk in nets:

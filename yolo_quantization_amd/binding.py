@@ -323,9 +323,12 @@ class Net:
     def set(self, key, val):
         assert self.H.dnq_net_set(self.h, key.encode(), int(val)) == 0
 
-    def replica(self):
+    def replica(self, default_stream=False):
         """network_replica: a second executor of this prepared model on the same device (own activations, input and HIP
-        stream; this network's packed weights).  This network must outlive it."""
+        stream; this network's packed weights).  This network must outlive it.  default_stream: the replica launches on the
+        device's default stream (HIP's fourth hardware queue: darknet_q.h replica_default_stream)."""
+        if default_stream:
+            self.set("replica_default_stream", 1)
         r = object.__new__(Net)
         r.H = self.H
         r.h = self.H.network_replica(self.h)

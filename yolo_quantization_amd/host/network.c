@@ -252,7 +252,7 @@ static void plan_views(network *net)
 static void alloc_network_device(network *net)
 {
     check_mi355(mi355_init(net->gpu_index), "mi355_init");
-    if (!net->stream) check_mi355(mi355_stream_create(&net->stream), "stream");
+    if (!net->stream && !net->on_default_stream) check_mi355(mi355_stream_acquire(&net->stream), "stream");
     if (net->input_uint8_gpu) mi355_free(net->input_uint8_gpu);
     if (net->input_t.data) mi355_free(net->input_t.data);
     check_mi355(mi355_alloc((void **)&net->input_uint8_gpu, (size_t)net->batch * net->inputs), "alloc input");
@@ -406,7 +406,7 @@ void quantization_weights_and_activations_gpu(network *net, const float *input_g
 {
     if (!input_gpu) error("quantization_weights_and_activations_gpu: null input");
     check_mi355(mi355_init(net->gpu_index), "mi355_init");
-    if (!net->stream) check_mi355(mi355_stream_create(&net->stream), "stream");
+    if (!net->stream && !net->on_default_stream) check_mi355(mi355_stream_acquire(&net->stream), "stream");
     if (!net->quant_mm_gpu) check_mi355(mi355_alloc((void **)&net->quant_mm_gpu, 2 * sizeof(float)), "alloc minmax");
     float mm[2];
     check_mi355(mi355_image_minmax(input_gpu, net->inputs, net->quant_mm_gpu, net->stream), "mi355_image_minmax");
@@ -442,7 +442,7 @@ void network_letterbox_input_gpu(network *net, int slot, const float *im_gpu, in
 {
     if (slot < 0 || slot >= net->batch || !im_gpu) error("network_letterbox_input_gpu: bad slot / null image");
     check_mi355(mi355_init(net->gpu_index), "mi355_init");
-    if (!net->stream) check_mi355(mi355_stream_create(&net->stream), "stream");
+    if (!net->stream && !net->on_default_stream) check_mi355(mi355_stream_acquire(&net->stream), "stream");
     if (!net->input_gpu)
         check_mi355(mi355_alloc((void **)&net->input_gpu, (size_t)net->batch * net->inputs * sizeof(float)), "alloc float input");
     check_mi355(mi355_letterbox_forward(im_gpu, imw, imh, net->c, net->input_gpu + (size_t)slot * net->inputs, net->w, net->h,
@@ -603,6 +603,7 @@ void forward_network_gpu(network *netp)
     if (!netp->prepared) error("forward_network_gpu before quantization_weights_and_activations");
     if (netp->accum_mode == MI355_ACC_REF_F32 && !netp->has_host_weights)
         error("-accum ref-f32 reads the raw weights_uint8 of every layer; a network imported from packed blobs does not hold them");
+    if (netp->use_graph && netp->on_default_stream) error("use_graph: the default stream cannot be captured; run this executor eagerly");
     if (netp->use_graph) {
         if (!netp->graph) {
             run_layers(netp); /* warm-up outside capture (module load, attribute calls) */
@@ -908,7 +909,7 @@ void network_import_packed_gpu(network *net, const void *dev_buf, size_t bytes)
 void network_bcast_packed(network *net, void *comm, int rank, int root)
 {
     check_mi355(mi355_init(net->gpu_index), "mi355_init");
-    if (!net->stream) check_mi355(mi355_stream_create(&net->stream), "stream");
+    if (!net->stream && !net->on_default_stream) check_mi355(mi355_stream_acquire(&net->stream), "stream");
     const size_t sz = network_packed_size(net);
     void *dev = NULL;
     check_mi355(mi355_alloc(&dev, sz), "alloc packed");
@@ -942,6 +943,8 @@ network *network_replica(network *parent)
     net->dump_int32 = 0;
     if (parent->accum_mode == MI355_ACC_REF_F32) error("network_replica: MI355_ACC_REF_F32 reads raw weights, which a replica does not hold");
     net->replica_of = parent;
+    net->on_default_stream = parent->replica_default_stream; /* one-shot request of the parent (darknet_q.h) */
+    parent->replica_default_stream = 0;
     /* more than one batch in flight from here on: both executors ask the launchers for kernels that share a CU */
     parent->plan = MI355_PLAN_THROUGHPUT;
     if (parent->graph) { mi355_graph_destroy(parent->graph); parent->graph = NULL; } /* captured with the other plan's kernels */
@@ -999,7 +1002,7 @@ void free_network(network *net)
     if (net->input_gpu) mi355_free(net->input_gpu);
     if (net->quant_mm_gpu) mi355_free(net->quant_mm_gpu);
     if (net->selfcheck_gpu) mi355_free(net->selfcheck_gpu);
-    if (net->stream) mi355_stream_destroy(net->stream);
+    if (net->stream) mi355_stream_release(net->stream);
     free(net->layers); free(net->input); free(net->input_uint8); free(net->seen); free(net->cfg_path);
     free(net);
 }
