@@ -6,7 +6,7 @@
              device may overlap the launches with each other.
 The sum of the flood column is what a step would cost if mixing different layers bought nothing beyond overlapping a layer
 with itself; the in-flight step of bench.py sits next to it.
-usage: tools/layer_flood.py [--cfg ...] [--batch 64] [--inflight 3] [--plan 1] [--reps 60]"""
+usage: tools/layer_flood.py [--cfg ...] [--batch 64] [--inflight 4] [--plan 1] [--reps 60]"""
 import argparse
 import os
 import sys
@@ -19,7 +19,7 @@ from yolo_quantization_amd import binding, synth  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cfg", default=os.path.join(ROOT, "cfg", "yolov3-tiny_quant.cfg"))
 ap.add_argument("--batch", type=int, default=64)
-ap.add_argument("--inflight", type=int, default=3)
+ap.add_argument("--inflight", type=int, default=4)
 ap.add_argument("--plan", type=int, default=1)
 ap.add_argument("--reps", type=int, default=60)
 a = ap.parse_args()
@@ -33,7 +33,7 @@ wts = f"/tmp/flood_{os.getpid()}.weights"
 synth.synth_weights(a.cfg, wts, seed=1234)
 net = binding.Net(a.cfg, wts, batch=a.batch, keep_head_float=False)
 net.prepare_fixed(1.0 / 255.0, 0)
-nets = [net] + [net.replica() for _ in range(a.inflight - 1)]
+nets = [net] + [net.replica(default_stream=(k == 3)) for k in range(1, a.inflight)]  # the fourth instance on the default stream, as in bench.py
 info = net.info
 for k, nk in enumerate(nets):
     nk.set("plan", a.plan)
