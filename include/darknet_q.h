@@ -161,6 +161,7 @@ struct network {
     int has_l0_weights;   /* imported from a packed exchange: blobs only, plus layer 0's raw record (re-prep on a new input scale) */
     char *cfg_path;       /* the cfg this network was parsed from (network_replica parses it again) */
     struct network *replica_of; /* non-NULL: a replica (network_replica): packed weights on the device are the parent's */
+    int n_replicas;             /* live replicas of this network: it cannot be freed, re-batched or re-prepared while > 0 */
     uint64_t *selfcheck_gpu; /* [passes] checksums of the pending self-check */
     int selfcheck_passes;
     void *graph; /* hipGraph of the layer loop, built lazily when use_graph */

@@ -370,6 +370,7 @@ static void plan_fusion(network *net)
 
 void quantization_weights_and_activations_fixed_input(network *net, float in_scale, uint8_t in_zp)
 {
+    if (net->n_replicas > 0 || net->replica_of) error("quantization_weights_and_activations: not while replicas share this network's packed weights");
     quantization_prep_host(net, in_scale, in_zp);
     plan_fusion(net);
     alloc_network_device(net);
@@ -419,6 +420,7 @@ void quantization_weights_and_activations_gpu(network *net, const float *input_g
         quantization_weights_and_activations_fixed_input(net, s, zp);
     } else if (l0->input_data_uint8_scales[0] != s || l0->input_data_uint8_zero_point[0] != zp) {
         if (net->replica_of) error("the input scale changed: a replica shares its parent's layer-0 blob and cannot re-derive it");
+        if (net->n_replicas > 0) error("the input scale changed: layer 0's blob is shared with replicas that may be running; free them first");
         if (!net->has_host_weights && !net->has_l0_weights)
             error("the input scale changed but this network holds no raw layer-0 weights to re-derive layer 0 from");
         const int zp_changed = l0->input_data_uint8_zero_point[0] != zp;
@@ -460,6 +462,7 @@ void set_batch_network(network *net, int b)
     if (b < 1) error("set_batch_network: batch < 1");
     if (b == net->batch && net->prepared) return;
     if (net->replica_of) error("set_batch_network on a replica: re-batch the parent and make new replicas");
+    if (net->n_replicas > 0) error("set_batch_network: free this network's replicas first (they borrow its packed weights on the device)");
     net->batch = b;
     free(net->input); free(net->input_uint8);
     net->input = calloc((size_t)net->inputs * b, sizeof(float));
@@ -884,6 +887,7 @@ void network_load_packed(network *net, char *filename)
 
 void network_import_packed(network *net, const void *buf, size_t bytes)
 {
+    if (net->n_replicas > 0 || net->replica_of) error("network_import_packed: not while replicas share this network's packed weights");
     network_import_packed_host(net, buf, bytes);
     plan_fusion(net);
     alloc_network_device(net);
@@ -943,6 +947,7 @@ network *network_replica(network *parent)
     net->dump_int32 = 0;
     if (parent->accum_mode == MI355_ACC_REF_F32) error("network_replica: MI355_ACC_REF_F32 reads raw weights, which a replica does not hold");
     net->replica_of = parent;
+    parent->n_replicas++;
     net->on_default_stream = parent->replica_default_stream; /* one-shot request of the parent (darknet_q.h) */
     parent->replica_default_stream = 0;
     /* more than one batch in flight from here on: both executors ask the launchers for kernels that share a CU */
@@ -984,6 +989,8 @@ network *network_replica(network *parent)
 void free_network(network *net)
 {
     if (!net) return;
+    if (net->n_replicas > 0) error("free_network: free this network's replicas first (they borrow its packed weights on the device)");
+    if (net->replica_of) net->replica_of->n_replicas--;
     for (int i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];
         free_layer_device(l);
