@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--cpu-omp", action="store_true", help="also time the reference's OpenMP build on all host cores (extra JSON key)")
     ap.add_argument("--no-ref-f32", action="store_true", help="skip the extra leg that times the bit-faithful MI355_ACC_REF_F32 mode")
     ap.add_argument("--ref-f32-steps", type=int, default=2)
+    ap.add_argument("--inflight-events", action="store_true",
+                    help="with batches in flight: also record per-layer events on instance 0 inside the timed region (roofline.in_flight); they "
+                         "cost ~0.1 ms of a profiled step and measure launches that share their CUs, so they are off by default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the latency-plan leg and the sustained-rate leg (profiling runs)")
     ap.add_argument("--serial-steps", type=int, default=64, help="steps of the serial leg that follows the timed region when --inflight > 1")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("BENCH_INFLIGHT", "4")),
@@ -281,7 +284,7 @@ def main():
         net.profile_begin(n, prof_stride, phase)
         return n
 
-    prof_steps = arm_events((args.steps + ninfl - 1) // ninfl)
+    prof_steps = arm_events((args.steps + ninfl - 1) // ninfl) if (ninfl == 1 or args.inflight_events) else arm_events(0)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -528,7 +531,9 @@ def main():
                           "launch": (f"{ninfl} batches in flight per GPU: step i runs on network instance i % {ninfl} (network_replica: own activations, input and "
                                      "HIP stream -- the fourth on the default stream, i.e. the fourth hardware queue; one copy of the packed weights), so the device overlaps the kernels of consecutive steps; every step is one "
                                      f"forward pass over its own batch of {B} images; " if ninfl > 1 else "one batch at a time on one stream; ")
-                                    + ("hipGraph replay" if args.graph else f"eager launches, per-layer HIP events on every {prof_stride}th forward of instance 0"),
+                                    + ("hipGraph replay" if args.graph else
+                                       (f"eager launches, per-layer HIP events on every {prof_stride}th forward of instance 0" if (ninfl == 1 or args.inflight_events)
+                                        else "eager launches, no events inside the timed region (per-kernel figures come from the serial leg after it)")),
                           "weight_broadcast_ms": round(bcast_ms, 3)},
                "roofline": roof, "serial": serial, "cpu_baseline": cpu, "accum_ref_f32_mode": ref_f32, "selfcheck": selfcheck}
         if cpu_omp:
