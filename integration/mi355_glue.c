@@ -119,7 +119,7 @@ void mi355_bind_network(network *net, int gpu, int accum_mode, int store_mode)
     G.net = net;
     G.accum_mode = accum_mode; G.store_mode = store_mode;
     G.ls = calloc(net->n, sizeof(mi355_layer_state));
-    chk(mi355_stream_create(&G.stream), "stream");
+    chk(mi355_stream_acquire(&G.stream), "stream"); /* a stream measured to run beside the default stream and other acquired ones */
     chk(mi355_alloc((void **)&G.input_nchw, (size_t)net->batch * net->inputs), "alloc input");
     size_t bytes = mi355_tensor_describe(&G.input, net->batch, net->h, net->w, net->c);
     chk(mi355_alloc(&G.input.data, bytes), "alloc input tensor");
@@ -210,7 +210,7 @@ void mi355_unbind_network(network *net)
     }
     mi355_free(G.input_nchw);
     mi355_free(G.input.data);
-    mi355_stream_destroy(G.stream);
+    mi355_stream_release(G.stream);
     free(G.ls);
     memset(&G, 0, sizeof(G));
 }

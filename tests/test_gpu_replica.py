@@ -121,3 +121,31 @@ def test_layer_range_reruns_one_layer_in_place(tmp_path):
     for i, v in yolo.items():
         assert np.array_equal(net.pull(i)["f32"], v), f"yolo {i}"
     net.close()
+
+
+def test_stream_pool_hands_out_streams_that_run_side_by_side():
+    """mi355_stream_acquire: the first three streams per device come from the measured pool (distinct, reusable after release);
+    whatever was created before them -- here two plain streams -- does not change that"""
+    import ctypes as C
+    import time
+    binding.init(0)
+    S = binding.shim()
+    junk = [C.c_void_p() for _ in range(2)]
+    for j in junk:
+        binding.check(S.mi355_stream_create(C.byref(j)), "create")
+    got = [C.c_void_p() for _ in range(4)]
+    for g in got:
+        binding.check(S.mi355_stream_acquire(C.byref(g)), "acquire")
+    vals = [g.value for g in got]
+    assert len(set(vals)) == 4 and all(vals)
+    # streams in use elsewhere (another network of this process) may hold pool slots: release ours and take them again
+    for g in got:
+        binding.check(S.mi355_stream_release(g), "release")
+    again = [C.c_void_p() for _ in range(3)]
+    for g in again:
+        binding.check(S.mi355_stream_acquire(C.byref(g)), "acquire")
+    assert len({g.value for g in again}) == 3
+    for g in again:
+        binding.check(S.mi355_stream_release(g), "release")
+    for j in junk:
+        binding.check(S.mi355_stream_destroy(j), "destroy")

@@ -55,6 +55,8 @@ def shim():
         for n in ("mi355_h2d", "mi355_d2h", "mi355_d2d"):
             getattr(L, n).argtypes = [vp, vp, sz, vp]
         L.mi355_stream_create.argtypes = [C.POINTER(vp)]
+        L.mi355_stream_acquire.argtypes = [C.POINTER(vp)]
+        L.mi355_stream_release.argtypes = [vp]
         L.mi355_stream_destroy.argtypes = [vp]
         L.mi355_stream_sync.argtypes = [vp]
         L.mi355_event_create.argtypes = [C.POINTER(vp)]
