@@ -22,6 +22,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--inflight", type=int, default=4)
 ap.add_argument("--plan", type=int, default=1)
 ap.add_argument("--reps", type=int, default=60)
+ap.add_argument("--power", action="store_true", help="sample the device's socket power and shader clock (hwmon) during every flood phase (use --reps 2000+)")
 a = ap.parse_args()
 binding.init(0)
 if os.environ.get("BENCH_FORCE_TILE"):  # "bm,bn[,nt]" for every conv_rows launch
@@ -43,6 +44,46 @@ for k, nk in enumerate(nets):
     nk.sync()
 
 
+import glob
+import threading
+
+
+class Sampler:
+    """mean socket power (W) and shader clock (MHz) of THIS device from its hwmon files while a phase runs"""
+    def __init__(self):
+        self.dir = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(0)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            d = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            self.dir = d[0] if d else None
+        except Exception as e:  # noqa: BLE001
+            print("power sampler unavailable:", e)
+
+    def run(self, fn):
+        if not self.dir:
+            return fn(), None, None
+        stop = [False]
+        pw, ck = [], []
+
+        def loop():
+            while not stop[0]:
+                try:
+                    pw.append(int(open(self.dir + "/power1_input").read()) / 1e6)
+                    ck.append(int(open(self.dir + "/freq1_input").read()) / 1e6)
+                except Exception:  # noqa: BLE001
+                    pass
+                time.sleep(0.005)
+        t = threading.Thread(target=loop)
+        t.start()
+        r = fn()
+        stop[0] = True
+        t.join()
+        half = len(pw) // 2  # the second half: the sensor averages over a window
+        return r, (sum(pw[half:]) / max(len(pw[half:]), 1)), (sum(ck[half:]) / max(len(ck[half:]), 1))
+
+
 def timed(ns, reps):
     for nk in ns:
         nk.sync()
@@ -59,6 +100,7 @@ def timed(ns, reps):
 convs = [i for i, inf in enumerate(info) if inf["type"] == binding.T_CONV]
 groups = [(c, (convs[k + 1] if k + 1 < len(convs) else len(info))) for k, c in enumerate(convs)]
 tot_s = tot_f = 0.0
+sampler = Sampler() if a.power else None
 print(f"plan {a.plan}, {a.inflight} instances, batch {a.batch}")
 print("| layers | conv | serial us | flood us per launch | flood / serial |")
 print("|---|---|---|---|---|")
@@ -66,16 +108,27 @@ for lo, hi in groups:
     for nk in nets:
         nk.set("range_lo", lo); nk.set("range_hi", hi)
     timed(nets, 5)
-    ts = timed(nets[:1], a.reps)
-    tf = timed(nets, a.reps)
+    ts = timed(nets[:1], min(a.reps, 200))
+    extra = ""
+    if sampler:
+        tf, pw, ck = sampler.run(lambda: timed(nets, a.reps))
+        extra = f" {pw:.0f} W, {ck:.0f} MHz |" if pw is not None else ""
+    else:
+        tf = timed(nets, a.reps)
     tot_s += ts; tot_f += tf
     inf = info[lo]
-    print(f"| {lo}..{hi - 1} | {inf['size']}x{inf['size']} {inf['c']}->{inf['n']} @{inf['out_h']} | {ts:.1f} | {tf:.1f} | {tf / ts:.2f} |")
+    print(f"| {lo}..{hi - 1} | {inf['size']}x{inf['size']} {inf['c']}->{inf['n']} @{inf['out_h']} | {ts:.1f} | {tf:.1f} | {tf / ts:.2f} |" + extra)
 for nk in nets:
     nk.set("range_lo", 0); nk.set("range_hi", 0)
 timed(nets, 10)
 step_s = timed(nets[:1], a.reps)
-step_f = timed(nets, a.reps)
+if sampler:
+    step_f, pw, ck = sampler.run(lambda: timed(nets, a.reps))
+    print(f"whole step in flight: {pw:.0f} W, {ck:.0f} MHz" if pw is not None else "no power data")
+    _, pw1, ck1 = sampler.run(lambda: timed(nets[:1], a.reps))
+    print(f"whole step, one batch at a time: {pw1:.0f} W, {ck1:.0f} MHz" if pw1 is not None else "")
+else:
+    step_f = timed(nets, a.reps)
 print(f"| sum | | {tot_s:.1f} | {tot_f:.1f} | {tot_f / tot_s:.2f} |")
 print(f"| whole step | | {step_s:.1f} | {step_f:.1f} | {step_f / step_s:.2f} |")
 for nk in reversed(nets):
