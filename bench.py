@@ -172,6 +172,7 @@ def main():
         # wait, ~0.6 ms measured on one rank -- 10 % of a 20-step region -- and it says nothing a host barrier between ranks that have
         # each synchronised their device does not
         try:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node; the container's hostname may not resolve
             tgroup = dist.new_group(backend="gloo")
         except Exception as e:  # noqa: BLE001
             print(f"[bench] gloo group unavailable ({e}); timing barriers stay on RCCL", file=sys.stderr)
