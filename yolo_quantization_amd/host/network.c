@@ -990,7 +990,11 @@ void free_network(network *net)
 {
     if (!net) return;
     if (net->n_replicas > 0) error("free_network: free this network's replicas first (they borrow its packed weights on the device)");
-    if (net->replica_of) net->replica_of->n_replicas--;
+    if (net->replica_of && --net->replica_of->n_replicas == 0) { /* the parent is alone on the device again: whole-chip kernels */
+        network *parent = net->replica_of;
+        parent->plan = MI355_PLAN_LATENCY;
+        if (parent->graph) { mi355_graph_destroy(parent->graph); parent->graph = NULL; }
+    }
     for (int i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];
         free_layer_device(l);
