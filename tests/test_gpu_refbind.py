@@ -153,6 +153,12 @@ def test_cli_detector_test_on_a_non_network_sized_image(cfg_dir, tmp_path):
     _write_ppm(ppm2, rng.integers(0, 256, (480, 640, 3), dtype=np.uint8))
     r4 = subprocess.run([exe, "detector", "test", data, cfg2, wts2, ppm2, "-thresh", "0.5"], capture_output=True, text=True, timeout=300)
     assert r4.returncode == 0 and "Predicted in" in r4.stdout, r4.stderr
+    # several batches in flight from plain C: four executors (network_replica), same detections as the single pass
+    r5 = subprocess.run([exe, "detector", "test", data, cfg2, wts2, ppm2, "-thresh", "0.5", "-boxes", "-batch", "8", "-n", "3", "-inflight", "4"],
+                        capture_output=True, text=True, timeout=300)
+    assert r5.returncode == 0 and "4 batches in flight" in r5.stdout, r5.stderr
+    r6 = subprocess.run([exe, "detector", "test", data, cfg2, wts2, ppm2, "-thresh", "0.5", "-boxes", "-batch", "8"], capture_output=True, text=True, timeout=300)
+    assert [l for l in r5.stdout.splitlines() if l.startswith("box:")] == [l for l in r6.stdout.splitlines() if l.startswith("box:")]
 
 
 def test_c_abi_rccl_broadcast_world1(cfg_dir, tmp_path):

@@ -16,7 +16,9 @@
  * (rejected: float path not built).  Added: -batch <B> (replicates the image), -accum exact|ref-f32,
  * -parity wrap|saturate, -dump <dir> (per-layer tensors in the reference layout), -graph (hipGraph replay), -n <iters>,
  * -save_packed <file> / -packed <file>, -boxes (one machine-readable line per kept box), -bcast (with
- * -gpus: replica 0 reads the weights file, the others receive the packed blobs by one RCCL broadcast over xGMI).
+ * -gpus: replica 0 reads the weights file, the others receive the packed blobs by one RCCL broadcast over xGMI),
+ * -inflight <N> (with -n <iters>: after the timed passes, the same passes dealt round-robin to N executors of the prepared
+ * model -- network_replica: own activations and stream, shared packed weights; the 4th on the default stream -- and their rate).
  *
  * Image input: binary PPM (P6) of ANY size (letterboxed like the reference does), a raw `.u8` file holding [c][h][w] bytes at
  * network size, or `synthetic:<seed>`.  JPEG/PNG decoding is third-party code in the reference (stb_image, SURVEY.md 2
@@ -114,7 +116,7 @@ static void dump_layer(const char *dir, network *net, int i)
 typedef struct {
     const char *datacfg, *cfgfile, *weightfile, *filename, *dumpdir, *packed_in, *packed_out;
     float thresh, hier_thresh;
-    int batch, accum, store, use_graph, iters, gpu, boxes, quiet;
+    int batch, accum, store, use_graph, iters, gpu, boxes, quiet, inflight;
     int rank, nranks;      /* -gpus with -bcast: this replica's rank; rank 0 reads the weights file, the others receive blobs */
     const void *comm_id;   /* shared 128-byte RCCL unique id (NULL: every replica reads the file) */
     double seconds; /* out: per forward pass */
@@ -174,6 +176,28 @@ static void test_detector(detect_job *job)
                job->batch, job->batch / job->seconds, job->gpu, job->accum == MI355_ACC_EXACT ? "exact" : "ref-f32",
                job->store == MI355_STORE_WRAP ? "wrap" : "saturate");
 
+    if (job->inflight > 1 && job->accum == MI355_ACC_EXACT && !job->dumpdir) { /* several batches in flight (darknet_q.h network_replica) */
+        const int n = job->inflight > 8 ? 8 : job->inflight;
+        network *ex[8] = {net};
+        for (int k = 1; k < n; ++k) {
+            net->replica_default_stream = (k == 3 && !job->use_graph); /* the fourth hardware queue belongs to the default stream */
+            ex[k] = network_replica(net);
+            if (mi355_d2d(ex[k]->input_uint8_gpu, net->input_uint8_gpu, (size_t)net->batch * net->inputs, ex[k]->stream) ||
+                mi355_stream_sync(ex[k]->stream)) error("replica input");
+        }
+        const int passes = job->iters * n;
+        for (int k = 0; k < n; ++k) forward_network_gpu(ex[k]); /* the throughput plan's kernels: first launch outside the timing */
+        for (int k = 0; k < n; ++k) if (mi355_stream_sync(ex[k]->stream)) error("sync");
+        const double t1 = what_time_is_it_now();
+        for (int it = 0; it < passes; ++it) forward_network_gpu(ex[it % n]);
+        for (int k = 0; k < n; ++k) if (mi355_stream_sync(ex[k]->stream)) error("sync");
+        const double dt = (what_time_is_it_now() - t1) / passes;
+        if (!job->quiet)
+            printf("%d batches in flight: %f seconds per pass (batch %d, %.1f images/s, gpu %d)\n", n, dt, job->batch, job->batch / dt, job->gpu);
+        job->seconds = dt;
+        for (int k = n - 1; k >= 1; --k) free_network(ex[k]);
+    }
+
     int classes = 0;
     for (int i = 0; i < net->n; ++i)
         if (net->layers[i].type == YOLO) classes = net->layers[i].classes; /* ref: `l = net->layers[net->n-1]` (:910) */
@@ -214,7 +238,7 @@ int main(int argc, char **argv)
     if (argc < 2) {
         fprintf(stderr, "usage: %s detector test <data> <cfg> <weights> <image> [-thresh t] [-i gpu | -gpus a,b,..] [-batch B] "
                         "[-accum exact|ref-f32] [-parity wrap|saturate] [-dump dir] [-graph] [-n iters] [-boxes] "
-                        "[-save_packed file] [-packed file] [-bcast]\n", argv[0]);
+                        "[-save_packed file] [-packed file] [-bcast] [-inflight N]\n", argv[0]);
         return 0;
     }
     detect_job job;
@@ -235,6 +259,7 @@ int main(int argc, char **argv)
     job.boxes = find_arg(argc, argv, "-boxes");
     const int bcast = find_arg(argc, argv, "-bcast");
     job.iters = atoi(find_char_arg(argc, argv, "-n", "1"));
+    job.inflight = atoi(find_char_arg(argc, argv, "-inflight", "1"));
     if (job.iters < 1) job.iters = 1;
     if (job.batch < 1) job.batch = 1;
     job.accum = 0 == strcmp(accum_s, "ref-f32") ? MI355_ACC_REF_F32 : MI355_ACC_EXACT;
