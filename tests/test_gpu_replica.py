@@ -149,3 +149,36 @@ def test_stream_pool_hands_out_streams_that_run_side_by_side():
         binding.check(S.mi355_stream_release(g), "release")
     for j in junk:
         binding.check(S.mi355_stream_destroy(j), "destroy")
+
+
+@pytest.mark.parametrize("c,n,hw,batch,replanned", [(256, 512, 13, 64, True), (512, 1024, 13, 32, True), (128, 256, 76, 16, False),
+                                                    (512, 1024, 19, 16, False)])
+def test_plan_hint_on_single_convs(c, n, hw, batch, replanned):
+    """mi355_conv_desc.plan through the C-ABI on single launches: one-round launches on well-filled row images are re-planned (other
+    kernel family or tile, same bytes), launches of several rounds and badly filled row images (19-wide maps) keep their kernel"""
+    C = binding.C
+    S = binding.shim()
+    binding.init(0)
+    rng = np.random.default_rng(c + n + hw)
+    x = rng.integers(0, 256, (batch, c, hw, hw), dtype=np.uint8)
+    K = c * 9
+    wq = rng.integers(0, 256, (n, K), dtype=np.uint8)
+    zp_w = rng.integers(100, 157, n, dtype=np.uint8)
+    bias = rng.integers(-2000, 2000, n).astype(np.int32)
+    mv = np.full(n, 0.75); sv = np.full(n, 2.0 ** -13)
+    xt = binding.DevTensor.from_nchw(x, 0)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv))
+    out, fam = {}, {}
+    for plan in (0, 1):
+        y = binding.DevTensor(batch, hw, hw, n, 23)
+        d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT["leaky"], binding.STORE_WRAP, binding.ACC_EXACT, 0, 23, 1.0, plan)
+        binding.check(S.mi355_conv_forward(C.byref(d), xt.ref(), blob.ptr, None, None, y.ref(), None, None, None), "conv")
+        binding.check(S.mi355_stream_sync(None), "sync")
+        fam[plan] = S.mi355_last_conv_kernel()
+        out[plan] = y.to_nchw()
+    assert np.array_equal(out[0], out[1]), "the plans disagree"
+    if c in (128, 256):
+        assert fam[0] == 4                      # conv_ws3 alone on the device
+        assert fam[1] == (5 if replanned else 4)
+    else:
+        assert fam[0] == 5 and fam[1] == 5      # row-image kernel either way (tile 128 x 384 or 128 x 128)
