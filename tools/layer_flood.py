@@ -22,6 +22,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--inflight", type=int, default=4)
 ap.add_argument("--plan", type=int, default=1)
 ap.add_argument("--reps", type=int, default=60)
+ap.add_argument("--by-shape", action="store_true", help="one row per distinct conv shape (sums over its layer groups): for the deep nets")
 ap.add_argument("--power", action="store_true", help="sample the device's socket power and shader clock (hwmon) during every flood phase (use --reps 2000+)")
 a = ap.parse_args()
 binding.init(0)
@@ -100,6 +101,7 @@ def timed(ns, reps):
 convs = [i for i, inf in enumerate(info) if inf["type"] == binding.T_CONV]
 groups = [(c, (convs[k + 1] if k + 1 < len(convs) else len(info))) for k, c in enumerate(convs)]
 tot_s = tot_f = 0.0
+shapes = {}
 sampler = Sampler() if a.power else None
 print(f"plan {a.plan}, {a.inflight} instances, batch {a.batch}")
 print("| layers | conv | serial us | flood us per launch | flood / serial |")
@@ -117,7 +119,14 @@ for lo, hi in groups:
         tf = timed(nets, a.reps)
     tot_s += ts; tot_f += tf
     inf = info[lo]
-    print(f"| {lo}..{hi - 1} | {inf['size']}x{inf['size']} {inf['c']}->{inf['n']} @{inf['out_h']} | {ts:.1f} | {tf:.1f} | {tf / ts:.2f} |" + extra)
+    key = (inf["size"], inf["c"], inf["n"], inf["out_h"], hi - lo)
+    e = shapes.setdefault(key, [0, 0.0, 0.0]); e[0] += 1; e[1] += ts; e[2] += tf
+    if not a.by_shape:
+        print(f"| {lo}..{hi - 1} | {inf['size']}x{inf['size']} {inf['c']}->{inf['n']} @{inf['out_h']} | {ts:.1f} | {tf:.1f} | {tf / ts:.2f} |" + extra)
+if a.by_shape:
+    for (k, c, n, hw, span), (cnt, ts, tf) in sorted(shapes.items(), key=lambda kv: -kv[1][2]):
+        ops = 2.0 * n * c * k * k * hw * hw * a.batch
+        print(f"| {cnt} x ({span} layers) | {k}x{k} {c}->{n} @{hw} | {ts:.1f} | {tf:.1f} | {tf / ts:.2f} | {ops / (tf / cnt) / 1e6:.0f} TOP/s sustained |")
 for nk in nets:
     nk.set("range_lo", 0); nk.set("range_hi", 0)
 timed(nets, 10)
