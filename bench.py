@@ -42,7 +42,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8, help="bounded CPU-baseline sample (images through the reference)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
-    ap.add_argument("--cpu-omp", action="store_true", help="also time the reference's OpenMP build on all host cores (extra JSON key)")
+    ap.add_argument("--cpu-omp", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-cpu-omp", action="store_true", help="skip the all-cores leg of the CPU baseline (the reference's MULTI_CORE=1 OpenMP build)")
+    ap.add_argument("--cpu-omp-images", type=int, default=4, help="bounded sample of the all-cores leg")
     ap.add_argument("--no-ref-f32", action="store_true", help="skip the extra leg that times the bit-faithful MI355_ACC_REF_F32 mode")
     ap.add_argument("--ref-f32-steps", type=int, default=2)
     ap.add_argument("--inflight-events", action="store_true",
@@ -53,6 +55,10 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("BENCH_INFLIGHT", "4")),
                     help="batches in flight per GPU: that many network instances (own activations, own HIP stream, same packed weights); "
                          "step i runs on instance i %% inflight, so kernels of consecutive steps overlap on the device")
+    ap.add_argument("--dry-dist", action="store_true",
+                    help="CPU dry run of the multi-rank start-up (no GPU needed): the same launcher, rendezvous, packed-weights broadcast, image "
+                         "sharding and max-over-ranks timing code on the gloo backend, host-only prep; rank 0 prints one JSON line and the "
+                         "exit code is 0 only when every rank ends up with byte-identical packed state")
     ap.add_argument("--selfcheck-passes", type=int, default=48,
                     help="determinism self-check before the warmup steps: that many passes over the input, yolo-output checksums compared (0: off)")
     return ap.parse_args()
@@ -62,12 +68,52 @@ METRICS = {"yolov3-tiny_quant.cfg": "images/sec yolov3-tiny INT8 416x416", "yolo
 
 
 def conv_layer_work(info, batch):
-    """Algorithmic ops / bytes of one conv launch: 2*M*K*N ops, uint8 in + weights + uint8 out."""
+    """Algorithmic ops of one conv launch: 2*M*K*N, and the UNFUSED byte count uint8 in + weights + uint8 out
+    (what the layer would move as a launch of its own; launch_bytes() below is what the launch that really runs has to move)."""
     K = info["c"] * info["size"] * info["size"]
     N = info["out_h"] * info["out_w"] * batch
     ops = 2.0 * info["n"] * K * N
     byt = info["c"] * info["h"] * info["w"] * batch + info["n"] * K + info["n"] * N
     return ops, byt
+
+
+def launch_bytes(net, i, batch):
+    """Algorithmic HBM bytes (read, written) of the launch that serves layer i as the host planned it: input tensor + weights read; only
+    the tensors the launch STORES written -- a conv fused with its maxpool / upsample / yolo layer stores that layer's tensor and not
+    its own (unless a route also reads it), a fused residual add also reads the `from` tensor.  VERDICT r03: the unfused figure
+    counted L0's 177 MB pre-pool tensor, which never leaves the CU."""
+    from yolo_quantization_amd import binding
+    inf = net.info[i]
+    if inf["type"] == binding.T_CONV:
+        rd = inf["c"] * inf["h"] * inf["w"] * batch + inf["n"] * inf["c"] * inf["size"] * inf["size"]
+        own = inf["n"] * inf["out_h"] * inf["out_w"] * batch
+        if net.fuses_next(i):
+            nx = net.info[i + 1]
+            wr = 0 if net.is_fused(i) else own
+            if nx["type"] == binding.T_YOLO:
+                wr += 4 * nx["outputs"] * batch            # float activations of the yolo layer
+            elif nx["type"] == binding.T_SHORTCUT:
+                rd += nx["outputs"] * batch
+                wr += nx["outputs"] * batch
+            else:                                          # maxpool / upsample
+                wr += nx["outputs"] * batch
+        else:
+            wr = own + (4 * own if inf["quant_stop"] else 0)
+        return rd, wr
+    if inf["type"] in (binding.T_MAXPOOL, binding.T_UPSAMPLE, binding.T_ROUTE):
+        return inf["c"] * inf["h"] * inf["w"] * batch, inf["outputs"] * batch
+    if inf["type"] == binding.T_SHORTCUT:
+        return 2 * inf["outputs"] * batch, inf["outputs"] * batch
+    return 0, 0
+
+
+def pmc_kernel_rows():
+    """rows of the newest COMMITTED rocprofv3 PMC traffic summary (profiles/*_pmc_traffic.json) + its path"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))  # rNN_vM_...: the name orders them
+    if not files:
+        return [], None
+    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
 
 
 def pmc_traffic_per_launch():
@@ -145,15 +191,149 @@ def flush_c_stdio():
         pass
 
 
+class StdoutGuard:
+    """Everything any library writes to file descriptor 1 while the bench runs (RCCL's version banner, gloo's "[Gloo] Rank .." lines from
+    C++ iostreams) goes to stderr; `emit` puts the ONE JSON line on the real stdout."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line):
+        flush_c_stdio()
+        os.dup2(self.saved, 1)
+        print(line, flush=True)
+        os.dup2(2, 1)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): re-run this command under torch.distributed.run,
+    one rank per GPU on this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve).  Rank 0 of the child job
+    prints the ONE JSON line on the inherited stdout; the launcher's exit code is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] no launcher around --gpus %d: re-running as  %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dist_init(backend, rank, world, dev=None):
+    """Rendezvous (env:// on 127.0.0.1) + the host-side group the timing barriers run on.  Returns (dist, timing group or None)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getppid() % 2000))  # the launcher sets it; this default only serves BENCH_FORCE_DIST
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node; the container's hostname may not resolve
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # the barriers that bracket the timed region run on the host (gloo): an RCCL barrier is an all-reduce kernel + its launch and
+        # wait, ~0.6 ms measured on one rank -- 10 % of a 20-step region -- and it says nothing a host barrier between ranks that have
+        # each synchronised their device does not
+        try:
+            tgroup = dist.new_group(backend="gloo")
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] gloo group unavailable ({e}); timing barriers stay on RCCL", file=sys.stderr)
+            tgroup = None
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        tgroup = None
+    return dist, tgroup
+
+
+def bcast_packed(dist, torch, rank, packed, dev):
+    """The one collective of the path: rank 0's packed quantized weights (network_export_packed bytes) to every rank.  `dev` = the
+    rank's cuda device (RCCL over xGMI) or None (gloo, host tensors: the CPU dry run and tests).  Returns (uint8 tensor, ms)."""
+    size_t = torch.tensor([packed.size if rank == 0 else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(size_t, 0)
+    nbytes = int(size_t.item())
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        blob.copy_(torch.from_numpy(packed))
+    if dev is not None:
+        torch.cuda.synchronize()
+    t0 = time.time()
+    dist.broadcast(blob, 0)
+    if dev is not None:
+        torch.cuda.synchronize()
+    return blob, (time.time() - t0) * 1e3
+
+
+def image_shard(rank, world, batch):
+    """global image indices [start, stop) of this rank's batch: weak scaling, `batch` images per rank (sharding.shard_range)"""
+    from yolo_quantization_amd.sharding import shard_range
+    return shard_range(world * batch, rank, world)
+
+
+def dry_dist(args, rank, world):
+    """--dry-dist: the multi-rank start-up on CPU (gloo, host-only prep, no kernels).  Everything bench.py does across ranks runs: rendezvous,
+    rank 0 reads + preps + packs, broadcast of the packed bytes, import on the other ranks, image sharding, barrier-bracketed timed region
+    (empty steps) with the MAX over ranks.  Checked: every rank's re-exported packed state has rank 0's SHA-256; shards are disjoint and
+    cover the global batch."""
+    import hashlib
+    import numpy as np
+    import torch
+    from yolo_quantization_amd import binding, synth
+    guard = StdoutGuard()
+    dist, tgroup = dist_init("gloo", rank, world)
+    wts = f"/tmp/bench_dry_{os.getpid()}.weights"
+    if rank == 0:
+        synth.synth_weights(args.cfg, wts, seed=1234)
+        net = binding.Net(args.cfg, wts, batch=args.batch)
+        net.prepare_host_only(1.0 / 255.0, 0)
+        packed = net.export_packed()
+    else:
+        net = binding.Net(args.cfg, None, batch=args.batch)
+        packed = None
+    blob, bcast_ms = bcast_packed(dist, torch, rank, packed, None)
+    if rank != 0:
+        net.import_packed_host(blob.numpy())
+    digest = hashlib.sha256(net.export_packed().tobytes()).digest()
+    mine = torch.tensor(list(digest) + list(image_shard(rank, world, args.batch)), dtype=torch.int64)
+    everyone = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    dist.barrier(group=tgroup) if tgroup is not None else dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass  # a step launches kernels; there is no GPU here
+    dist.barrier(group=tgroup) if tgroup is not None else dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    same = all(bool((e[:32] == everyone[0][:32]).all()) for e in everyone)
+    spans = [(int(e[32]), int(e[33])) for e in everyone]
+    covered = sorted(spans) == [(r * args.batch, (r + 1) * args.batch) for r in range(world)]
+    net.close()
+    if rank == 0:
+        os.remove(wts)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        guard.emit(json.dumps({"dry_dist": True, "n_gpus": world, "backend": "gloo", "packed_bytes": int(blob.numel()), "weight_broadcast_ms": round(bcast_ms, 3),
+                          "packed_sha256_rank0": digest.hex(), "packed_state_identical_on_all_ranks": same, "image_shards": spans,
+                          "shards_cover_global_batch": covered, "max_over_ranks_s": float(t.item()),
+                          "note": "CPU dry run of the multi-rank start-up; no kernels ran, nothing here is a throughput figure"}))
+    sys.exit(0 if (same and covered) else 1)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"[bench] --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            self_launch(args)  # does not return
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} ranks", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_dist:
+        dry_dist(args, rank, world)  # does not return
+    guard = StdoutGuard()
     import numpy as np
     import torch  # first: its bundled HIP runtime must be the one the process uses (same SONAME as /opt/rocm's)
     if not torch.cuda.is_available():
@@ -163,20 +343,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"  # exercise the RCCL start-up path on one rank
+    tgroup = None
     if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29500 + os.getppid() % 2000))  # the launcher sets it; this default only serves BENCH_FORCE_DIST
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        # the barriers that bracket the timed region run on the host (gloo): an RCCL barrier is an all-reduce kernel + its launch and
-        # wait, ~0.6 ms measured on one rank -- 10 % of a 20-step region -- and it says nothing a host barrier between ranks that have
-        # each synchronised their device does not
-        try:
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node; the container's hostname may not resolve
-            tgroup = dist.new_group(backend="gloo")
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] gloo group unavailable ({e}); timing barriers stay on RCCL", file=sys.stderr)
-            tgroup = None
+        dist, tgroup = dist_init("nccl", rank, world, dev)
 
     from yolo_quantization_amd import binding, synth
     binding.init(local_rank)
@@ -197,22 +366,13 @@ def main():
         net = binding.Net(args.cfg, wts, batch=B, gpu=local_rank, use_graph=args.graph, keep_head_float=False)
         net.prepare_fixed(1.0 / 255.0, 0)
         packed = net.export_packed()
-        size_t = torch.tensor([packed.size], dtype=torch.int64, device=dev)
     else:
         net = binding.Net(args.cfg, None, batch=B, gpu=local_rank, use_graph=args.graph, keep_head_float=False)
-        size_t = torch.zeros(1, dtype=torch.int64, device=dev)
+        packed = None
     bcast_ms = 0.0
     if world > 1 or force_dist:
-        dist.broadcast(size_t, 0)
-        nbytes = int(size_t.item())
-        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            blob.copy_(torch.from_numpy(packed))
-        torch.cuda.synchronize()
-        t0 = time.time()
-        dist.broadcast(blob, 0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.time() - t0) * 1e3
+        blob, bcast_ms = bcast_packed(dist, torch, rank, packed, dev)
+        nbytes = int(blob.numel())
         flush_c_stdio()
         if rank != 0 or force_dist:
             if force_dist and rank == 0:  # single-rank self test: re-import what was exported
@@ -224,7 +384,8 @@ def main():
         net.set("input_direct", 0)
     # ---- synthetic input, resident in HBM in the reference layout before the timed region
     in_c, in_h, in_w = net.info[0]["c"], net.info[0]["h"], net.info[0]["w"]  # 3 x 416 x 416 for the headline cfg
-    x = synth.synth_image_u8(in_c, in_h, in_w, seed=1000 + rank, batch=B)
+    img0, img1 = image_shard(rank, world, B)  # this rank's images of the global batch (weak scaling: B per rank)
+    x = synth.synth_image_u8(in_c, in_h, in_w, seed=1000 + img0 // max(B, 1), batch=img1 - img0)
     net.push_input(x)
     net.sync()
 
@@ -404,10 +565,15 @@ def main():
         for i, inf in enumerate(net.info):
             t_ms = max(float(ms[i + 1]) / nprof - ev_cost, 1e-6)
             row = {"i": i, "type": inf["type"], "ms": round(t_ms, 5)}
+            rd_b, wr_b = launch_bytes(net, i, B)
+            launches = not ((i > 0 and fused[i - 1]) or (i > 0 and net.fuses_next(i - 1)) or inf["type"] in (binding.T_ROUTE, binding.T_YOLO))
             if inf["type"] == binding.T_CONV:
-                ops, byt = conv_layer_work(inf, B)
-                row.update(tops=round(ops / (t_ms * 1e-3) / 1e12, 2), gbs=round(byt / (t_ms * 1e-3) / 1e9, 1),
-                           k=inf["size"], c=inf["c"], n=inf["n"], hw=inf["out_h"], ops=ops)
+                ops, _ = conv_layer_work(inf, B)
+                # gbs: algorithmic bytes of the launch that runs (fused launches: input + weights + the tensors it STORES)
+                row.update(tops=round(ops / (t_ms * 1e-3) / 1e12, 2), gbs=round((rd_b + wr_b) / (t_ms * 1e-3) / 1e9, 1), bytes=rd_b + wr_b,
+                           fused_next=bool(net.fuses_next(i)), k=inf["size"], c=inf["c"], n=inf["n"], hw=inf["out_h"], ops=ops)
+            elif launches and t_ms > 1e-3:
+                row.update(gbs=round((rd_b + wr_b) / (t_ms * 1e-3) / 1e9, 1), bytes=rd_b + wr_b)
             rows.append(row)
         return rows, ev_cost, max(float(ms[0]) / nprof - ev_cost, 0.0)
 
@@ -460,6 +626,35 @@ def main():
                                                    "source": "profiles/r02_v3_ubench_mfma_data_power.log -- not measured in this run"},
                 "input_layout_ms": round(in_layout_ms, 5),
                 "event_overhead_ms": round(ev_cost, 5)}
+        # ---- HBM rows ("GB/s for L0/L2/pools"): the few-channel convs with their fused pools and every stand-alone glue launch.
+        # algorithmic = launch_bytes() (fused launches count what they read and STORE); counter = the same launch's bytes in the newest
+        # committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, fabric side: Infinity-Cache hits included) over THIS run's duration.
+        pmc_rows, pmc_src = pmc_kernel_rows()
+
+        def pmc_bytes_of(i, inf):
+            code = net.conv_kernel(i) if inf["type"] == binding.T_CONV else -1
+            want = {1: "conv_first_mfma", 2: ("conv_mid_pool" if inf["c"] == 64 else f"conv_small_pool_kernel<{inf['c']},")}.get(code)
+            if inf["type"] == binding.T_MAXPOOL:
+                want = "maxpool_u8_kernel"
+            for r in pmc_rows:
+                if want and want in r["kernel"] and (inf["type"] != binding.T_MAXPOOL or r["grid_threads"] == B * inf["outputs"] // 16):
+                    return (r["hbm_read_bytes_per_launch"] or 0) + (r["hbm_write_bytes_per_launch"] or 0)
+            return None
+
+        hbm_rows = []
+        if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg":
+            for r in layers:
+                inf = net.info[r["i"]]
+                if "bytes" not in r or (inf["type"] == binding.T_CONV and not (inf["c"] < 64 and inf["size"] == 3)):
+                    continue
+                cb = pmc_bytes_of(r["i"], inf)
+                hbm_rows.append({"layer": r["i"], "what": ("conv %d->%d 3x3%s" % (inf["c"], inf["n"], " + maxpool" if r.get("fused_next") else "")) if inf["type"] == binding.T_CONV else "maxpool",
+                                 "us": round(r["ms"] * 1e3, 2), "algorithmic_bytes": r["bytes"], "gbs": r["gbs"], "frac": round(r["gbs"] / PEAK_HBM_GBS, 4),
+                                 "counter_bytes": cb, "counter_gbs": round(cb / (r["ms"] * 1e-3) / 1e9, 1) if cb else None,
+                                 "counter_frac": round(cb / (r["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if cb else None})
+        roof["hbm_layers"] = {"peak": PEAK_HBM_GBS, "unit": "GB/s", "rows": hbm_rows,
+                              "note": "HBM-side rows: algorithmic bytes = input + weights + the tensors the (fused) launch stores; counter bytes from the committed PMC "
+                                      f"passes ({pmc_src}; FETCH_SIZE x2 + WRITE_SIZE, not measured in this run) over this run's launch duration"}
         if flight_prof and ninfl > 1:  # the same kernels while other batches' kernels share the CUs (timed region)
             f_rows, _, _ = layer_table(flight_prof[0], flight_prof[1], None, 0)
             f_ops, f_ms = rows_rate(f_rows)
@@ -513,8 +708,13 @@ def main():
     cpu = cpu_omp = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cfg, wts, args.cpu_images)
-        if args.cpu_omp:
-            cpu_omp = cpu_baseline(args.cfg, wts, args.cpu_images * 4, omp=True)
+        if not args.no_cpu_omp and cpu and cpu["kind"] == "reference":
+            # the reference's own all-cores build (Makefile MULTI_CORE=1: `#pragma omp parallel for` over the GEMM's output rows,
+            # ref src/gemm.c:291) on every hardware thread of this host, bounded sample, after the timed region
+            try:
+                cpu_omp = cpu_baseline(args.cfg, wts, args.cpu_omp_images, omp=True)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] all-cores CPU baseline unavailable ({e})", file=sys.stderr)
 
     if rank == 0:
         out = {"metric": METRICS.get(os.path.basename(args.cfg), f"images/sec {os.path.basename(args.cfg)} INT8"), "value": round(value, 1), "unit": "images/s",
@@ -538,7 +738,7 @@ def main():
                           "weight_broadcast_ms": round(bcast_ms, 3)},
                "roofline": roof, "serial": serial, "cpu_baseline": cpu, "accum_ref_f32_mode": ref_f32, "selfcheck": selfcheck}
         if cpu_omp:
-            out["cpu_baseline_allcores"] = cpu_omp
+            out["cpu_baseline_omp"] = cpu_omp
         if layers:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             json.dump({"ms_per_step": serial["ms_per_step"] if serial else ms_per_step, "layers": layers},
@@ -553,9 +753,8 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
-    flush_c_stdio()
-    if rank == 0:  # the ONE JSON line, last on stdout (RCCL's start-up banner sits in C stdio's buffer until flushed)
-        print(json.dumps(out), flush=True)
+    if rank == 0:  # the ONE JSON line, alone on stdout
+        guard.emit(json.dumps(out))
 
 
 if __name__ == "__main__":

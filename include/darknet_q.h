@@ -156,7 +156,9 @@ struct network {
                                    a fourth batch in flight only runs beside the other three from there (bench: 0.2719 -> 0.2671 ms
                                    per step; a fourth created stream shares a queue with the first: 0.2719 -> 0.30).  Only for hosts
                                    that put nothing else on the default stream. */
-    int plan;             /* MI355_PLAN_*: handed to every conv launch; network_replica switches parent and replica to the throughput plan */
+    int plan;             /* MI355_PLAN_*: handed to every conv launch; network_replica switches parent and replica to the throughput plan
+                             (change it with network_set_plan, which also re-derives the fusion plan and drops a captured graph) */
+    int plan_user;        /* the plan the caller asked for (network_set_plan); a parent returns to it when its last replica is freed */
     int has_host_weights; /* load_weights ran: raw weights_uint8 / biases / scales of every layer are on the host */
     int has_l0_weights;   /* imported from a packed exchange: blobs only, plus layer 0's raw record (re-prep on a new input scale) */
     char *cfg_path;       /* the cfg this network was parsed from (network_replica parses it again) */
@@ -206,6 +208,13 @@ void quantization_prep_host(network *net, float in_scale, uint8_t in_zp);
  * (measured: DESIGN.md 4.3).  The parent must be prepared and must outlive its replicas; a replica cannot re-derive
  * layer 0 for another input scale, serve MI355_ACC_REF_F32 or be re-batched (error()). */
 network *network_replica(network *parent);
+/* the same with the stream choice as a parameter instead of the one-shot field: default_stream != 0 -> the replica launches on the
+ * device's default (NULL) stream -- HIP's fourth hardware queue -- and owns no stream of its own */
+network *network_replica_ex(network *parent, int default_stream);
+/* MI355_PLAN_LATENCY / MI355_PLAN_THROUGHPUT for every conv launch of this executor from the next pass on.  Waits for the executor's
+ * stream, drops a captured hipGraph (it holds the other plan's kernels) and re-derives the conv + pool / upsample / yolo / residual
+ * fusion flags: a launcher that declined a fused call under one plan (flag cleared at run time) is asked again under the other. */
+void network_set_plan(network *net, int plan);
 
 /* ---- execution ----------------------------------------------------------------------------------------------- */
 void forward_network(network *net);     /* == forward_network_gpu; dies if no device */

@@ -101,3 +101,29 @@ def test_requant_identities():
     assert np.array_equal(got.astype(np.float64), want)
     x = np.arange(0, 65536, dtype=np.uint64)
     assert np.array_equal((x * 0xCCCD) >> 19, x // 10)
+
+
+def test_bench_self_launch_dry_dist_world2(cfg_dir):
+    """`python bench.py --gpus 2 --dry-dist` with no launcher around it (what the round driver runs for N > 1, plus the dry switch):
+    bench.py re-runs itself under torch.distributed.run with two ranks and drives ITS OWN rendezvous, packed-weights broadcast,
+    import, image sharding and max-over-ranks timing code on gloo with host-only prep.  One JSON line, rc 0, identical packed
+    state on both ranks."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-dist", "--steps", "3", "--cfg",
+                        os.path.join(cfg_dir, "tiny_unit.cfg")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_dist"] and d["n_gpus"] == 2 and d["packed_state_identical_on_all_ranks"] and d["shards_cover_global_batch"]
+    assert d["image_shards"] == [[0, 64], [64, 128]]
+
+
+def test_bench_rejects_a_world_that_is_not_gpus():
+    """a launcher that started another number of ranks than --gpus says is an error (rc 2), not a silent re-launch"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-dist"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 2

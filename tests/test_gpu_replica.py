@@ -182,3 +182,62 @@ def test_plan_hint_on_single_convs(c, n, hw, batch, replanned):
         assert fam[1] == (5 if replanned else 4)
     else:
         assert fam[0] == 5 and fam[1] == 5      # row-image kernel either way (tile 128 x 384 or 128 x 128)
+
+
+def test_parent_returns_to_the_latency_plan_with_its_fused_pools(tmp_path):
+    """under the throughput plan conv_ws3 declines the one-round 128 / 256-channel layers, the fused conv + pool call fails
+    and the host clears fuse_next_pool for that layer.  When the last replica is freed (or the plan is set back by hand) the parent
+    must run the round 1-2 kernels again -- fused pools included -- and not conv + maxpool as two launches for the rest of its life."""
+    binding.init(0)
+    cfgp = os.path.join(ROOT, "cfg", "yolov3-tiny_quant.cfg")
+    wts = str(tmp_path / "w.weights")
+    synth.synth_weights(cfgp, wts, seed=9)
+    x = synth.synth_image_u8(3, 416, 416, seed=31, batch=64)
+    net = binding.Net(cfgp, wts, batch=64)
+    net.prepare_fixed(1.0 / 255.0, 0)
+    net.push_input(x)
+
+    def state():
+        net.forward()
+        net.sync()
+        return ({i: net.conv_kernel(i) for i, inf in enumerate(net.info) if inf["type"] == binding.T_CONV},
+                {i: net.fuses_next(i) for i in range(net.n)}, _outputs(net))
+
+    k0, f0, y0 = state()
+    assert f0[8] and f0[10] and k0[8] == 4 and k0[10] == 4  # conv_ws3 with its fused pools
+    rep = net.replica()
+    k1, f1, y1 = state()
+    assert k1[8] == 5 and k1[10] == 5 and not f1[8] and not f1[10]  # row-image 128 x 128 tiles, stand-alone pools
+    rep.close()
+    k2, f2, y2 = state()
+    assert k2 == k0 and f2 == f0, "the parent did not return to the latency plan's launches"
+    net.set("plan", 1)
+    k3, f3, y3 = state()
+    net.set("plan", 0)
+    k4, f4, y4 = state()
+    assert k3 == k1 and k4 == k0 and f4 == f0
+    for y in (y1, y2, y3, y4):
+        for a, b in zip(y, y0):
+            assert np.array_equal(a, b)
+    net.close()
+
+
+def test_layer_range_refuses_what_it_cannot_run(tmp_path):
+    """the layer-range diagnostic dies with a message (error(), like the reference) instead of reading unwritten tensors"""
+    import subprocess
+    import sys
+    code = f"""
+import sys; sys.path.insert(0, {ROOT!r})
+from yolo_quantization_amd import binding, synth
+binding.init(0)
+cfg = {os.path.join(ROOT, 'cfg', 'yolov3-tiny_quant.cfg')!r}
+synth.synth_weights(cfg, {str(tmp_path / 'w.weights')!r}, seed=1)
+net = binding.Net(cfg, {str(tmp_path / 'w.weights')!r}, batch=2)
+net.prepare_fixed(1.0 / 255.0, 0)
+net.push_input(synth.synth_image_u8(3, 416, 416, seed=1, batch=2))
+net.forward(); net.sync()
+net.set("range_lo", 1); net.set("range_hi", 3)   # layer 0's own tensor is never stored (fused with its pool)
+net.forward()
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "layer range" in r.stderr

@@ -110,28 +110,35 @@ int mi355_stream_destroy(void *stream)
 // HIP maps the streams of a process onto the device's hardware queues round-robin in creation order (four queues; the default
 // stream owns one): two streams on the same queue serialise.  Which created stream lands beside which depends on every stream
 // any library of the process created before (measured: one unused stream created ahead of a network's three turns 0.277 ms per
-// step into 0.311).  mi355_stream_acquire therefore MEASURES: per device it creates candidate streams and keeps those that run
-// a 100 us spin kernel concurrently with the default stream and with every stream kept so far.
-__global__ void mi355_spin_kernel(long long ticks)  // 100 MHz wall clock; bounded by construction
+// step into 0.311).  mi355_stream_acquire therefore MEASURES: per device it creates candidate streams and keeps those whose
+// 200 us spin kernel OVERLAPS, by the device's own wall clock, the spin kernels of the default stream and of every stream kept so
+// far.  The test reads device-side time stamps (start / end of each spin in wall_clock64 ticks, tick rate from
+// hipDeviceAttributeWallClockRate), so a slow host, a profiler or other users of the device cannot turn "side by side" into
+// "rejected".  Not to be called while a stream capture is active in the process: the measurement synchronises the device and
+// launches on the NULL stream (once per device; later calls only hand out pool entries).
+__global__ void mi355_spin_kernel(long long ticks, long long *stamp)  // bounded by construction
 {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (stamp && threadIdx.x == 0) { stamp[0] = t0; stamp[1] = wall_clock64(); }
 }
-static double spin_pair_us(hipStream_t a, hipStream_t b, long long ticks)
+// ticks the two spins overlapped (device wall clock), or -1 on a HIP error
+static long long spin_pair_overlap(hipStream_t a, hipStream_t b, long long ticks, long long *stamps_dev)
 {
-    (void)hipDeviceSynchronize();
-    const auto t0 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(mi355_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
-    if (b != a) hipLaunchKernelGGL(mi355_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
-    (void)hipDeviceSynchronize();
-    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    long long h[4] = {0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    hipLaunchKernelGGL(mi355_spin_kernel, dim3(1), dim3(64), 0, a, ticks, stamps_dev);
+    hipLaunchKernelGGL(mi355_spin_kernel, dim3(1), dim3(64), 0, b, ticks, stamps_dev + 2);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(h, stamps_dev, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const long long lo = h[0] > h[2] ? h[0] : h[2], hi = h[1] < h[3] ? h[1] : h[3];
+    return hi > lo ? hi - lo : 0;
 }
-static bool streams_concurrent(hipStream_t a, hipStream_t b)
+static bool streams_concurrent(hipStream_t a, hipStream_t b, long long ticks, long long *stamps_dev)
 {
-    const long long ticks = 20000;  // 200 us
-    double best = 1e30;
-    for (int i = 0; i < 3; ++i) { const double t = spin_pair_us(a, b, ticks); if (t < best) best = t; }
-    return best < 330.0;  // side by side: ~200 us (+ launch overhead); one behind the other: >= 400 us
+    long long best = 0;
+    for (int i = 0; i < 3; ++i) { const long long o = spin_pair_overlap(a, b, ticks, stamps_dev); if (o > best) best = o; }
+    return best * 2 > ticks;  // side by side: nearly the whole spin; one behind the other: none of it
 }
 struct StreamPool { hipStream_t s[8]; bool used[8]; int n; bool built; };
 static StreamPool g_pool[64];
@@ -144,18 +151,37 @@ int mi355_stream_acquire(void **stream)
     std::lock_guard<std::mutex> lk(g_pool_mu);
     StreamPool &P = g_pool[dev & 63];
     if (!P.built) {
-        P.built = true;
-        P.n = 0;
-        hipLaunchKernelGGL(mi355_spin_kernel, dim3(1), dim3(64), 0, 0, 1);  // module load + warm launch path outside the timing
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;  // gfx950: 100 MHz
+        const long long ticks = (long long)khz / 5;  // 200 us
+        long long *stamps = nullptr;
+        HIPCHK(hipMalloc(&stamps, 4 * sizeof(long long)));
+        hipLaunchKernelGGL(mi355_spin_kernel, dim3(1), dim3(64), 0, 0, 1, stamps);  // module load + warm launch path outside the measurement
         (void)hipDeviceSynchronize();
-        for (int c = 0; c < 8 && P.n < 3; ++c) {  // three created streams + the default one = the device's four queues
+        hipStream_t kept[8], rejected[8];
+        int nk = 0, nr = 0;
+        bool hip_ok = true;
+        for (int c = 0; c < 8 && nk < 3 && hip_ok; ++c) {  // three created streams + the default one = the device's four queues
             hipStream_t cand;
-            HIPCHK(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
-            bool ok = streams_concurrent(nullptr, cand);
-            for (int k = 0; ok && k < P.n; ++k) ok = streams_concurrent(P.s[k], cand);
-            if (ok) { P.s[P.n] = cand; P.used[P.n] = false; ++P.n; }
-            // (a rejected candidate stays alive on purpose: destroying it would hand its queue slot to the next creation)
+            if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { hip_ok = false; break; }
+            bool ok = streams_concurrent(nullptr, cand, ticks, stamps);
+            for (int k = 0; ok && k < nk; ++k) ok = streams_concurrent(kept[k], cand, ticks, stamps);
+            if (ok) kept[nk++] = cand;
+            else rejected[nr++] = cand;  // stays alive until the pool is complete: destroying it now would hand its queue slot to the next creation
         }
+        for (int k = 0; k < nr; ++k) (void)hipStreamDestroy(rejected[k]);
+        (void)hipFree(stamps);
+        if (!hip_ok) {  // nothing half-built is kept
+            for (int k = 0; k < nk; ++k) (void)hipStreamDestroy(kept[k]);
+            snprintf(g_err, sizeof(g_err), "stream_acquire: stream creation failed while measuring the pool");
+            return MI355_EHIP;
+        }
+        for (int k = 0; k < nk; ++k) { P.s[k] = kept[k]; P.used[k] = false; }
+        P.n = nk;
+        P.built = true;
+        if (nk < 3)
+            fprintf(stderr, "mi355_stream_acquire: device %d: only %d created stream(s) ran side by side with the default stream "
+                            "(expected 3: four hardware queues); further executors will share a queue\n", dev, nk);
     }
     for (int k = 0; k < P.n; ++k)
         if (!P.used[k]) { P.used[k] = true; *stream = P.s[k]; return MI355_OK; }
@@ -218,7 +244,7 @@ int mi355_graph_end(void *stream, void **graph_exec)
     HIPCHK(hipStreamEndCapture((hipStream_t)stream, &g));
     hipGraphExec_t ge;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate");
     *graph_exec = ge;
     return MI355_OK;

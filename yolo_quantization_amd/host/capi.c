@@ -24,7 +24,7 @@ int dnq_net_set(network *net, const char *key, int val)
     else if (!strcmp(key, "range_lo")) net->range_lo = val;
     else if (!strcmp(key, "range_hi")) net->range_hi = val;
     else if (!strcmp(key, "replica_default_stream")) net->replica_default_stream = val;
-    else if (!strcmp(key, "plan")) net->plan = val; /* MI355_PLAN_LATENCY / MI355_PLAN_THROUGHPUT */
+    else if (!strcmp(key, "plan")) network_set_plan(net, val); /* MI355_PLAN_LATENCY / MI355_PLAN_THROUGHPUT: syncs, drops the graph, re-plans fusion */
     else if (!strcmp(key, "input_direct")) { /* 0: always convert the input to 4-byte cells (A/B runs); survives re-allocation */
         net->input_direct_off = !val;
         net->input_direct = val && net->c == 3 && !net->dump_int32;

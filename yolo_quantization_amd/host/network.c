@@ -525,6 +525,17 @@ static void run_layers(network *netp)
 {
     network net = *netp;
     void **ev = NULL;
+    const int ranged = netp->range_hi > netp->range_lo;
+    if (ranged) { /* diagnostic knob: validate it instead of reading tensors nobody wrote */
+        if (netp->use_graph) error("forward_network_gpu: a layer range cannot be combined with use_graph (the captured graph is the whole net)");
+        if (netp->prof_ev && netp->prof_used < netp->prof_cap) error("forward_network_gpu: a layer range cannot be combined with armed per-layer events");
+        if (netp->range_lo > 0) {
+            const layer *pl = &netp->layers[netp->range_lo - 1];
+            const int stored = !(pl->type == CONVOLUTIONAL && netp->fuse_maxpool && !netp->dump_int32 && netp->accum_mode == MI355_ACC_EXACT &&
+                                 ((pl->fuse_next_pool && !pl->fuse_pool_keep) || pl->fuse_next_upsample || pl->fuse_next_shortcut || pl->fuse_next_yolo));
+            if (!stored) error("forward_network_gpu: layer range starts behind a conv whose own tensor is not stored (fused with the layer after it)");
+        }
+    }
     if (netp->prof_ev && netp->prof_used < netp->prof_cap && !netp->use_graph && netp->prof_calls++ % netp->prof_stride == netp->prof_phase % netp->prof_stride)
         ev = netp->prof_ev + (size_t)(netp->prof_used++) * (net.n + 2);
     if (ev) check_mi355(mi355_event_record(ev[0], net.stream), "event");
@@ -934,7 +945,32 @@ void network_bcast_packed(network *net, void *comm, int rank, int root)
 /* A second executor of the same prepared model (darknet_q.h).  The cfg is parsed again (layer geometry, host-side arrays),
  * the per-layer quantisation records and the fusion plan's inputs are copied from the parent, every conv layer borrows the
  * parent's packed blob on the device; activations, input buffers and the stream are the replica's own. */
+static void set_plan_internal(network *net, int plan)
+{
+    /* the executor may still have a pass (or its captured graph) in flight on its stream */
+    if (net->prepared && (net->stream || net->on_default_stream)) check_mi355(mi355_stream_sync(net->on_default_stream ? NULL : net->stream), "sync");
+    if (net->graph) { mi355_graph_destroy(net->graph); net->graph = NULL; } /* captured with the other plan's kernels */
+    net->plan = plan;
+    /* fused calls a launcher refused under the old plan (conv_ws3's fused pools under the throughput plan: flags cleared at run
+     * time, layers.c) are candidates again; the tensor views were planned with the flags set, so both forms stay valid */
+    if (net->prepared) plan_fusion(net);
+}
+
+void network_set_plan(network *net, int plan)
+{
+    net->plan_user = plan;
+    set_plan_internal(net, plan);
+}
+
 network *network_replica(network *parent)
+{
+    if (!parent) error("network_replica: no parent");
+    const int ds = parent->replica_default_stream; /* one-shot request of the parent (darknet_q.h) */
+    parent->replica_default_stream = 0;
+    return network_replica_ex(parent, ds);
+}
+
+network *network_replica_ex(network *parent, int default_stream)
 {
     if (!parent || !parent->prepared) error("network_replica: the parent network is not prepared");
     if (!parent->cfg_path) error("network_replica: the parent network was not parsed from a cfg file");
@@ -948,12 +984,11 @@ network *network_replica(network *parent)
     if (parent->accum_mode == MI355_ACC_REF_F32) error("network_replica: MI355_ACC_REF_F32 reads raw weights, which a replica does not hold");
     net->replica_of = parent;
     parent->n_replicas++;
-    net->on_default_stream = parent->replica_default_stream; /* one-shot request of the parent (darknet_q.h) */
-    parent->replica_default_stream = 0;
-    /* more than one batch in flight from here on: both executors ask the launchers for kernels that share a CU */
-    parent->plan = MI355_PLAN_THROUGHPUT;
-    if (parent->graph) { mi355_graph_destroy(parent->graph); parent->graph = NULL; } /* captured with the other plan's kernels */
-    net->plan = MI355_PLAN_THROUGHPUT;
+    net->on_default_stream = default_stream != 0;
+    /* more than one batch in flight from here on: both executors ask the launchers for kernels that share a CU (the parent keeps
+     * a plan its caller set explicitly after the first replica: only the first replica switches it) */
+    if (parent->n_replicas == 1 && parent->plan != MI355_PLAN_THROUGHPUT) set_plan_internal(parent, MI355_PLAN_THROUGHPUT);
+    net->plan = net->plan_user = parent->plan;
     net->batch = parent->batch;
     free(net->input); free(net->input_uint8);
     net->input = calloc((size_t)net->inputs * net->batch, sizeof(float));
@@ -990,11 +1025,9 @@ void free_network(network *net)
 {
     if (!net) return;
     if (net->n_replicas > 0) error("free_network: free this network's replicas first (they borrow its packed weights on the device)");
-    if (net->replica_of && --net->replica_of->n_replicas == 0) { /* the parent is alone on the device again: whole-chip kernels */
-        network *parent = net->replica_of;
-        parent->plan = MI355_PLAN_LATENCY;
-        if (parent->graph) { mi355_graph_destroy(parent->graph); parent->graph = NULL; }
-    }
+    if (net->replica_of && --net->replica_of->n_replicas == 0) /* the parent is alone on the device again: back to the plan its caller chose
+                                                                  (whole-chip kernels by default), fused launches re-planned */
+        set_plan_internal(net->replica_of, net->replica_of->plan_user);
     for (int i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];
         free_layer_device(l);

@@ -207,6 +207,11 @@ static layer parse_shortcut(section *o, size_params p, network *net, int count)
     layer s = make_shortcut_layer(p.batch, index, p.w, p.h, p.c, from.out_w, from.out_h, from.out_c, q, qs,
                                   p.close_quantization, count);
     s.fisrt_time_train_fag = option_find_int(o, "first_time", 0);
+    /* first_time = 1 means "no activation record in the weights file yet" (the calibration pass of the reference's glue layers, which
+     * inherit their input's record: ref src/parser.c:1174-1199).  The sum of two tensors has no input to inherit from, and a record
+     * derived here would be a second spec: refuse it at parse time instead of failing later in mi355_shortcut_multiplier. */
+    if (q && s.fisrt_time_train_fag)
+        error("[shortcut] quantized=1 first_time=1: the residual add needs its own (scale, zero point) record in the weights file");
     return s;
 }
 
@@ -364,8 +369,8 @@ void load_weights(network *net, char *filename)
         if (l.type == UPSAMPLE && l.layer_quant_flag) { /* ref :1185-1199 */
             if (!l.fisrt_time_train_fag) load_act_record(l, fp);
         }
-        if (l.type == SHORTCUT && l.layer_quant_flag && !l.fisrt_time_train_fag)
-            load_act_record(l, fp); /* builder-specified: the sum's own (scale, zero point), under the upsample record's conditions */
+        if (l.type == SHORTCUT && l.layer_quant_flag)
+            load_act_record(l, fp); /* builder-specified: the sum's own (scale, zero point); first_time = 1 is refused by parse_shortcut */
     }
     long here = ftell(fp);
     fseek(fp, 0, SEEK_END);

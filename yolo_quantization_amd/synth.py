@@ -106,6 +106,8 @@ def layer_shapes(sections: list[dict]) -> tuple[dict, list[LayerShape]]:
         elif t == "[shortcut]":
             frm = int(s["from"])
             frm = frm if frm >= 0 else idx + frm
+            if q and int(s.get("first_time", 0)):  # same rule as host/parser.c parse_shortcut: the sum has no record to inherit
+                raise ValueError("[shortcut] quantized=1 first_time=1: the residual add needs its own activation record")
             L = LayerShape("shortcut", c, h, w, c, h, w, 0, 0, 1, 0, s.get("activation", "linear"), 0, q, qs, [idx - 1, frm])
             assert (layers[frm].out_c, layers[frm].out_h, layers[frm].out_w) == (c, h, w), "shortcut inputs must share dims"
         elif t == "[yolo]":
