@@ -421,7 +421,7 @@ def main():
     # over the resident input, a device-side checksum of the yolo outputs after each; compared after the timed region, a mismatch
     # fails the run.  Nothing is synchronised here, so the passes also leave the device at its steady clocks when the warmup steps
     # start: after any idle phase of >= 20 ms (the host-side set-up above is one) the first ~40 steps of the net run up to 8 %
-    # slower (tools/dbg/step_curve.py) -- without this a `--warmup 5 --steps 20` region measures mostly that.
+    # slower (tools/step_curve.py) -- without this a `--warmup 5 --steps 20` region measures mostly that.
     if args.selfcheck_passes > 0 and not args.graph:
         for nk in nets:  # every instance checks itself; with several in flight their passes overlap on the device like the timed steps
             nk.selfcheck(args.selfcheck_passes)
@@ -433,7 +433,7 @@ def main():
     # 8th step profiled, 0.365 with a single profiled step -- 3 % of `value` went into its own instrumentation.  Every 32nd step
     # (at least one) keeps that below 1 % on long runs (1.4 % at --steps 20).
     # A short timed region also sees the device's start-up: after any idle phase of more than ~2 ms the first ~25 steps run up
-    # to 8 % slower (tools/dbg/step_curve.py: 0.400 0.388 0.376 0.370 0.368 .. ms per step in groups of five; --warmup 5
+    # to 8 % slower (tools/step_curve.py: 0.400 0.388 0.376 0.370 0.368 .. ms per step in groups of five; --warmup 5
     # --steps 20 gives 0.38, --warmup 50 0.361, --warmup 200 0.355 in the same box).  Nothing is done about that here.
     prof_stride = max(1, int(os.environ.get("BENCH_PROF_STRIDE", "32")))
     ninfl = len(nets)

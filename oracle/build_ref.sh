@@ -8,7 +8,8 @@
 # We do not run the reference's own Makefile: the flags below restate Makefile:33-37,88-96 and the object list
 # Makefile:98.  The only deviation is `-idirafter include` instead of `-Iinclude`: the reference ships a
 # Windows `include/unistd.h` shim (`#include <io.h>`) that shadows the system header under -I.
-# The MKL flavour (OPENBLAS=1) needs mkl.h / libmkl_rt, which this image lacks -> unbuildable here.
+# The MKL flavour (OPENBLAS=1, ref Makefile:56-61) needs mkl.h / mkl_cblas.h: the image carries libmkl_rt.so (/opt/conda/lib) but NOT the
+# headers, and stand-in headers are not allowed -> unbuildable here (its epilogue is restated in oracle.c:orc_requant_mkl, unpinned).
 set -euo pipefail
 REF=${REF:-/root/reference}
 HERE="$(cd "$(dirname "$0")" && pwd)"

@@ -313,3 +313,29 @@ def test_reference_side_binding_compiles_against_the_real_header(tmp_path):
     if refdrv.available("mi355"):
         L = refdrv.lib("mi355")
         assert hasattr(L, "refdrv_mi355_bind") and hasattr(L, "mi355_bind_network") and hasattr(L, "forward_network_mi355")
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/cfg/yolov3_tiny_quant_channelwise.cfg"), reason="reference checkout absent (GPU box)")
+def test_host_parser_swallows_the_reference_s_shipped_cfg(tmp_path, cfg_dir):
+    """the repo's cfgs are regenerated (tools/make_cfg.py, training keys stripped); host/parser.c must also take
+    the reference's OWN file (ref cfg/yolov3_tiny_quant_channelwise.cfg through ref src/parser.c:579-674's key set: `# Training`
+    comments, `start_quantization_step`, spaced `saturation = 1.5`, blank lines), and the same file with CRLF line ends.  Checked:
+    the 24 layer shapes of SURVEY.md section 8 and equality with the parse of the regenerated relu6 cfg."""
+    from yolo_quantization_amd import binding
+    ref_cfg = "/root/reference/cfg/yolov3_tiny_quant_channelwise.cfg"
+    crlf = tmp_path / "crlf.cfg"
+    crlf.write_bytes(open(ref_cfg, "rb").read().replace(b"\r\n", b"\n").replace(b"\n", b"\r\n"))
+    keys = ("type", "c", "h", "w", "n", "size", "stride", "pad", "out_c", "out_h", "out_w", "activation", "batch_normalize", "quantized", "quant_stop", "outputs")
+    parses = []
+    for p in (ref_cfg, str(crlf), os.path.join(cfg_dir, "yolov3-tiny_quant_relu6.cfg")):
+        net = binding.Net(p, None)
+        parses.append([tuple(inf[k] for k in keys) for inf in net.info])
+        net.close()
+    assert parses[0] == parses[1] == parses[2]
+    # SURVEY.md section 8: (type, Cin, Cout, out H) of the 24 layers; conv = 0, maxpool = 3, route = 8, yolo = 23, upsample = 26
+    want = [(0, 3, 16, 416), (3, 16, 16, 208), (0, 16, 32, 208), (3, 32, 32, 104), (0, 32, 64, 104), (3, 64, 64, 52), (0, 64, 128, 52),
+            (3, 128, 128, 26), (0, 128, 256, 26), (3, 256, 256, 13), (0, 256, 512, 13), (3, 512, 512, 13), (0, 512, 1024, 13),
+            (0, 1024, 256, 13), (0, 256, 512, 13), (0, 512, 30, 13), (23, 30, 30, 13), (8, 0, 256, 13), (0, 256, 128, 13),
+            (26, 128, 128, 26), (8, 0, 384, 26), (0, 384, 256, 26), (0, 256, 30, 26), (23, 30, 30, 26)]
+    got = [(t[0], t[1], t[8], t[9]) for t in parses[0]]
+    assert got == want

@@ -22,6 +22,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--inflight", type=int, default=4)
 ap.add_argument("--plan", type=int, default=1)
 ap.add_argument("--reps", type=int, default=60)
+ap.add_argument("--only", default="", help="comma-separated first layers of the groups to measure (default: every group)")
 ap.add_argument("--by-shape", action="store_true", help="one row per distinct conv shape (sums over its layer groups): for the deep nets")
 ap.add_argument("--power", action="store_true", help="sample the device's socket power and shader clock (hwmon) during every flood phase (use --reps 2000+)")
 a = ap.parse_args()
@@ -106,7 +107,10 @@ sampler = Sampler() if a.power else None
 print(f"plan {a.plan}, {a.inflight} instances, batch {a.batch}")
 print("| layers | conv | serial us | flood us per launch | flood / serial |")
 print("|---|---|---|---|---|")
+only = {int(v) for v in a.only.split(",") if v}
 for lo, hi in groups:
+    if only and lo not in only:
+        continue
     for nk in nets:
         nk.set("range_lo", lo); nk.set("range_hi", hi)
     timed(nets, 5)
