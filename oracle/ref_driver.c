@@ -212,6 +212,19 @@ void refdrv_letterbox(float *im, int imw, int imh, int c, int w, int h, float *o
     free_image(boxed);
 }
 
+/* load_image_color of the reference itself (ref: src/image.c load_image_color -> stb_image, examples/detector.c:903): decoded
+ * planar float image [c][h][w] in 0..1.  Returns a malloc'd buffer (refdrv_free_floats) and the dimensions; NULL on failure. */
+float *refdrv_load_image_color(const char *path, int *w, int *h, int *c)
+{
+    hush();
+    image im = load_image_color((char *)path, 0, 0);
+    unhush();
+    if (!im.data) return NULL;
+    *w = im.w; *h = im.h; *c = im.c;
+    return im.data;
+}
+void refdrv_free_floats(float *p) { free(p); }
+
 /* get_yolo_detections of the reference itself (src/yolo_layer.c:316-345) on yolo layer i after a forward: records in
  * the layout of orc_yolo_detections (oracle.c).  Also hands out the layer's anchors / mask for the restatement. */
 int refdrv_yolo_detections(void *h, int i, int imw, int imh, float thresh, int relative, float *recs, int max_recs)

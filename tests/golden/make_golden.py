@@ -10,6 +10,9 @@ Fixtures are data only (inputs + the reference's outputs):
   funcs.npz                 known-answer vectors for gemm_nn_uint8_int32_te / im2col_cpu_uint8 /
                             quant_multi_smaller_than_one_to_scale_and_shift / quant_weights_with_min_max_channel
   nms.npz                   do_nms_sort (src/box.c:58-89) on clustered random detections
+  realimg_416.npz           the reference's test image as the NETWORK sees it: quantised uint8 input + scale / zero point of the
+                            layer-0 dynamic quantiser (+ the two extreme floats): data, no image file
+  yolov3_tiny_{leaky,relu6}_realimg.json   the per-layer hashes below for that input
   yolov3_tiny_{leaky,relu6}.json   per-layer SHA-256 of output_int32 / output_uint8_final / output (f32) of the
                             24-layer net @416x416 on the seeded synthetic model + seeded uint8 image, the host-prep
                             arrays' SHA-256, and the full head tensors' uint8 bytes (L15, L22) as hex.
@@ -159,14 +162,62 @@ def nms():
     np.savez_compressed(os.path.join(HERE, "nms.npz"), **d)
 
 
-def yolov3_tiny(tag, cfgname):
+REAL_IMAGE = "/root/reference/test_image/000044.jpg"
+
+
+def real_image():
+    """BASELINE config[0]'s real-image half: the reference's own test image through the reference's own
+    load_image_color -> letterbox_image(416, 416) (ref examples/detector.c:903-904) and its layer-0 dynamic quantiser
+    (ref src/blas.c:279 -> :108-168).  Committed as DATA: the quantised uint8 network input, the quantiser's scale / zero point, and the
+    two extreme floats of the letterboxed image with their positions -- enough to rebuild a float image on which the reference's
+    quantiser (checked here) returns the same scale, zero point and bytes: synth.dequantized_float_image.  No image file is stored."""
+    import ctypes as C
+    im = refdrv.load_image_color(REAL_IMAGE)
+    lb = refdrv.letterbox(im, 416, 416)
+    L = refdrv.lib()
+
+    def quantize(xf):
+        xx = np.ascontiguousarray(xf, np.float32).ravel().copy()
+        out = np.empty(xx.size, np.uint8)
+        s_, z_ = C.c_float(), C.c_uint8()
+        L.refdrv_quantize_image(xx.ctypes.data, xx.size, out.ctypes.data, C.byref(s_), C.byref(z_))
+        return out, np.float32(s_.value), int(z_.value)
+    u8, s_, z_ = quantize(lb)
+    imin, imax = int(np.argmin(lb)), int(np.argmax(lb))
+    d = {"input_u8": u8.reshape(3, 416, 416), "scale": np.float32(s_), "zero_point": np.uint8(z_), "fmin": np.float32(lb.ravel()[imin]),
+         "fmax": np.float32(lb.ravel()[imax]), "imin": np.int64(imin), "imax": np.int64(imax), "source_w": np.int32(im.shape[2]),
+         "source_h": np.int32(im.shape[1]), "letterbox_sha256": np.array(sha(lb))}
+    xr = synth.dequantized_float_image(d["input_u8"], d["scale"], d["zero_point"], d["fmin"], d["imin"], d["fmax"], d["imax"])
+    u2, s2, z2 = quantize(xr)
+    assert np.array_equal(u2, u8) and s2 == s_ and z2 == z_, "the rebuilt float image must quantise like the letterboxed one"
+    np.savez_compressed(os.path.join(HERE, "realimg_416.npz"), **d)
+    print(f"realimg_416: {im.shape[2]}x{im.shape[1]} -> 416x416, scale {s_!r}, zero point {z_}, bytes {u8.min()}..{u8.max()}")
+    return lb, d
+
+
+def yolov3_tiny(tag, cfgname, real=None):
     cfg = os.path.join(ROOT, "cfg", cfgname)
     wts = f"/tmp/golden_{tag}.weights"
     meta = synth.synth_weights(cfg, wts, seed=WEIGHT_SEED)
-    net, layers, x = run_ref(cfg, wts, img_seed=IMAGE_SEED)
+    if real is None:
+        net, layers, x = run_ref(cfg, wts, img_seed=IMAGE_SEED)
+    else:  # the letterboxed real image through the reference's dynamic layer-0 quantiser (test_detector's order: prep, then predict)
+        lb, rd = real
+        net = refdrv.RefNet(cfg, wts)
+        _, layers = synth.layer_shapes(synth.read_cfg(cfg))
+        xq = net.prepare(lb)
+        assert np.array_equal(xq, rd["input_u8"].ravel())
+        p0 = net.prep(0)
+        assert p0["zp_in"] == int(rd["zero_point"])
+        net.forward()
+        x = rd["input_u8"]
+        tag = tag + "_realimg"
     wrec = oracle.read_weights(wts, layers)
-    out = {"cfg": cfgname, "weight_seed": WEIGHT_SEED, "image_seed": IMAGE_SEED, "weights_sha256": meta["sha256"],
+    out = {"cfg": cfgname, "weight_seed": WEIGHT_SEED, "image_seed": IMAGE_SEED if real is None else None, "weights_sha256": meta["sha256"],
            "input_sha256": sha(x), "oracle": "reference default build (GPU=0 QUANTIZATION=1 -Ofast)", "layers": []}
+    if real is not None:
+        out["image"] = "ref test_image/000044.jpg -> load_image_color -> letterbox_image(416,416) -> layer-0 dynamic quantiser; data in realimg_416.npz"
+        out["input_scale"] = float(real[1]["scale"]); out["input_zero_point"] = int(real[1]["zero_point"])
     for i, L in enumerate(layers):
         e = {"i": i, "type": L.type}
         if L.type == "conv":
@@ -208,7 +259,7 @@ def yolov3_tiny(tag, cfgname):
     # below 2^24, so the reference's tensors are exact integers and can pin the exact-integer kernels on every element.
     # Run after the whole-net hashes above (a conv's forward only overwrites that layer's own outputs).
     for i, L in enumerate(layers):
-        if L.type != "conv" or L.c * L.size * L.size < 2304:
+        if L.type != "conv" or L.c * L.size * L.size < 2304 or real is not None:
             continue
         xl = (synth.synth_image_u8(L.c, L.h, L.w, seed=LOWRANGE_SEED + i) >> LOWRANGE_SHIFT).astype(np.uint8)
         net.forward_layer(i, xl)
@@ -243,3 +294,7 @@ if __name__ == "__main__":
     if want("yolov3_tiny"):
         yolov3_tiny("leaky", "yolov3-tiny_quant.cfg")
         yolov3_tiny("relu6", "yolov3-tiny_quant_relu6.cfg")
+    if want("realimg"):
+        ri = real_image()
+        yolov3_tiny("leaky", "yolov3-tiny_quant.cfg", real=ri)
+        yolov3_tiny("relu6", "yolov3-tiny_quant_relu6.cfg", real=ri)

@@ -66,6 +66,30 @@ def _as(ptr, n, dt):
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dt)), shape=(n,))
 
 
+def load_image_color(path, omp=False):
+    """the reference's own load_image_color (stb_image decode) -> float32 [c][h][w] in 0..1 (only where the reference is built)"""
+    L = lib(omp)
+    L.refdrv_load_image_color.restype = C.POINTER(C.c_float)
+    L.refdrv_load_image_color.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.refdrv_free_floats.argtypes = [C.POINTER(C.c_float)]
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    p = L.refdrv_load_image_color(path.encode(), C.byref(w), C.byref(h), C.byref(c))
+    assert p, f"load_image_color({path}) failed"
+    a = np.ctypeslib.as_array(p, shape=(c.value, h.value, w.value)).copy()
+    L.refdrv_free_floats(p)
+    return a
+
+
+def letterbox(im_chw, w, h, omp=False):
+    """the reference's own letterbox_image (src/image.c:812-831)"""
+    L = lib(omp)
+    im = np.ascontiguousarray(im_chw, np.float32)
+    out = np.empty((im.shape[0], h, w), np.float32)
+    L.refdrv_letterbox.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.refdrv_letterbox(im.ctypes.data, im.shape[2], im.shape[1], im.shape[0], w, h, out.ctypes.data)
+    return out
+
+
 class RefNet:
     def __init__(self, cfg, weights, omp=False):
         self.L = lib(omp)

@@ -980,3 +980,61 @@ def test_microbench_shape_vs_oracle_and_linearity():
     a2 = binding.conv_forward(xt, w2, zp_w, k, bias, mv, sv, 0, 23, 1.0, binding.ACT["leaky"])["int32"].astype(np.int64)
     a0 = binding.conv_forward(xt, z, zp_w, k, bias, mv, sv, 0, 23, 1.0, binding.ACT["leaky"])["int32"].astype(np.int64)
     assert np.array_equal(a1 + a2 - a0, got["int32"].astype(np.int64))
+
+
+@pytest.mark.parametrize("tag", ["leaky", "relu6"])
+def test_yolov3_tiny_416_real_image_through_the_device_quantiser(golden_dir, cfg_dir, tmp_path, tag):
+    """BASELINE config[0], real-image half.  The float image rebuilt from
+    tests/golden/realimg_416.npz (the reference's test image after ITS load_image_color -> letterbox_image, as data) goes through the
+    DEVICE quantiser (quantization_weights_and_activations_gpu: min / max reduce, scale / zero point, per-element quantise; ref
+    src/blas.c:279) and the 24 layers:
+      * MI355_ACC_REF_F32: every int32 / uint8 / float tensor has the hash the reference produced on that image;
+      * MI355_ACC_EXACT (production kernels): equals the oracle's exact mode on every tensor; on every conv whose input still equals
+        the reference's, the accumulators and bytes inside the committed fp32-exact mask hash like the reference's."""
+    r = np.load(os.path.join(golden_dir, "realimg_416.npz"))
+    g = json.load(open(os.path.join(golden_dir, f"yolov3_tiny_{tag}_realimg.json")))
+    cfg = os.path.join(cfg_dir, g["cfg"])
+    wts = str(tmp_path / "w.weights")
+    assert synth.synth_weights(cfg, wts, seed=g["weight_seed"])["sha256"] == g["weights_sha256"]
+    xf = synth.dequantized_float_image(r["input_u8"], r["scale"], r["zero_point"], r["fmin"], r["imin"], r["fmax"], r["imax"])
+    x = r["input_u8"]
+    outs = {}
+    for accum in (binding.ACC_REF_F32, binding.ACC_EXACT):
+        net = binding.Net(cfg, wts, batch=1, accum=accum, dump_int32=True)
+        xq = net.prepare_from_float_gpu(xf)
+        assert np.array_equal(xq, x.ravel()), "device quantiser bytes"
+        p0 = net.prep(0)
+        assert np.float32(p0["s_in"]) == r["scale"] and p0["zp_in"] == int(r["zero_point"])
+        net.forward()
+        net.sync()
+        outs[accum] = [net.pull(i) for i in range(net.n)]
+        info = net.info
+        net.close()
+    for e in g["layers"]:  # bit-faithful mode: the reference's hashes, every layer
+        i, o = e["i"], outs[binding.ACC_REF_F32][e["i"]]
+        if "int32_sha256" in e:
+            assert sha(o["int32"]) == e["int32_sha256"], f"layer {i} int32"
+        if "u8_sha256" in e:
+            assert sha(o["u8"]) == e["u8_sha256"], f"layer {i} u8"
+        if "f32_sha256" in e and e["type"] == "conv":
+            assert sha(o["f32"]) == e["f32_sha256"], f"layer {i} f32"
+    onet = oracle.OracleNet(cfg, wts)
+    onet.prepare(np.float32(r["scale"]), int(r["zero_point"]))
+    want = onet.forward(x, accum=oracle.ACC_EXACT, want_s1=True)
+    same_input = True  # the exact net's input to layer i still equals the reference's
+    checked = 0
+    for i, inf in enumerate(info):
+        o, e = outs[binding.ACC_EXACT][i], g["layers"][i]
+        if inf["type"] == binding.T_CONV:
+            assert np.array_equal(o["int32"], want[i]["int32"].ravel()), f"layer {i} int32 vs oracle"
+            if same_input:
+                ex, s1 = want[i]["int32"], want[i]["s1"]
+                mask = (s1 <= 2 ** 24) & (np.abs(ex.astype(np.int64)) <= 2 ** 24)
+                assert int(mask.sum()) == e["exact_mask_count"] and sha(np.packbits(mask.ravel())) == e["exact_mask_sha256"], f"layer {i} mask"
+                assert sha(np.where(mask, o["int32"].reshape(ex.shape), 0).astype(np.int32)) == e["ref_int32_masked_sha256"], f"layer {i} masked int32"
+                assert sha(np.where(mask, o["u8"].reshape(ex.shape), 0).astype(np.uint8)) == e["ref_u8_masked_sha256"], f"layer {i} masked u8"
+                checked += 1
+        if inf["type"] != binding.T_YOLO:
+            assert np.array_equal(o["u8"], want[i]["u8"].ravel()), f"layer {i} u8 vs oracle"
+            same_input = same_input and sha(o["u8"]) == e["u8_sha256"]
+    assert checked >= 5  # layers 0..8 at least: K <= 1152 never leaves the fp32-exact regime on this image

@@ -225,3 +225,35 @@ def test_yolo_detections_vs_reference(golden_dir, name, seed):
             cnt, recs = oracle.yolo_detections(out, n, classes, side[0], side[1], anchors, mask, side[2], side[2], imw, imh, th, rel)
             assert_detections_match(cnt, recs, int(g[f"L{i}_det{k}_count"]), g[f"L{i}_det{k}_recs"])
             assert cnt > 0 or name == "s2_unit"
+
+
+@pytest.mark.parametrize("tag", ["leaky", "relu6"])
+def test_yolov3_tiny_416_real_image_hashes_ref_f32(golden_dir, cfg_dir, tmp_path, tag):
+    """BASELINE config[0], real-image half: the reference's test image as its own load_image_color ->
+    letterbox_image -> layer-0 dynamic quantiser saw it (tests/golden/realimg_416.npz, data only).  The oracle's quantiser on the
+    rebuilt float image returns the committed bytes / scale / zero point, and the oracle net prepared with THAT scale reproduces
+    the reference's per-layer hashes of all 24 layers (bit-faithful ref-f32 accumulation)."""
+    r = np.load(os.path.join(golden_dir, "realimg_416.npz"))
+    g = json.load(open(os.path.join(golden_dir, f"yolov3_tiny_{tag}_realimg.json")))
+    xf = synth.dequantized_float_image(r["input_u8"], r["scale"], r["zero_point"], r["fmin"], r["imin"], r["fmax"], r["imax"])
+    u8, s, zp = oracle.quantize_image(xf)
+    assert np.array_equal(u8.ravel(), r["input_u8"].ravel()) and np.float32(s) == r["scale"] and int(zp) == int(r["zero_point"])
+    assert sha(r["input_u8"]) == g["input_sha256"]
+    cfg = os.path.join(cfg_dir, g["cfg"])
+    wts = str(tmp_path / "w.weights")
+    assert synth.synth_weights(cfg, wts, seed=g["weight_seed"])["sha256"] == g["weights_sha256"]
+    net = oracle.OracleNet(cfg, wts)
+    net.prepare(np.float32(s), int(zp))
+    outs = net.forward(r["input_u8"], accum=oracle.ACC_REF_F32)
+    for e in g["layers"]:
+        i = e["i"]
+        if "prep_sha256" in e:
+            p = net.p[i]
+            assert sha(np.concatenate([p["biases_int32"].view(np.uint8), p["M_value"].view(np.uint8),
+                                       p["shift_value"].view(np.uint8)])) == e["prep_sha256"], f"prep {i}"
+        if "int32_sha256" in e:
+            assert sha(outs[i]["int32"]) == e["int32_sha256"], f"layer {i} int32"
+        if "u8_sha256" in e:
+            assert sha(outs[i]["u8"]) == e["u8_sha256"], f"layer {i} u8"
+        if "f32_sha256" in e and e["type"] == "conv":
+            assert sha(outs[i]["f32"]) == e["f32_sha256"], f"layer {i} f32"

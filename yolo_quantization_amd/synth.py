@@ -212,3 +212,14 @@ def synth_image_u8(c: int, h: int, w: int, seed: int = 7, batch: int | None = No
 
 def image_u8_to_float(x: np.ndarray) -> np.ndarray:
     return (x.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+
+
+def dequantized_float_image(u8, scale, zero_point, fmin, imin, fmax, imax) -> np.ndarray:
+    """A float image on which the reference's layer-0 dynamic quantiser (src/blas.c:108-168) returns exactly (u8, scale, zero_point):
+    every element is its own dequantised value (u8 - zp) * scale, except the two positions that carried the original image's extreme
+    floats (the quantiser's scale / zero point are functions of min and max alone).  tests/golden/realimg_416.npz holds the arguments;
+    tests/golden/make_golden.py checks the claim against the compiled reference when it writes them."""
+    x = ((np.asarray(u8).astype(np.int32).ravel() - int(zero_point)).astype(np.float32) * np.float32(scale)).astype(np.float32)
+    x[int(imin)] = np.float32(fmin)
+    x[int(imax)] = np.float32(fmax)
+    return x.reshape(np.asarray(u8).shape)
