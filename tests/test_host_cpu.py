@@ -339,3 +339,21 @@ def test_host_parser_swallows_the_reference_s_shipped_cfg(tmp_path, cfg_dir):
             (26, 128, 128, 26), (8, 0, 384, 26), (0, 384, 256, 26), (0, 256, 30, 26), (23, 30, 30, 26)]
     got = [(t[0], t[1], t[8], t[9]) for t in parses[0]]
     assert got == want
+
+
+def test_error_dies_with_this_library_s_message_inside_python(tmp_path, cfg_dir):
+    """The reference's error convention (ref src/utils.c:232-237: message, exit) must hold when libdarknet_q.so is loaded into a
+    process whose executable already binds `error` to glibc's error(int, int, fmt, ...) -- python does: without -Bsymbolic-functions
+    the host's own error("...") calls landed there, printed "python: " and crashed (round 4 finding)."""
+    import subprocess
+    code = f"""
+import sys; sys.path.insert(0, {ROOT!r})
+from yolo_quantization_amd import binding, synth
+cfg = {os.path.join(cfg_dir, 'tiny_unit.cfg')!r}
+synth.synth_weights(cfg, {str(tmp_path / 'w.weights')!r}, seed=1)
+net = binding.Net(cfg, {str(tmp_path / 'w.weights')!r}, batch=2)
+net.replica()   # not prepared: error()
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 255, (r.returncode, r.stderr[-500:])
+    assert "darknet_q: network_replica: the parent network is not prepared" in r.stderr

@@ -228,6 +228,58 @@ __device__ __forceinline__ void leaky_lut_build(uint8_t *lut, int zp_act, int ti
         reinterpret_cast<uint32_t *>(lut)[i] = w;
     }
 }
+// ---------------------------------------------------------------------------------------------------------
+// Integer requantisation (round 4).  With the reference's decomposition M = M0 * 2^-31 * 2^-s (src/blas.c:387-418: M0 an int32 in
+// [2^30, 2^31), shift_value = 2^-s exactly), the epilogue's  q = trunc(fl((double)a * M_value) * 2^-s)  is, for every accumulator a with
+// |a| * M0 < 2^53 (the FP64 product is then EXACT, so nothing is rounded before the truncation),
+//     q = trunc(a * M0 / 2^(31+s)),       f := floor(a * M0 / 2^(31+s)) = mulhi_i32(a, M0) >> (s - 1)      (s >= 1)
+// and f == q for a >= 0, f == q - 1 for a < 0 unless a * M0 is an exact multiple of 2^(31+s) -- impossible for -2^(31+s-tz) < a < 0,
+// tz = trailing zero bits of M0.  Two full-rate integer instructions (v_mul_hi_i32, v_ashrrev_i32) replace convert / FP64 multiply /
+// convert and the 64-bit register pairs that go with them.  The pooled kernels only requantise window maxima INSIDE their wrap-safe
+// accumulator range [lo, hi], so the three conditions are checked per channel against that range when the kernel starts
+// (intrq_make); a channel that fails keeps the FP64 form for the whole launch.  What consumes f: the LEAKY byte table indexed by f
+// (leaky_lutf_build: entry f holds the byte of q = f + (f < 0)), or RELU6's zp + max(f, 0) == zp + max(q, 0).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool intrq_make(double mval, int s, int32_t lo, int32_t hi, int32_t &m0, int32_t &sh)
+{
+    m0 = 0; sh = 0;
+    if (!(mval > 0.0 && mval < 1.0) || s < 1 || s > 31) return false;
+    const double t = mval * 2147483648.0;   // exact: a power-of-two scaling
+    const int32_t m = (int32_t)t;
+    if ((double)m != t || m <= 0) return false;   // M_value is not an int32 * 2^-31
+    const long amax = (-(long)lo > (long)hi) ? -(long)lo : (long)hi;
+    if (amax < 0 || (unsigned long)amax * (unsigned long)m >= (1ul << 53)) return false;  // FP64 product not provably exact
+    const int tz = __builtin_ctz((unsigned)m);
+    const int e = 31 + s - tz;   // a * M0 % 2^(31+s) == 0  <=>  a % 2^e == 0
+    if (e < 40 && lo < 0 && -(long)lo >= (1l << e)) return false;  // a negative exact multiple inside the range
+    m0 = m; sh = s - 1;
+    return true;
+}
+__device__ __forceinline__ int32_t intrq_floor(int32_t a, int32_t m0, int32_t sh) { return __mulhi(a, m0) >> sh; }
+// the LEAKY byte table for the floor form: entry f -> byte of q = f + (f < 0)
+template <bool SAT>
+__device__ __forceinline__ void leaky_lutf_build(uint8_t *lut, int zp_act, int tid, int nthreads)
+{
+    for (int i = tid; i < LUTQ_N / 4; i += nthreads) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = 4 * i + e - LUTQ_OFF;
+            w |= leaky_byte_biased<SAT>(f < 0 ? f + 1 : f, zp_act) << (8 * e);
+        }
+        reinterpret_cast<uint32_t *>(lut)[i] = w;
+    }
+}
+// LEAKY on the floor form, branch free in four VALU instructions, for -65 545 <= f <= 40 000 (always true for window maxima inside the
+// wrap-safe range: -10 zp - 6 <= f <= 255):  with q = f + (f < 0),
+//     q < 0:  round(q * 0.1) = -((|q| + 5) / 10) = floor((q + 4) / 10) = floor((f + 5) / 10) = ((f + 5) * 52428) >> 19      (arithmetic shift)
+//     q >= 0: q = f
+// and the first expression never exceeds f for f >= 0 nor falls below it for f < 0:  v = zp + max(floor form, f).
+__device__ __forceinline__ int32_t leaky_of_floor(int32_t f, int zp_act)
+{
+    const int32_t k = 5 * 52428 + (zp_act << 19);
+    return max((__mul24(f, 52428) + k) >> 19, f + zp_act);
+}
 // four table bytes (each in the low byte of its dword) -> one packed dword
 __device__ __forceinline__ uint32_t pack4_bytes(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
 {

@@ -258,6 +258,36 @@ int conv_ref_f32_launch(AuxArgs &a, hipStream_t st)
 // column 1, so that x = 32 tx - 1 sits at the EVEN column 4 and a lane's five-cell reads stay 8-byte aligned (ds_read_b64)
 __host__ __device__ constexpr int first_stage_rowc(bool planar) { return planar ? 42 : 34; }
 
+// The first-layer pooled kernels' exact path: every value of the 2x2 window requantised, then the maximum of the BYTES (the reference's
+// order: src/convolutional_layer.c:737-749 then src/maxpool_layer.c:134-146).  Only taken by waves that see an accumulator outside the
+// wrap-safe range.  acc[j][r]: window position j, channel r, biased by lo[r].
+template <int ACT, bool SAT>
+__device__ __forceinline__ uint32_t first_pool_exact_path(const v4i (&acc)[4], const v4i &lo, const double (&mp)[4], const double *mval4,
+                                                       const double *sval4, int zp_act, bool pow2)
+{
+    int32_t accb[4][4], m[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accb[r][j] = (int32_t)((uint32_t)acc[j][r] + (uint32_t)lo[r]);  // true accumulators
+    if (pow2) {
+        int32_t v[4][4];
+        requant_values<ACT, SAT, 4>(accb, mp, zp_act, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int32_t t = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                t = max(t, (int32_t)requant_u8(accb[r][j], 0, mval4[r], sval4[r], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
+            m[r] = t;
+        }
+    }
+    return pack4_biased(m[0], m[1], m[2], m[3]);
+}
+
 template <int ACT, bool SAT, int NM, bool PLANAR>
 __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxArgs a)
 {
@@ -276,14 +306,21 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + 7) >> 3, tpi = tiles_x * tiles_y;
     const int ntiles = a.B * tpi;
     const bool pow2 = a.hdr->pow2 == 1;
-    if constexpr (LUT) leaky_lut_build<false>(lut, a.zp_act, tid, 256);  // visible after the __syncthreads_or below
 
     // ---- per-lane constants: A fragments (row = channel 16*mt + pc, k-group g), channel parameters of the lane's four
     //      accumulator rows 16*mt + 4*g + r
-    v4i wa[NM], wd1[NM], wd2[NM], cb[NM], lo[NM], hi[NM];
+    // Two A fragments per m-tile: window column jx = 0 reads image cells x-1 .. x+1 = cells 0 .. 2 of the lane's four-cell group, column
+    // jx = 1 cells 1 .. 3 of the SAME group -- so the weights, not the B operand, are shifted by one cell: both window columns use one
+    // aligned four-register B operand per image row (round 4; shifting the operand cost five-cell reads and seven v_mov per unit).
+    v4i wa[NM][2], wd1[NM][2], wd2[NM][2], cb[NM], lo[NM], hi[NM];
     int chq[NM];
     double mp[NM][4];
-    int never_l = 0;
+    // integer requantisation of the window maxima (common.h intrq_make): multiplier M0 and shift s - 1 per channel, valid for the
+    // whole launch only if EVERY channel's wrap-safe range passes the exactness conditions (workgroup-uniform flag)
+    constexpr bool INTRQ = LUT || ACT == MI355_ACT_RELU6;
+    int32_t qm0[NM][4], qsh[NM][4];
+    const int32_t *shiftp = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(a.hdr) + a.hdr->off_shift);
+    int never_l = 0, noint_l = 0;
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt) {
         const int ch = 16 * mt + pc;
@@ -291,12 +328,15 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         const int d1 = dz > 127 ? 127 : dz, d2 = dz - d1;  // dz in [-127, 128]
         const uint32_t m1 = (uint32_t)(d1 & 0xFF) * 0x00010101u, m2 = (uint32_t)(d2 & 0xFF) * 0x00010101u;
 #pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {
-            const bool real = g < 3 && dx < 3;
-            wa[mt][dx] = real ? (int)(a.wfirst[ch * 9 + 3 * g + dx] ^ 0x00808080u) : 0;  // w' = w - 128 on the three channels
-            wd1[mt][dx] = real ? (int)m1 : 0;
-            wd2[mt][dx] = real ? (int)m2 : 0;
-        }
+        for (int jx = 0; jx < 2; ++jx)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int t = dx - jx;  // tap column of cell dx for window column jx
+                const bool real = g < 3 && t >= 0 && t < 3;
+                wa[mt][jx][dx] = real ? (int)(a.wfirst[ch * 9 + 3 * g + t] ^ 0x00808080u) : 0;  // w' = w - 128 on the three channels
+                wd1[mt][jx][dx] = real ? (int)m1 : 0;
+                wd2[mt][jx][dx] = real ? (int)m2 : 0;
+            }
         chq[mt] = 16 * mt + 4 * g;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -307,15 +347,22 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
             if (!SAT) small_safe_range<ACT>(m, a.zp_act, l, h);
             int32_t lb = 0; uint32_t rg = 0;
             if (!biased_safe_range(l, h, lb, rg)) never_l = 1;
+            qm0[mt][r] = qsh[mt][r] = 0;
+            if (INTRQ && (!pow2 || !intrq_make(a.mval[c2], shiftp[c2], lb, (int32_t)((uint32_t)lb + rg), qm0[mt][r], qsh[mt][r]))) noint_l = 1;
             cb[mt][r] = (int32_t)((uint32_t)a.cwb[c2] - (uint32_t)lb);  // accumulators biased by the safe range's lower end (common.h)
             lo[mt][r] = lb;
             hi[mt][r] = (int32_t)rg;  // hi - lo
         }
     }
     const bool never = __syncthreads_or(never_l) != 0;
+    const bool use_int = INTRQ && __syncthreads_or(noint_l) == 0;
+    if constexpr (LUT) {  // visible after the first __syncthreads of the tile loop
+        if (use_int) leaky_lutf_build<false>(lut, a.zp_act, tid, 256);
+        else leaky_lut_build<false>(lut, a.zp_act, tid, 256);
+    }
     bool need_d2 = false;
 #pragma unroll
-    for (int mt = 0; mt < NM; ++mt) need_d2 |= __builtin_amdgcn_ballot_w64(wd2[mt][0] != 0) != 0;
+    for (int mt = 0; mt < NM; ++mt) need_d2 |= __builtin_amdgcn_ballot_w64(wd2[mt][0][0] != 0) != 0;
 
     // ---- staging: thread t owns image dwords t, t + 256, t + 512 (< 612): their cell offsets from the tile origin
     int soff[3];
@@ -358,7 +405,9 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
             // out-of-image groups read a clamped in-image address and are replaced by the pad value
             const int y = 16 * p.ty - 1 + prow_ix, x0 = 32 * p.tx - 4 + 4 * pq;
             const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x0 < (unsigned)a.W && tid < 180;
-            const uint8_t *tbase = a.x + (size_t)p.b * 3 * plane_sz + (size_t)(16 * p.ty) * a.W + 32 * p.tx;
+            // (32-bit: the launcher refuses inputs of 2 GiB and more)
+            const unsigned tb = ((unsigned)p.b * 3u) * (unsigned)plane_sz + (unsigned)(16 * p.ty) * (unsigned)a.W + 32u * (unsigned)p.tx;
+            const uint8_t *tbase = a.x + (size_t)tb;
             const unsigned off = inside ? (unsigned)(planar_off + (int)plane_sz) : (unsigned)plane_sz;  // biased by one plane: never negative
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -419,65 +468,81 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         advance(nxp);
         if (more) fetch(nxp, nxt);
         const int b = cur.b, ty = cur.ty, tx = cur.tx;
+        // byte offset of the patch's first pooled cell: wave-uniform 32-bit arithmetic on the scalar unit (the launcher refuses pooled
+        // tensors of 4 GiB and more), once per tile; a pooled row further down is one row pitch on.  The store then is
+        // "scalar base + the lane's loop-invariant 32-bit offset".
+        const unsigned tile_off = (unsigned)(a.pool_lead + (b * (OH + 1) + 8 * ty + 1) * (OW + 1) + 16 * tx) * (unsigned)a.pool_cs;
+        const unsigned rowpitch = (unsigned)(OW + 1) * (unsigned)a.pool_cs;
+        const bool colvalid = 16 * tx + pc < OW;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int pr = 2 * wave + s;  // pooled row inside the patch
-            const int prow = 8 * ty + pr, pcol = 16 * tx + pc;
-            const bool valid = prow < OH && pcol < OW;
-            // two image rows x five cells feed the four window positions of this lane's k-group
+            const bool valid = colvalid && 8 * ty + pr < OH;
+            // two image rows x four cells (x = 2 pcol - 1 .. 2 pcol + 2) feed the four window positions of this lane's k-group:
+            // one aligned 16-byte operand per row (8-byte aligned in LDS: two dwords each from a ds_read2_b64)
             const uint32_t *p0 = img[buf] + (2 * pr + (g < 3 ? g : 2)) * ROWC + 2 * pc + XO;
-            uint32_t rw[2][5];
+            v4i bf[2];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                rw[0][i] = p0[i];
-                rw[1][i] = p0[ROWC + i];
+            for (int jy = 0; jy < 2; ++jy) {
+                const uint2 q0 = *reinterpret_cast<const uint2 *>(p0 + jy * ROWC), q1 = *reinterpret_cast<const uint2 *>(p0 + jy * ROWC + 2);
+                bf[jy] = v4i{(int)q0.x, (int)q0.y, (int)q1.x, (int)q1.y};
             }
-            // wave-uniform part of the pooled cell (scalar arithmetic) + the lane's column (precomputed byte offset)
-            const long rowcell = (long)a.pool_lead + ((long)b * (OH + 1) + (prow + 1)) * (OW + 1) + 16 * tx;
-            uint8_t *outp = a.ypool + rowcell * a.pool_cs + pc_off;
+            uint8_t *const outp = a.ypool + (size_t)(tile_off + (unsigned)pr * rowpitch);  // wave-uniform
 #pragma unroll
             for (int mt = 0; mt < NM; ++mt) {
                 v4i acc[4];
                 if (!(a.debug_flags & 131072)) __builtin_amdgcn_s_setprio(3);  // the MFMA chain outranks the other waves' requantisation
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int jy = j >> 1, jx = j & 1;
-                    const v4i bf = {(int)rw[jy][jx], (int)rw[jy][jx + 1], (int)rw[jy][jx + 2], (int)rw[jy][jx + 3]};
-                    acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[mt], bf, cb[mt], 0, 0, 0);
-                }
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[mt][j & 1], bf[j >> 1], cb[mt], 0, 0, 0);
                 // the correction passes as their own rounds over the four (independent) window positions; the dz = 128
                 // pass is chosen once, not behind a branch after every MFMA
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int jy = j >> 1, jx = j & 1;
-                    const v4i bf = {(int)rw[jy][jx], (int)rw[jy][jx + 1], (int)rw[jy][jx + 2], (int)rw[jy][jx + 3]};
-                    acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd1[mt], bf, acc[j], 0, 0, 0);
-                }
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd1[mt][j & 1], bf[j >> 1], acc[j], 0, 0, 0);
                 if (need_d2) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int jy = j >> 1, jx = j & 1;
-                        const v4i bf = {(int)rw[jy][jx], (int)rw[jy][jx + 1], (int)rw[jy][jx + 2], (int)rw[jy][jx + 3]};
-                        acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt], bf, acc[j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt][j & 1], bf[j >> 1], acc[j], 0, 0, 0);
                 }
                 __builtin_amdgcn_s_setprio(0);
                 // accumulators are biased by lo: one unsigned maximum gives the range test and the window maximum (common.h)
-                int32_t accb[4][4], amax[4][1];
+                uint32_t umax[4];
                 bool bad = never;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) accb[r][j] = acc[j][r];
-                    const uint32_t u = max(max((uint32_t)accb[r][0], (uint32_t)accb[r][1]), max((uint32_t)accb[r][2], (uint32_t)accb[r][3]));
-                    bad |= u > (uint32_t)hi[mt][r];
-                    amax[r][0] = (int32_t)(u + (uint32_t)lo[mt][r]);
+                    umax[r] = max(max((uint32_t)acc[0][r], (uint32_t)acc[1][r]), max((uint32_t)acc[2][r], (uint32_t)acc[3][r]));
+                    bad |= umax[r] > (uint32_t)hi[mt][r];
                 }
-                int32_t m[4];
-                uint32_t packed = 0;
-                bool packed_done = false;
+                uint32_t packed;
                 if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {
-                    if constexpr (LUT) {  // q of a window inside the safe range lies inside the table (common.h)
+                    int32_t amax[4][1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
+                    if (INTRQ && use_int) {  // two integer instructions per value instead of convert / FP64 multiply / convert
+                        int32_t f[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] = intrq_floor(amax[r][0], qm0[mt][r], qsh[mt][r]);
+#ifndef MI355_L0_LEAKY_ARITH
+                        if constexpr (LUT) {
+                            uint32_t bt[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) bt[r] = lut[f[r] + LUTQ_OFF];
+                            packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
+                        } else
+#else
+                        if constexpr (LUT) {  // A/B build: LEAKY in four VALU instructions on the floor form instead of the table's LDS round trip
+                            packed = pack4_biased(leaky_of_floor(f[0], a.zp_act), leaky_of_floor(f[1], a.zp_act), leaky_of_floor(f[2], a.zp_act),
+                                                  leaky_of_floor(f[3], a.zp_act));
+                        } else
+#endif
+                        {  // RELU6: zp + max(q, 0) == zp + max(f, 0); SAT clamps
+                            int32_t v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                v[r] = a.zp_act + max(f[r], 0);
+                                if (SAT) v[r] = min(v[r], 255);
+                            }
+                            packed = pack4_biased(v[0], v[1], v[2], v[3]);
+                        }
+                    } else if constexpr (LUT) {  // q of a window inside the safe range lies inside the table (common.h)
                         // four independent chains, issued pass by pass: left alone the compiler threads all four conversions through
                         // one register pair and every FP64 instruction waits out the latency of the one before it
                         uint32_t bt[4];
@@ -495,38 +560,15 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
 #pragma unroll
                         for (int r = 0; r < 4; ++r) bt[r] = lut[qq[r] + LUTQ_OFF];
                         packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
-                        packed_done = true;
                     } else {
                         int32_t v1[4][1];
                         requant_values<ACT, SAT, 1>(amax, mp[mt], a.zp_act, v1);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) m[r] = v1[r][0];
+                        packed = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
                     }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) accb[r][j] = (int32_t)((uint32_t)accb[r][j] + (uint32_t)lo[mt][r]);  // true accumulators
-                    if (pow2) {
-                        int32_t v[4][4];
-                        requant_values<ACT, SAT, 4>(accb, mp[mt], a.zp_act, v);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            int32_t t = 0;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                t = max(t, (int32_t)requant_u8(accb[r][j], 0, a.mval[chq[mt] + r], a.sval[chq[mt] + r], a.zp_act,
-                                                               ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
-                            m[r] = t;
-                        }
-                    }
+                } else {  // some window of this wave may wrap (or odd shifts): the reference's order, bytes first, then the maximum
+                    packed = first_pool_exact_path<ACT, SAT>(acc, lo[mt], mp[mt], a.mval + chq[mt], a.sval + chq[mt], a.zp_act, pow2);
                 }
-                if (!packed_done) packed = pack4_biased(m[0], m[1], m[2], m[3]);
-                if (valid) *reinterpret_cast<uint32_t *>(outp + chq[mt]) = packed;
+                if (valid) *reinterpret_cast<uint32_t *>(outp + (pc_off + (unsigned)chq[mt])) = packed;
             }
         }
         if (more) stash(buf ^ 1, nxt);
@@ -810,6 +852,9 @@ int conv_first_mfma_pool_launch(AuxArgs &a, hipStream_t st)
     if (a.planar ? ((a.W & 3) || (reinterpret_cast<size_t>(a.x) & 3)) : a.in_cs != 4) return MI355_EINVAL;
     if ((long)a.in_cells + 64L * (a.W + 1) >= (1L << 31)) return MI355_EINVAL;  // 32-bit cell arithmetic in the kernel
     const int OH = a.H / 2, OW = a.W / 2;
+    // 32-bit byte offsets in the kernel: the pooled tensor and (planar) the input planes
+    if (((long)a.pool_lead + (long)a.B * (OH + 1) * (OW + 1) + OW + 2) * a.pool_cs >= (1L << 32)) return MI355_EINVAL;
+    if (a.planar && (long)a.B * 3 * a.H * a.W >= (1L << 31)) return MI355_EINVAL;
     const long ntiles = (long)a.B * ((OW + 15) / 16) * ((OH + 7) / 8);
     const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // persistent: four workgroups per CU (five measured slower)
     if (a.n == 16) {

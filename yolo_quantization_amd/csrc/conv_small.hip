@@ -74,6 +74,65 @@ __device__ __forceinline__ uint32_t pool_requant_quad(const int32_t (&accb)[4][4
     return pack4_biased(m[0], m[1], m[2], m[3]);
 }
 
+// Round 4: the same on accumulators BIASED by the lower end of the wrap-safe range (the seed cw + bias - lo is the MFMA's C operand /
+// the accumulator's start value: free), common.h biased_safe_range: one unsigned maximum over the window is the range test and the
+// maximum (3 VALU per pooled output instead of 8), and the maximum is requantised with two integer instructions where the launch's
+// channels allow it (common.h intrq_make; use_int is workgroup-uniform) -- 11 VALU per pooled output instead of ~21 on the fast path.
+// u[r][j] = biased accumulator of channel r at window position j; lo / rg = lower end and width of the safe range; `never`: some
+// channel of the launch has no safe range at all.
+template <int ACT, bool SAT>
+__device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)[4][4], const int (&lo)[4], const int (&rg)[4], bool never,
+                                                             bool use_int, const int (&m0)[4], const int (&sh)[4], const double *ldsMP4,
+                                                             int zp_act, bool pow2, const double *mval4, const double *sval4)
+{
+    uint32_t umax[4];
+    bool bad = never;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        umax[r] = max(max(u[r][0], u[r][1]), max(u[r][2], u[r][3]));
+        bad |= umax[r] > (uint32_t)rg[r];
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {  // no window of this wave can wrap: requantise the maxima
+        int32_t amax[4][1], v[4][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[r]);
+        if ((ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT && use_int) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int32_t f = intrq_floor(amax[r][0], m0[r], sh[r]);
+                v[r][0] = ACT == MI355_ACT_LEAKY ? leaky_of_floor(f, zp_act) : zp_act + max(f, 0);
+            }
+        } else {
+            const double mp[4] = {ldsMP4[0], ldsMP4[1], ldsMP4[2], ldsMP4[3]};
+            requant_values<ACT, SAT, 1>(amax, mp, zp_act, v);
+        }
+        return pack4_biased(v[0][0], v[1][0], v[2][0], v[3][0]);
+    }
+    int32_t accb[4][4];  // true accumulators: the reference's order, bytes first, then the max
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accb[r][j] = (int32_t)(u[r][j] + (uint32_t)lo[r]);
+    int32_t m[4];
+    if (pow2) {
+        const double mp[4] = {ldsMP4[0], ldsMP4[1], ldsMP4[2], ldsMP4[3]};
+        int32_t v[4][4];
+        requant_values<ACT, SAT, 4>(accb, mp, zp_act, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
+    } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int32_t t = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                t = max(t, (int32_t)requant_u8(accb[r][j], 0, mval4[r], sval4[r], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
+            m[r] = t;
+        }
+    }
+    return pack4_biased(m[0], m[1], m[2], m[3]);
+}
+
 // MODE 0: conv + 2x2/2 maxpool.  1: no pool, the four window positions of a lane are four output pixels.  2: stride-2
 // convolution = the stride-1 output at the even positions = window position 0 only (a quarter of the MFMAs), stored on the
 // pooled geometry (the output map of a stride-2 3x3 pad-1 convolution on an even map is the pooled map).
@@ -105,7 +164,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier
     int *ldsDZ = reinterpret_cast<int *>(ldsMP + N);                      // [N] 128 - zp_w
     int *ldsCB = ldsDZ + N;                                               // [N] cw + bias
-    int *ldsLO = ldsCB + N, *ldsHI = ldsLO + N;                           // [N] wrap-safe accumulator range
+    int *ldsLO = ldsCB + N, *ldsHI = ldsLO + N;                           // [N] wrap-safe accumulator range (POOL: lower end, width)
+    int *ldsM0 = ldsHI + N, *ldsSH = ldsM0 + N;                           // [N] integer requantisation: M0, s - 1 (common.h intrq_make)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
     const int tid = threadIdx.x;
@@ -119,17 +179,33 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     const int ntiles = patch ? a.B * tpi : (total_p + SM_PPB - 1) / SM_PPB;
     const bool pow2 = a.hdr->pow2 == 1;
 
-    // ---- per-channel parameters and the wrap-safe ranges
+    // ---- per-channel parameters and the wrap-safe ranges.  POOL: the accumulators are kept BIASED by the range's lower end (seed
+    //      cw + bias - lo), ldsLO / ldsHI hold that end and the range's width (common.h biased_safe_range)
+    int never_l = 0, noint_l = 0;
     if (tid < N) {
         const double mp = a.mprime[tid];
         ldsMP[tid] = mp;
         ldsDZ[tid] = a.dzp[tid];
-        ldsCB[tid] = a.cwb[tid];
         int32_t lo = -2147483647 - 1, hi = 2147483647;
         if (!SAT && POOL) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
-        ldsLO[tid] = lo;
-        ldsHI[tid] = hi;
+        int32_t m0 = 0, sh = 0;
+        if constexpr (POOL) {
+            int32_t lb = 0; uint32_t rg = 0;
+            if (!biased_safe_range(lo, hi, lb, rg)) never_l = 1;
+            if (!(pow2 && intrq_make(a.mval[tid], a.shift[tid], lb, (int32_t)((uint32_t)lb + rg), m0, sh))) noint_l = 1;
+            ldsCB[tid] = (int32_t)((uint32_t)a.cwb[tid] - (uint32_t)lb);
+            ldsLO[tid] = lb;
+            ldsHI[tid] = (int32_t)rg;
+        } else {
+            ldsCB[tid] = a.cwb[tid];
+            ldsLO[tid] = lo;
+            ldsHI[tid] = hi;
+        }
+        ldsM0[tid] = m0;
+        ldsSH[tid] = sh;
     }
+    const bool never = POOL && __syncthreads_or(never_l) != 0;
+    const bool use_int = POOL && __syncthreads_or(noint_l) == 0;
 
     // ---- stationary A fragments: plane ws = [m-tile][k-step][lane][16 B]
     v4i wf[NM][KST];
@@ -361,12 +437,21 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
                 double mp[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    mp[r] = ldsMP[ch0 + r];
+                    if (!POOL) mp[r] = ldsMP[ch0 + r];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) accb[r][j] = j >= NJ ? 0 : (DZM ? acc[j][grp * 4 + r] : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]));
                 }
                 if constexpr (POOL) {
-                    pk[mt][grp] = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
+                    const int4 m04 = *reinterpret_cast<const int4 *>(ldsM0 + ch0);
+                    const int4 sh4 = *reinterpret_cast<const int4 *>(ldsSH + ch0);
+                    const int m0v[4] = {m04.x, m04.y, m04.z, m04.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+                    uint32_t ub[4][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ub[r][j] = (uint32_t)accb[r][j];
+                    pk[mt][grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, use_int, m0v, shv, ldsMP + ch0, a.zp_act, pow2,
+                                                                     a.mval + ch0, a.sval + ch0);
                 } else if constexpr (MODE == 2) {  // stride 2: one value per (pixel, channel), plain requantisation
                     int32_t a1[4][1], v1[4][1];
 #pragma unroll
@@ -782,7 +867,7 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
     size_t lds = 2 * (size_t)(c / 16) * a.sm_pieceb + (size_t)a.rows_cap * a.sm_ncell * 4;
     lds = (lds + 15) & ~(size_t)15;
     a.lds_param_off = (int)lds;
-    lds += (size_t)a.n * 24;
+    lds += (size_t)a.n * 32;
     if (lds > 160 * 1024) return MI355_EINVAL;
     // persistent workgroups per CU: LDS permitting; the c = 16, n = 32 variant needs few enough registers for three
     int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
