@@ -6,6 +6,7 @@ import hashlib
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
