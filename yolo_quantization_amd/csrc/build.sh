@@ -11,7 +11,10 @@ pids=()
 for f in conv_igemm conv_rows conv_rows16 conv_rows_k1 conv_small conv1x1 conv_ws3 conv_aux glue comm shim; do
   if [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ "$HERE/conv_rows.hip" -nt "$OUT/$f.o" -a "$f" = conv_rows_k1 ] || [ "$HERE/kargs.h" -nt "$OUT/$f.o" ] || \
      [ "$HERE/common.h" -nt "$OUT/$f.o" ] || [ "$HERE/../../include/mi355_yolo_int8.h" -nt "$OUT/$f.o" ]; then
-    $HIPCC $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$HERE/$f.hip" -o "$OUT/$f.o" &
+    # conv_rows16: its 128-row wave tiles unroll past clang's default pragma-unroll budget; a loop left rolled indexes the accumulator
+    # array dynamically, which then lives in scratch memory (one scratch store behind every MFMA)
+    X=""; [ "$f" = conv_rows16 ] && X="-mllvm -pragma-unroll-threshold=1000000"
+    $HIPCC $FLAGS $X ${EXTRA_HIPCC_FLAGS:-} -c "$HERE/$f.hip" -o "$OUT/$f.o" &
     pids+=($!)
   fi
 done

@@ -165,22 +165,17 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
         const int q = nb >> 3, r = nb & 7, xcd = id & 7, idx = id >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // `logical` gives every XCD (workgroup id % 8) one contiguous range of tiles.  M-major ranges make an XCD read few
-    // weight slabs but the whole input; when the launcher found a better split (xcd_gm) the XCD owns a block of
-    // (mtiles / gm) x (ntiles / gn) tiles instead, so that the weights + input slices its L2 has to hold are smallest.
+    // `logical` gives every XCD (workgroup id % 8) one contiguous range of tiles.  Tiles are numbered in blocks of xcd_mb M tiles:
+    // inside a block N-major (the xcd_mb M tiles of one N tile are neighbours), block after block -- so an XCD's range is about
+    // xcd_mb M tiles x (range / xcd_mb) N tiles whatever the tile counts are (no divisibility conditions: L12's 8 x 85 tiles of
+    // the throughput plan fetched 62.7 MB per launch M-major, every XCD the whole input).  xcd_mb = 1 is the M-major order; the
+    // launcher picks the block height that minimises weight slabs + input rows per L2.
     int mtile, ntile;
-    if (a.xcd_gm > 0) {
-        // (the launcher sets xcd_gm only when the grid is a multiple of 8: logical = xcd * per + idx, XCD `xcd`, tile `idx` of it)
-        const int x = blockIdx.x & 7, within = blockIdx.x >> 3;
-        const int gm = a.xcd_gm, lg = gm == 8 ? 3 : gm == 4 ? 2 : gm == 2 ? 1 : 0;  // gm is a power of two
-        const int mt_per = a.mtiles >> lg, nt_per = a.ntiles_n >> (3 - lg);
-        const int xm = x & (gm - 1), xn = x >> lg;
-        const int wq = fd_div(within, a.fd_ntper);
-        mtile = xm * mt_per + wq;
-        ntile = xn * nt_per + (within - wq * nt_per);
-    } else {
-        mtile = fd_div(logical, a.fd_ntn);
-        ntile = logical - mtile * a.ntiles_n;
+    {
+        const int blk = fd_div(logical, a.fd_ntper);            // / (xcd_mb * ntiles_n)
+        const int rem = logical - blk * (a.xcd_mb * a.ntiles_n);
+        ntile = fd_div(rem, a.fd_mb);
+        mtile = blk * a.xcd_mb + (rem - ntile * a.xcd_mb);
     }
     // N tiles split the flattened pixel range evenly (tile widths differ by at most one pixel and never exceed BN):
     // the host picks ntiles_n so that mtiles * ntiles_n fills whole rounds of workgroups over the 256 CUs.
@@ -824,20 +819,22 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
                                 (int)lds) != hipSuccess)
             return MI355_EHIP;
     }
-    // XCD grid: minimise the bytes one XCD's L2 has to pull in = its M tiles' weight slabs + its N tiles' input rows
-    a.xcd_gm = 0;
+    // XCD tile order: minimise the bytes one XCD's L2 has to pull in = its M tiles' weight slabs + its N tiles' input rows
+    a.xcd_mb = 1;
     if (!(a.debug & (1 << 24))) {
-        const long nb = (long)a.ntiles_n * a.mtiles;
+        const long nb = (long)a.ntiles_n * a.mtiles, per = (nb + 7) / 8;
         const double wslab = (double)BM * a.ksteps * 64, itile = (double)a.total_n / a.ntiles_n * a.cb * a.nchunks;
         double best = 0;
-        for (int gm = 1; gm <= 8; gm <<= 1) {
-            const int gn = 8 / gm;
-            if (nb % 8 || a.mtiles % gm || a.ntiles_n % gn) continue;
-            const double bytes = (a.mtiles / gm) * wslab + (a.ntiles_n / gn) * itile;
-            if (a.xcd_gm == 0 || bytes < best) { best = bytes; a.xcd_gm = gm; }
+        for (int mb = 1; mb <= a.mtiles; ++mb) {
+            if (a.mtiles % mb) continue;
+            const long blk = (long)mb * a.ntiles_n;
+            const long mt = std::min<long>(a.mtiles, mb * ((per + blk - 1) / blk)), nt = std::min<long>(a.ntiles_n, (per + mb - 1) / mb + (per % mb || blk % per || nb % 8 ? 1 : 0));  // ranges that start inside an N tile's column touch one more
+            const double bytes = mt * wslab + nt * itile;
+            if (mb == 1 || bytes < best) { best = bytes; a.xcd_mb = mb; }
         }
     }
-    a.fd_ntper = fastdiv_make((uint32_t)(a.xcd_gm > 0 ? a.ntiles_n / (8 / a.xcd_gm) : 1));
+    a.fd_ntper = fastdiv_make((uint32_t)(a.xcd_mb * a.ntiles_n));
+    a.fd_mb = fastdiv_make((uint32_t)a.xcd_mb);
     dim3 grid(a.ntiles_n * a.mtiles), block(NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;

@@ -68,7 +68,7 @@ __device__ __forceinline__ void row16_of_pixel(int n, int H, int W, FastDiv fd_h
 // NBX: extra B DMA slots per DMA wave, for maps that fill their LDS row image badly (19 + 2 cells in a 32-slot row: a 384-pixel tile
 // then spans more rows than the slot count sized for W >= 3/4 RS covers).  Its own instantiation: the common one keeps its registers.
 template <int BM, int BN, int WMW, int WNW, int RS, int KS, int NBX = 0>
-__global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const ConvArgs a)
+__global__ __launch_bounds__(64 * WMW * WNW, (BM / WMW > 64 ? 1 : 2)) void conv_rows16_i8_kernel(const ConvArgs a)
 {
     constexpr int NW = WMW * WNW, NT = 64 * NW;
     constexpr int TM = BM / WMW, TN = BN / WNW;
@@ -123,22 +123,17 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
         const int q = nb >> 3, r = nb & 7, xcd = id & 7, idx = id >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // `logical` gives every XCD (workgroup id % 8) one contiguous range of tiles.  M-major ranges make an XCD read few
-    // weight slabs but the whole input; when the launcher found a better split (xcd_gm) the XCD owns a block of
-    // (mtiles / gm) x (ntiles / gn) tiles instead, so that the weights + input slices its L2 has to hold are smallest.
+    // `logical` gives every XCD (workgroup id % 8) one contiguous range of tiles.  Tiles are numbered in blocks of xcd_mb M tiles:
+    // inside a block N-major (the xcd_mb M tiles of one N tile are neighbours), block after block -- so an XCD's range is about
+    // xcd_mb M tiles x (range / xcd_mb) N tiles whatever the tile counts are (no divisibility conditions: L12's 8 x 85 tiles of
+    // the throughput plan fetched 62.7 MB per launch M-major, every XCD the whole input).  xcd_mb = 1 is the M-major order; the
+    // launcher picks the block height that minimises weight slabs + input rows per L2.
     int mtile, ntile;
-    if (a.xcd_gm > 0) {
-        // (the launcher sets xcd_gm only when the grid is a multiple of 8: logical = xcd * per + idx, XCD `xcd`, tile `idx` of it)
-        const int x = blockIdx.x & 7, within = blockIdx.x >> 3;
-        const int gm = a.xcd_gm, lg = gm == 8 ? 3 : gm == 4 ? 2 : gm == 2 ? 1 : 0;  // gm is a power of two
-        const int mt_per = a.mtiles >> lg, nt_per = a.ntiles_n >> (3 - lg);
-        const int xm = x & (gm - 1), xn = x >> lg;
-        const int wq = fd_div(within, a.fd_ntper);
-        mtile = xm * mt_per + wq;
-        ntile = xn * nt_per + (within - wq * nt_per);
-    } else {
-        mtile = fd_div(logical, a.fd_ntn);
-        ntile = logical - mtile * a.ntiles_n;
+    {
+        const int blk = fd_div(logical, a.fd_ntper);            // / (xcd_mb * ntiles_n)
+        const int rem = logical - blk * (a.xcd_mb * a.ntiles_n);
+        ntile = fd_div(rem, a.fd_mb);
+        mtile = blk * a.xcd_mb + (rem - ntile * a.xcd_mb);
     }
     // N tiles split the flattened pixel range evenly (tile widths differ by at most one pixel and never exceed BN):
     // the host picks ntiles_n so that mtiles * ntiles_n fills whole rounds of workgroups over the 256 CUs.
@@ -305,7 +300,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows16_i8_kernel(const
         //      them, IN PLACE: B fragment ni is reloaded right after its four MFMAs, the A fragments during the last two rounds.
         constexpr int R = RA_STAGES;
         static_assert(R >= 4 && R <= 6, "ring depths the stage bookkeeping below is written for");
-        static_assert(MI == 4 && NI >= 2, "written for 64-row wave tiles");
+        static_assert((MI == 4 || MI == 8) && NI >= 2, "written for 64-row wave tiles (128-row ones: one wave per SIMD, accumulators in the AGPRs)");
         constexpr int ROT = 9 % R;  // ring phase advance of one channel chunk (nine K-steps)
         v4i fa[MI], fb[NI];
         // Fragment reads are issued as inline asm so that hipcc does not account for them (its own bookkeeping puts an
@@ -703,20 +698,22 @@ static int rows16_launch_cfg(ConvArgs &a, hipStream_t st)
                                 (int)lds) != hipSuccess)
             return MI355_EHIP;
     }
-    // XCD grid: minimise the bytes one XCD's L2 has to pull in = its M tiles' weight slabs + its N tiles' input rows
-    a.xcd_gm = 0;
+    // XCD tile order: minimise the bytes one XCD's L2 has to pull in = its M tiles' weight slabs + its N tiles' input rows
+    a.xcd_mb = 1;
     if (!(a.debug & (1 << 24))) {
-        const long nb = (long)a.ntiles_n * a.mtiles;
+        const long nb = (long)a.ntiles_n * a.mtiles, per = (nb + 7) / 8;
         const double wslab = (double)BM * a.ksteps * 64, itile = (double)a.total_n / a.ntiles_n * a.cb * a.nchunks;
         double best = 0;
-        for (int gm = 1; gm <= 8; gm <<= 1) {
-            const int gn = 8 / gm;
-            if (nb % 8 || a.mtiles % gm || a.ntiles_n % gn) continue;
-            const double bytes = (a.mtiles / gm) * wslab + (a.ntiles_n / gn) * itile;
-            if (a.xcd_gm == 0 || bytes < best) { best = bytes; a.xcd_gm = gm; }
+        for (int mb = 1; mb <= a.mtiles; ++mb) {
+            if (a.mtiles % mb) continue;
+            const long blk = (long)mb * a.ntiles_n;
+            const long mt = std::min<long>(a.mtiles, mb * ((per + blk - 1) / blk)), nt = std::min<long>(a.ntiles_n, (per + mb - 1) / mb + (per % mb || blk % per || nb % 8 ? 1 : 0));  // ranges that start inside an N tile's column touch one more
+            const double bytes = mt * wslab + nt * itile;
+            if (mb == 1 || bytes < best) { best = bytes; a.xcd_mb = mb; }
         }
     }
-    a.fd_ntper = fastdiv_make((uint32_t)(a.xcd_gm > 0 ? a.ntiles_n / (8 / a.xcd_gm) : 1));
+    a.fd_ntper = fastdiv_make((uint32_t)(a.xcd_mb * a.ntiles_n));
+    a.fd_mb = fastdiv_make((uint32_t)a.xcd_mb);
     dim3 grid(a.ntiles_n * a.mtiles), block(NT);
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
@@ -738,6 +735,10 @@ static int rows16_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
 // variant with exact LDS rows + extra DMA slots can give 128 x 384 tiles (YOLOv3-608's 512 -> 1024 @19: 92.7 -> 66.2 us).  On
 // well-filled 32-slot rows (384 -> 256 @26) the 32x32x32 kernel is ~1 us faster (this kernel's 128 x 384 instantiation sits at the
 // 256-register limit there) and keeps the layer; 64-slot rows were not measured and stay with it too.
+// Round 4, measured and not kept: the 128 x 384 tile on FOUR waves of 128 x 96 (rows16_launch_cfg<128, 384, 1, 4, RS, 3>: one wave per
+// SIMD, 192 accumulators in the AGPRs, 14 fragment reads per 48 MFMAs instead of 10 per 24; compiles without scratch only with
+// -mllvm -pragma-unroll-threshold raised, see build.sh) -- bit-identical, L12 62-64 us against 54-57, L21 50-51 against 43-45
+// (profiles/r04_rows16_4wave_ab.log): with one wave per SIMD nothing covers the issuing wave's DMA instructions and barrier waits.
 // MI355_EINVAL -> conv_rows.hip's kernel.
 int conv_rows16_launch(ConvArgs &a, hipStream_t st, int bm, int bn)
 {

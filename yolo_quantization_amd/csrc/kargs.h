@@ -17,9 +17,9 @@ struct ConvArgs {
     int stride, OH, OW;      // output map = (H + 2*pad - ksize) / stride + 1 (== H, W for the stride-1 kernels)
     int ksize, cb, nchunks, upc, spc, ksteps;
     int total_n, ntiles_n, mtiles;
-    int xcd_gm;              // conv_rows: the 8 XCDs form an xcd_gm x (8 / xcd_gm) grid over (M tiles, N tiles); 0 = M-major ranges
+    int xcd_mb;              // conv_rows: tiles are numbered in blocks of xcd_mb M tiles, N-major inside a block (1 = M-major): what one XCD's contiguous range covers
     // conv_rows: launch constants of the index arithmetic (divisions by them are multiplications, common.h FastDiv)
-    FastDiv fd_hw, fd_w, fd_ntn, fd_ntper, fd_nch;  // H * W, W, ntiles_n, N tiles per XCD, channel chunks
+    FastDiv fd_hw, fd_w, fd_ntn, fd_ntper, fd_nch, fd_mb;  // H * W, W, ntiles_n, xcd_mb * ntiles_n, channel chunks, xcd_mb
     int tile_q, tile_r;      // N tile t covers pixels [t q + min(t, r), + q + (t < r))
     int zp_act, act, store_mode;
     float s_act;
