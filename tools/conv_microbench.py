@@ -78,6 +78,7 @@ if __name__ == "__main__":
     ap.add_argument("--shift", type=int, default=13); ap.add_argument("--plan", action="store_true")
     ap.add_argument("--nt", type=int, default=0); ap.add_argument("--dbg", type=int, default=0, help="mi355_debug_flags value (512 = no chunk rotation)"); ap.add_argument("--timeline", action="store_true"); ap.add_argument("--timeline3", action="store_true"); ap.add_argument("--waveprof", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="timing ablation of the K loop (results are wrong)")
+    ap.add_argument("--timeline16", action="store_true", help="conv_rows16: per-workgroup phase timestamps (-DMI355_ABLATE build)")
     a = ap.parse_args()
     SHIFT = a.shift
     binding.init(0)
@@ -90,6 +91,23 @@ if __name__ == "__main__":
             r = run(a.c, a.n, a.hw, a.k, a.batch, a.iters, tuple(a.tile) if a.tile else None, a.mode)
             print(name, r["us"], "us", r["tops"], "TOPS")
         S.mi355_debug_flags(0)
+    elif a.timeline16:
+        S = binding.shim()
+        S.mi355_debug_flags(a.dbg)
+        r = run(a.c, a.n, a.hw, a.k, a.batch, 1, tuple(a.tile) if a.tile else None, a.mode, nt=a.nt)
+        S.mi355_stream_sync(None)
+        ts = np.zeros((6, 4096), np.int64)
+        S.mi355_debug_read_ts16.argtypes = [C.c_void_p]
+        assert S.mi355_debug_read_ts16(ts.ctypes.data) == 0
+        nb = int((ts[0] > 0).sum())
+        t = ts[:, :nb].astype(np.float64) / 100.0  # us
+        t0 = t[0].min()
+        print(f"blocks {nb}; span first start .. last end {t[5].max() - t0:.2f} us; starts: p50 {np.median(t[0]) - t0:.2f}, p90 {np.percentile(t[0], 90) - t0:.2f}, max {t[0].max() - t0:.2f}")
+        for i, nm in [(0, "index math, DMA tables, prologue loads issued"), (1, "accumulator seeds, parameters, first image landed"), (2, "K loop"), (3, "epilogue: box sums + requantise"), (4, "copy-out")]:
+            d = t[i + 1] - t[i]
+            print(f"  {nm:52s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
+        d = t[5] - t[0]
+        print(f"  {'whole workgroup':52s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
     elif a.timeline:  # per-workgroup phase timestamps (needs the -DMI355_ABLATE build)
         S = binding.shim()
         r = run(a.c, a.n, a.hw, a.k, a.batch, 1, tuple(a.tile) if a.tile else None, a.mode, nt=a.nt)

@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     // whole launch only if EVERY channel's wrap-safe range passes the exactness conditions (workgroup-uniform flag)
     constexpr bool INTRQ = LUT || ACT == MI355_ACT_RELU6;
     int32_t qm0[NM][4], qsh[NM][4];
+    int64_t qc[NM][4];  // lo * M0: the biased accumulator goes straight into one 64-bit multiply-add (u * M0 + lo * M0 = a * M0)
     const int32_t *shiftp = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(a.hdr) + a.hdr->off_shift);
     int never_l = 0, noint_l = 0;
 #pragma unroll
@@ -349,6 +350,8 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
             if (!biased_safe_range(l, h, lb, rg)) never_l = 1;
             qm0[mt][r] = qsh[mt][r] = 0;
             if (INTRQ && (!pow2 || !intrq_make(a.mval[c2], shiftp[c2], lb, (int32_t)((uint32_t)lb + rg), qm0[mt][r], qsh[mt][r]))) noint_l = 1;
+            qc[mt][r] = (int64_t)lb * (int64_t)qm0[mt][r];
+            asm volatile("" : "+v"(qc[mt][r]));  // opaque: the compiler otherwise factors u * M0 + lo * M0 back into (u + lo) * M0 as a 64 x 32 multiply
             cb[mt][r] = (int32_t)((uint32_t)a.cwb[c2] - (uint32_t)lb);  // accumulators biased by the safe range's lower end (common.h)
             lo[mt][r] = lb;
             hi[mt][r] = (int32_t)rg;  // hi - lo
@@ -505,21 +508,24 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                 __builtin_amdgcn_s_setprio(0);
                 // accumulators are biased by lo: one unsigned maximum gives the range test and the window maximum (common.h)
                 uint32_t umax[4];
-                bool bad = never;
+                // the four range tests as wave masks on the scalar unit (one v_cmp each; no per-lane flag to build and ballot)
+                uint64_t badm = never ? ~0ull : 0ull;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     umax[r] = max(max((uint32_t)acc[0][r], (uint32_t)acc[1][r]), max((uint32_t)acc[2][r], (uint32_t)acc[3][r]));
-                    bad |= umax[r] > (uint32_t)hi[mt][r];
+                    badm |= __builtin_amdgcn_ballot_w64(umax[r] > (uint32_t)hi[mt][r]);
                 }
                 uint32_t packed;
-                if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {
-                    int32_t amax[4][1];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
+                if (badm == 0 && pow2) {
                     if (INTRQ && use_int) {  // two integer instructions per value instead of convert / FP64 multiply / convert
+                        // f = floor(a * M0 / 2^(32 + sh)), a = u + lo:  v_mad_u64_u32 (u * M0 + lo * M0, exact mod 2^64: |a * M0| < 2^53),
+                        // then an arithmetic shift of the high dword
                         int32_t f[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) f[r] = intrq_floor(amax[r][0], qm0[mt][r], qsh[mt][r]);
+                        for (int r = 0; r < 4; ++r) {
+                            const uint64_t p = (uint64_t)umax[r] * (uint64_t)(uint32_t)qm0[mt][r] + (uint64_t)qc[mt][r];
+                            f[r] = (int32_t)(uint32_t)(p >> 32) >> qsh[mt][r];
+                        }
 #ifndef MI355_L0_LEAKY_ARITH
                         if constexpr (LUT) {
                             uint32_t bt[4];
@@ -543,6 +549,9 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                             packed = pack4_biased(v[0], v[1], v[2], v[3]);
                         }
                     } else if constexpr (LUT) {  // q of a window inside the safe range lies inside the table (common.h)
+                        int32_t amax[4][1];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
                         // four independent chains, issued pass by pass: left alone the compiler threads all four conversions through
                         // one register pair and every FP64 instruction waits out the latency of the one before it
                         uint32_t bt[4];
@@ -561,7 +570,9 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                         for (int r = 0; r < 4; ++r) bt[r] = lut[qq[r] + LUTQ_OFF];
                         packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
                     } else {
-                        int32_t v1[4][1];
+                        int32_t amax[4][1], v1[4][1];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
                         requant_values<ACT, SAT, 1>(amax, mp[mt], a.zp_act, v1);
                         packed = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
                     }

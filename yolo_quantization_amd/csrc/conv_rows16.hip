@@ -22,7 +22,17 @@
 #include <type_traits>
 
 #define DBG(bit) (false)
+#if defined(MI355_ABLATE)
+// phase timestamps (100 MHz wall clock) of wave 0 of every workgroup: tools/conv_microbench.py --timeline16 (-DMI355_ABLATE builds only)
+__device__ long long g_rows16_ts[6][4096];
+#define TS(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_rows16_ts[k][blockIdx.x] = wall_clock64(); } while (0)
+extern "C" int mi355_debug_read_ts16(long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rows16_ts), sizeof(long long) * 6 * 4096) == hipSuccess ? 0 : -5;
+}
+#else
 #define TS(k) do { } while (0)
+#endif
 #define WP_DECL do { } while (0)
 #define WP_START() do { } while (0)
 #define WP_MARK(k) do { } while (0)
@@ -324,6 +334,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (BM / WMW > 64 ? 1 : 2)) void conv_
         // then step 0's fragments are put on their way in the steady state's order
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * APT) : "memory");
         __builtin_amdgcn_s_barrier();
+        TS(2);
 #pragma unroll
         for (int ni = 0; ni < NI - 2; ++ni) LDS_READ128(fb[ni], baddr[ni], 0);
 #pragma unroll
@@ -739,6 +750,12 @@ static int rows16_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
 // SIMD, 192 accumulators in the AGPRs, 14 fragment reads per 48 MFMAs instead of 10 per 24; compiles without scratch only with
 // -mllvm -pragma-unroll-threshold raised, see build.sh) -- bit-identical, L12 62-64 us against 54-57, L21 50-51 against 43-45
 // (profiles/r04_rows16_4wave_ab.log): with one wave per SIMD nothing covers the issuing wave's DMA instructions and barrier waits.
+// Round 4, measured and not kept (profiles/r04_rows16_adir_experiment.log): the A operand straight from global memory
+// (the packed weights ARE the fragment images: one coalesced global_load_dwordx4 per fragment, three register sets, two K-steps
+// ahead), no A ring, one barrier per channel chunk instead of one per K-step.  Bit-identical; the same time alone (L12 58-60 us on
+// 128 x 128 tiles) and with four batches in flight (0.267-0.269 ms per step either way): two K-steps of fragments in registers do
+// not cover the L2 latency when a wave is alone on its SIMD (K loop 22.9 us against 16.8 for the LDS ring, which holds five), a
+// third step of fragments or 64 x 96 wave tiles spill at 256 registers.
 // MI355_EINVAL -> conv_rows.hip's kernel.
 int conv_rows16_launch(ConvArgs &a, hipStream_t st, int bm, int bn)
 {

@@ -83,26 +83,31 @@ __device__ __forceinline__ uint32_t pool_requant_quad(const int32_t (&accb)[4][4
 template <int ACT, bool SAT>
 __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)[4][4], const int (&lo)[4], const int (&rg)[4], bool never,
                                                              bool use_int, const int (&m0)[4], const int (&sh)[4], const double *ldsMP4,
-                                                             int zp_act, bool pow2, const double *mval4, const double *sval4)
+                                                             const double *gMP4, int zp_act, bool pow2, const double *mval4, const double *sval4)
 {
+    // ldsMP4: the channel's 8-byte LDS slot -- the folded FP64 multiplier, or (use_int, workgroup-uniform) the int64 lo * M0 of the integer
+    // form; gMP4: the multipliers in global memory, for the rare exact path of an integer-form launch
     uint32_t umax[4];
-    bool bad = never;
+    uint64_t badm = never ? ~0ull : 0ull;  // the four range tests as wave masks on the scalar unit: one v_cmp each
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         umax[r] = max(max(u[r][0], u[r][1]), max(u[r][2], u[r][3]));
-        bad |= umax[r] > (uint32_t)rg[r];
+        badm |= __builtin_amdgcn_ballot_w64(umax[r] > (uint32_t)rg[r]);
     }
-    if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {  // no window of this wave can wrap: requantise the maxima
-        int32_t amax[4][1], v[4][1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[r]);
+    if (badm == 0 && pow2) {  // no window of this wave can wrap: requantise the maxima
+        int32_t v[4][1];
         if ((ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT && use_int) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int32_t f = intrq_floor(amax[r][0], m0[r], sh[r]);
+                // f = floor(a * M0 / 2^(32 + sh)), a = u + lo, as u * M0 + lo * M0 in ONE v_mad_u64_u32 (exact mod 2^64) + a shift of the high dword
+                const uint64_t p = (uint64_t)umax[r] * (uint64_t)(uint32_t)m0[r] + reinterpret_cast<const uint64_t *>(ldsMP4)[r];
+                const int32_t f = (int32_t)(uint32_t)(p >> 32) >> sh[r];
                 v[r][0] = ACT == MI355_ACT_LEAKY ? leaky_of_floor(f, zp_act) : zp_act + max(f, 0);
             }
         } else {
+            int32_t amax[4][1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[r]);
             const double mp[4] = {ldsMP4[0], ldsMP4[1], ldsMP4[2], ldsMP4[3]};
             requant_values<ACT, SAT, 1>(amax, mp, zp_act, v);
         }
@@ -115,7 +120,9 @@ __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)
         for (int j = 0; j < 4; ++j) accb[r][j] = (int32_t)(u[r][j] + (uint32_t)lo[r]);
     int32_t m[4];
     if (pow2) {
-        const double mp[4] = {ldsMP4[0], ldsMP4[1], ldsMP4[2], ldsMP4[3]};
+        double mp[4];
+        if (use_int) { mp[0] = gMP4[0]; mp[1] = gMP4[1]; mp[2] = gMP4[2]; mp[3] = gMP4[3]; }
+        else { mp[0] = ldsMP4[0]; mp[1] = ldsMP4[1]; mp[2] = ldsMP4[2]; mp[3] = ldsMP4[3]; }
         int32_t v[4][4];
         requant_values<ACT, SAT, 4>(accb, mp, zp_act, v);
 #pragma unroll
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     const int bbytes = PIECES * pieceb;
     const bool patch = a.tiles_x > 0;
     int *ldsS = reinterpret_cast<int *>(smem + 2 * bbytes);               // [rows_cap * ncell] per-cell channel sums
-    double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier
+    double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier; POOL with the integer form: int64 lo * M0 instead
     int *ldsDZ = reinterpret_cast<int *>(ldsMP + N);                      // [N] 128 - zp_w
     int *ldsCB = ldsDZ + N;                                               // [N] cw + bias
     int *ldsLO = ldsCB + N, *ldsHI = ldsLO + N;                           // [N] wrap-safe accumulator range (POOL: lower end, width)
@@ -182,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     // ---- per-channel parameters and the wrap-safe ranges.  POOL: the accumulators are kept BIASED by the range's lower end (seed
     //      cw + bias - lo), ldsLO / ldsHI hold that end and the range's width (common.h biased_safe_range)
     int never_l = 0, noint_l = 0;
+    int64_t qc_l = 0;
     if (tid < N) {
         const double mp = a.mprime[tid];
         ldsMP[tid] = mp;
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
             ldsCB[tid] = (int32_t)((uint32_t)a.cwb[tid] - (uint32_t)lb);
             ldsLO[tid] = lb;
             ldsHI[tid] = (int32_t)rg;
+            qc_l = (int64_t)lb * (int64_t)m0;
         } else {
             ldsCB[tid] = a.cwb[tid];
             ldsLO[tid] = lo;
@@ -205,7 +214,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
         ldsSH[tid] = sh;
     }
     const bool never = POOL && __syncthreads_or(never_l) != 0;
-    const bool use_int = POOL && __syncthreads_or(noint_l) == 0;
+    const bool use_int = POOL && (ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT && __syncthreads_or(noint_l) == 0;
+    if (use_int && tid < N) reinterpret_cast<int64_t *>(ldsMP)[tid] = qc_l;  // (visible after the tile loop's first barrier)
 
     // ---- stationary A fragments: plane ws = [m-tile][k-step][lane][16 B]
     v4i wf[NM][KST];
@@ -450,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ub[r][j] = (uint32_t)accb[r][j];
-                    pk[mt][grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, use_int, m0v, shv, ldsMP + ch0, a.zp_act, pow2,
+                    pk[mt][grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, use_int, m0v, shv, ldsMP + ch0, a.mprime + ch0, a.zp_act, pow2,
                                                                      a.mval + ch0, a.sval + ch0);
                 } else if constexpr (MODE == 2) {  // stride 2: one value per (pixel, channel), plain requantisation
                     int32_t a1[4][1], v1[4][1];
