@@ -78,6 +78,7 @@ if __name__ == "__main__":
     ap.add_argument("--shift", type=int, default=13); ap.add_argument("--plan", action="store_true")
     ap.add_argument("--nt", type=int, default=0); ap.add_argument("--dbg", type=int, default=0, help="mi355_debug_flags value (512 = no chunk rotation)"); ap.add_argument("--timeline", action="store_true"); ap.add_argument("--timeline3", action="store_true"); ap.add_argument("--waveprof", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="timing ablation of the K loop (results are wrong)")
+    ap.add_argument("--timeline1", action="store_true", help="conv1x1_ws: per-workgroup phase timestamps (-DMI355_ABLATE build)")
     ap.add_argument("--timeline16", action="store_true", help="conv_rows16: per-workgroup phase timestamps (-DMI355_ABLATE build)")
     a = ap.parse_args()
     SHIFT = a.shift
@@ -91,6 +92,24 @@ if __name__ == "__main__":
             r = run(a.c, a.n, a.hw, a.k, a.batch, a.iters, tuple(a.tile) if a.tile else None, a.mode)
             print(name, r["us"], "us", r["tops"], "TOPS")
         S.mi355_debug_flags(0)
+    elif a.timeline1:
+        S = binding.shim()
+        S.mi355_debug_flags(a.dbg)
+        r = run(a.c, a.n, a.hw, a.k, a.batch, 1, None, None)
+        S.mi355_stream_sync(None)
+        ts = np.zeros((4, 8192), np.int64)
+        S.mi355_debug_read_ts1.argtypes = [C.c_void_p]
+        assert S.mi355_debug_read_ts1(ts.ctypes.data) == 0
+        nb = int((ts[0] > 0).sum())
+        t = ts[:, :nb].astype(np.float64) / 100.0
+        t0 = t[0].min()
+        st = np.sort(t[0] - t0)
+        print(f"blocks {nb}; span {t[3].max() - t0:.2f} us; starts: p25 {st[nb // 4]:.2f} p50 {st[nb // 2]:.2f} p75 {st[3 * nb // 4]:.2f} max {st[-1]:.2f}")
+        for i, nm in [(0, "pixel tables + image DMA issued"), (1, "parameters, A fragments, everything landed, barrier"), (2, "groups: MFMAs + requantise + stores")]:
+            d = t[i + 1] - t[i]
+            print(f"  {nm:52s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
+        d = t[3] - t[0]
+        print(f"  {'whole workgroup':52s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
     elif a.timeline16:
         S = binding.shim()
         S.mi355_debug_flags(a.dbg)

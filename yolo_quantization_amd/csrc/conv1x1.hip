@@ -18,8 +18,23 @@
 
 constexpr int P1_GMAX = 8;  // groups of 32 pixels per tile
 
+#ifdef MI355_ABLATE
+// phase timestamps (100 MHz wall clock) of wave 0 of every workgroup: tools/conv_microbench.py --timeline1 (-DMI355_ABLATE builds only)
+__device__ long long g_c1_ts[4][8192];
+#define TS1(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_c1_ts[k][blockIdx.x] = wall_clock64(); } while (0)
+extern "C" int mi355_debug_read_ts1(long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c1_ts), sizeof(long long) * 4 * 8192) == hipSuccess ? 0 : -5;
+}
+#else
+#define TS1(k) do { } while (0)
+#endif
+
+// (HIP's second launch-bound is WAVES PER SIMD, not workgroups per CU: with (512, 2) the LEAKY instantiations took 131-138 registers,
+// three waves per SIMD, i.e. ONE 8-wave workgroup per CU -- every multi-round launch (YOLOv3's 1x1 layers) ran its tile loads with
+// nothing beside them.  Four waves per SIMD = two workgroups per CU wherever the stationary weights leave room: C <= 256.)
 template <int KST, int ACT, bool SAT>
-__global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
+__global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // filter tiles: layers with more than 256 filters (YOLOv3's 1024 -> 512 necks) split them over a.mtiles workgroups per pixel
@@ -51,6 +66,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
     const int tile = blockIdx.x / mtl;
     const int n0 = tile * TP, n1 = min(n0 + TP, a.total_n);  // this tile's pixels [n0, n1)
     const bool pow2 = a.hdr->pow2 == 1;
+    TS1(0);
 
     // ---- tile image DMA: instruction (Q, chunk) = 16 pixels x 4 pieces of 64-channel chunk Q; lane -> (piece lane >> 4,
     //      pixel lane & 15).  The pixel -> cell division is done once per chunk and reused for every Q.
@@ -80,6 +96,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
                 }
         }
     }
+    TS1(1);
     // ---- parameters and this wave's A fragments (overlap the DMA)
     for (int i = tid; i < N32; i += NT) {
         ldsMP[i] = a.mprime[f0 + i];
@@ -93,6 +110,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
     for (int s = 0; s < KST; ++s) wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(((f0 >> 5) + wq) * KST + s) * 64 + lane) * 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    TS1(2);
 
     const char *X = smem;
     const int chw = 32 * wq;
@@ -146,6 +164,11 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
             }
             if (valid && f0 + ch0 < a.out_w) {
                 const uint32_t packed = pack4_biased(v[0][0], v[1][0], v[2][0], v[3][0]);
+#ifdef MI355_ABLATE
+                if (a.debug & 1) {  // timing ablation: no stores (keep the value alive)
+                    if (packed == 0x12345678u) a.y[0] = 1;
+                } else
+#endif
                 if (up == 1) {
                     *reinterpret_cast<uint32_t *>(a.y + (size_t)ocell * a.out_cs + f0 + ch0) = packed;
                 } else {
@@ -174,6 +197,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ConvArgs a)
             }
         }
     }
+    TS1(3);
 }
 
 template <int KST, int ACT>
@@ -214,6 +238,7 @@ int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
     const int c = a.cb * a.nchunks;
     if (!conv1x1_ws_eligible(a.n, c, a.ksize) || !a.ws || !a.y || a.acc_out || a.ypool || a.stride != 1) return MI355_EINVAL;
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
+    a.debug = mi355_debug_flags_get();
     // tiles of equal size, as few rounds of 256 workgroups as the 256-pixel tile limit allows
     const long total = a.total_n;
     // few input channels: a pixel costs little LDS, and layers with millions of pixels (64 -> 32 at 304 x 304) are bound
