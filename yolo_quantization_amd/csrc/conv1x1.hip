@@ -200,21 +200,17 @@ __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(con
     TS1(3);
 }
 
+template <int KST, int ACT, bool SAT>
+static int c1_launch_kern(ConvArgs &a, hipStream_t st, int grid, int threads, size_t lds)
+{
+    return launch_big_lds<conv1x1_ws_kernel<KST, ACT, SAT>>(grid, threads, lds, st, a);
+}
+
 template <int KST, int ACT>
 static int c1_launch_sat(ConvArgs &a, hipStream_t st, int grid, int threads, size_t lds)
 {
-    if (a.store_mode == MI355_STORE_SATURATE) {
-        auto kern = conv1x1_ws_kernel<KST, ACT, true>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
-    } else {
-        auto kern = conv1x1_ws_kernel<KST, ACT, false>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
-    }
-    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+    if (a.store_mode == MI355_STORE_SATURATE) return c1_launch_kern<KST, ACT, true>(a, st, grid, threads, lds);
+    return c1_launch_kern<KST, ACT, false>(a, st, grid, threads, lds);
 }
 
 template <int KST>

@@ -83,31 +83,26 @@ __device__ __forceinline__ uint32_t pool_requant_quad(const int32_t (&accb)[4][4
 template <int ACT, bool SAT>
 __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)[4][4], const int (&lo)[4], const int (&rg)[4], bool never,
                                                              bool use_int, const int (&m0)[4], const int (&sh)[4], const double *ldsMP4,
-                                                             const double *gMP4, int zp_act, bool pow2, const double *mval4, const double *sval4)
+                                                             int zp_act, bool pow2, const double *mval4, const double *sval4)
 {
-    // ldsMP4: the channel's 8-byte LDS slot -- the folded FP64 multiplier, or (use_int, workgroup-uniform) the int64 lo * M0 of the integer
-    // form; gMP4: the multipliers in global memory, for the rare exact path of an integer-form launch
     uint32_t umax[4];
-    uint64_t badm = never ? ~0ull : 0ull;  // the four range tests as wave masks on the scalar unit: one v_cmp each
+    bool bad = never;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         umax[r] = max(max(u[r][0], u[r][1]), max(u[r][2], u[r][3]));
-        badm |= __builtin_amdgcn_ballot_w64(umax[r] > (uint32_t)rg[r]);
+        bad |= umax[r] > (uint32_t)rg[r];
     }
-    if (badm == 0 && pow2) {  // no window of this wave can wrap: requantise the maxima
-        int32_t v[4][1];
+    if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {  // no window of this wave can wrap: requantise the maxima
+        int32_t amax[4][1], v[4][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[r]);
         if ((ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT && use_int) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                // f = floor(a * M0 / 2^(32 + sh)), a = u + lo, as u * M0 + lo * M0 in ONE v_mad_u64_u32 (exact mod 2^64) + a shift of the high dword
-                const uint64_t p = (uint64_t)umax[r] * (uint64_t)(uint32_t)m0[r] + reinterpret_cast<const uint64_t *>(ldsMP4)[r];
-                const int32_t f = (int32_t)(uint32_t)(p >> 32) >> sh[r];
+                const int32_t f = intrq_floor(amax[r][0], m0[r], sh[r]);
                 v[r][0] = ACT == MI355_ACT_LEAKY ? leaky_of_floor(f, zp_act) : zp_act + max(f, 0);
             }
         } else {
-            int32_t amax[4][1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[r]);
             const double mp[4] = {ldsMP4[0], ldsMP4[1], ldsMP4[2], ldsMP4[3]};
             requant_values<ACT, SAT, 1>(amax, mp, zp_act, v);
         }
@@ -120,9 +115,7 @@ __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)
         for (int j = 0; j < 4; ++j) accb[r][j] = (int32_t)(u[r][j] + (uint32_t)lo[r]);
     int32_t m[4];
     if (pow2) {
-        double mp[4];
-        if (use_int) { mp[0] = gMP4[0]; mp[1] = gMP4[1]; mp[2] = gMP4[2]; mp[3] = gMP4[3]; }
-        else { mp[0] = ldsMP4[0]; mp[1] = ldsMP4[1]; mp[2] = ldsMP4[2]; mp[3] = ldsMP4[3]; }
+        const double mp[4] = {ldsMP4[0], ldsMP4[1], ldsMP4[2], ldsMP4[3]};
         int32_t v[4][4];
         requant_values<ACT, SAT, 4>(accb, mp, zp_act, v);
 #pragma unroll
@@ -143,6 +136,10 @@ __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)
 // MODE 0: conv + 2x2/2 maxpool.  1: no pool, the four window positions of a lane are four output pixels.  2: stride-2
 // convolution = the stride-1 output at the even positions = window position 0 only (a quarter of the MFMAs), stored on the
 // pooled geometry (the output map of a stride-2 3x3 pad-1 convolution on an even map is the pooled map).
+// (launch bounds: HIP's second number is waves per SIMD.  The launcher runs the 16-channel, 32-filter pooled kernel three workgroups per
+// CU, which its LEAKY instantiations allow with 153-162 registers (<= 168).  Round 4 measured what happens beyond that: a requantise
+// variant that needed 170 put the third workgroup of every CU into a second round -- L2 38 -> 53 us; forced back to 168 with three
+// spilled dwords 39-40 us, and no gain where it fitted (profiles/r04_l2_occupancy.log): not kept.)
 template <int C, int NM, int ACT, bool SAT, int MODE = 0, bool VDZ = false>
 __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs a)
 {
@@ -168,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     const int bbytes = PIECES * pieceb;
     const bool patch = a.tiles_x > 0;
     int *ldsS = reinterpret_cast<int *>(smem + 2 * bbytes);               // [rows_cap * ncell] per-cell channel sums
-    double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier; POOL with the integer form: int64 lo * M0 instead
+    double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier
     int *ldsDZ = reinterpret_cast<int *>(ldsMP + N);                      // [N] 128 - zp_w
     int *ldsCB = ldsDZ + N;                                               // [N] cw + bias
     int *ldsLO = ldsCB + N, *ldsHI = ldsLO + N;                           // [N] wrap-safe accumulator range (POOL: lower end, width)
@@ -189,7 +186,6 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     // ---- per-channel parameters and the wrap-safe ranges.  POOL: the accumulators are kept BIASED by the range's lower end (seed
     //      cw + bias - lo), ldsLO / ldsHI hold that end and the range's width (common.h biased_safe_range)
     int never_l = 0, noint_l = 0;
-    int64_t qc_l = 0;
     if (tid < N) {
         const double mp = a.mprime[tid];
         ldsMP[tid] = mp;
@@ -204,7 +200,6 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
             ldsCB[tid] = (int32_t)((uint32_t)a.cwb[tid] - (uint32_t)lb);
             ldsLO[tid] = lb;
             ldsHI[tid] = (int32_t)rg;
-            qc_l = (int64_t)lb * (int64_t)m0;
         } else {
             ldsCB[tid] = a.cwb[tid];
             ldsLO[tid] = lo;
@@ -214,8 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
         ldsSH[tid] = sh;
     }
     const bool never = POOL && __syncthreads_or(never_l) != 0;
-    const bool use_int = POOL && (ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT && __syncthreads_or(noint_l) == 0;
-    if (use_int && tid < N) reinterpret_cast<int64_t *>(ldsMP)[tid] = qc_l;  // (visible after the tile loop's first barrier)
+    const bool use_int = POOL && __syncthreads_or(noint_l) == 0;
 
     // ---- stationary A fragments: plane ws = [m-tile][k-step][lane][16 B]
     v4i wf[NM][KST];
@@ -460,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ub[r][j] = (uint32_t)accb[r][j];
-                    pk[mt][grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, use_int, m0v, shv, ldsMP + ch0, a.mprime + ch0, a.zp_act, pow2,
+                    pk[mt][grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, use_int, m0v, shv, ldsMP + ch0, a.zp_act, pow2,
                                                                      a.mval + ch0, a.sval + ch0);
                 } else if constexpr (MODE == 2) {  // stride 2: one value per (pixel, channel), plain requantisation
                     int32_t a1[4][1], v1[4][1];
@@ -757,41 +751,43 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
 template <int ACT>
 static int mid_launch_sat(ConvArgs &a, hipStream_t st, int grid, int threads, size_t lds)
 {
-    auto go = [&](auto kern) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
-        return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
-    };
     const bool sat = a.store_mode == MI355_STORE_SATURATE;
-    if (a.ypool) return sat ? go(conv_mid_pool_kernel<ACT, true, 0>) : go(conv_mid_pool_kernel<ACT, false, 0>);
-    if (a.stride == 2) return sat ? go(conv_mid_pool_kernel<ACT, true, 2>) : go(conv_mid_pool_kernel<ACT, false, 2>);
-    return sat ? go(conv_mid_pool_kernel<ACT, true, 1>) : go(conv_mid_pool_kernel<ACT, false, 1>);
+    if (a.ypool) return sat ? launch_big_lds<conv_mid_pool_kernel<ACT, true, 0>>(grid, threads, lds, st, a) : launch_big_lds<conv_mid_pool_kernel<ACT, false, 0>>(grid, threads, lds, st, a);
+    if (a.stride == 2) return sat ? launch_big_lds<conv_mid_pool_kernel<ACT, true, 2>>(grid, threads, lds, st, a) : launch_big_lds<conv_mid_pool_kernel<ACT, false, 2>>(grid, threads, lds, st, a);
+    return sat ? launch_big_lds<conv_mid_pool_kernel<ACT, true, 1>>(grid, threads, lds, st, a) : launch_big_lds<conv_mid_pool_kernel<ACT, false, 1>>(grid, threads, lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Persistent 4-wave workgroups: `grid` is what the LDS allows per CU; what the registers of THIS instantiation allow is asked of the
+// runtime once (numRegs -> allocation granule of 8 -> waves per SIMD = workgroups per CU) -- a workgroup beyond that does not run beside
+// the others but after them, a second round of whole tile walks (measured on the 16-channel kernel: 38 -> 53 us at 170 registers with
+// three launched per CU; its RELU6 instantiations need 188-200)
+template <void (*kern)(const ConvArgs)>
+static int small_launch_kern(ConvArgs &a, hipStream_t st, int grid, size_t lds)
+{
+    static int per_cu_regs[64] = {0};  // per kernel instantiation (the template argument) and per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int &pc = per_cu_regs[dev & 63];
+    if (pc == 0) {
+        hipFuncAttributes fa;
+        pc = 8;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess && fa.numRegs > 0) {
+            const int alloc = (fa.numRegs + 7) & ~7;
+            pc = 512 / alloc < 1 ? 1 : 512 / alloc;
+        }
+    }
+    if (grid > 256 * pc) grid = 256 * pc;
+    return launch_big_lds<kern>(grid, 256, lds, st, a);
+}
+
 template <int C, int NM, int ACT, int POOL>
 static int small_launch_sat2(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 {
-    if (C == 16 && POOL == 0 && a.plan == MI355_PLAN_THROUGHPUT && a.store_mode != MI355_STORE_SATURATE) {
-        auto kern = conv_small_pool_kernel<C, NM, ACT, false, POOL, (C == 16)>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-        return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
-    }
-    if (a.store_mode == MI355_STORE_SATURATE) {
-        auto kern = conv_small_pool_kernel<C, NM, ACT, true, POOL>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-    } else {
-        auto kern = conv_small_pool_kernel<C, NM, ACT, false, POOL>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-    }
-    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+    if (C == 16 && POOL == 0 && a.plan == MI355_PLAN_THROUGHPUT && a.store_mode != MI355_STORE_SATURATE)
+        return small_launch_kern<conv_small_pool_kernel<C, NM, ACT, false, POOL, (C == 16)>>(a, st, grid, lds);
+    if (a.store_mode == MI355_STORE_SATURATE) return small_launch_kern<conv_small_pool_kernel<C, NM, ACT, true, POOL>>(a, st, grid, lds);
+    return small_launch_kern<conv_small_pool_kernel<C, NM, ACT, false, POOL>>(a, st, grid, lds);
 }
 
 template <int C, int NM, int ACT>

@@ -490,17 +490,9 @@ template <int KP, int ACT, int PM>
 static int w3_launch_sat(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 {
     if (a.store_mode == MI355_STORE_SATURATE) {
-        auto kern = conv_ws3_kernel<KP, ACT, true, PM>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
-    } else {
-        auto kern = conv_ws3_kernel<KP, ACT, false, PM>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MI355_EHIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        return launch_big_lds<conv_ws3_kernel<KP, ACT, true, PM>>(grid, 512, lds, st, a);
     }
-    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+    return launch_big_lds<conv_ws3_kernel<KP, ACT, false, PM>>(grid, 512, lds, st, a);
 }
 
 template <int KP, int PM>

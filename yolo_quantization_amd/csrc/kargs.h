@@ -154,3 +154,27 @@ int image_minmax_launch(const float *x, long count, uint32_t *mm, hipStream_t st
 int image_quantize_launch(const float *x, long count, float scale, int zp, uint8_t *out, hipStream_t st);
 int yolo_logistic_launch(const float *in, float *out, int B, int n, int classes, int hw, hipStream_t st);
 int checksum_u32_launch(const uint32_t *p, long n, unsigned long long *out, hipStream_t st);
+
+// Kernels with more than 64 KB of dynamic LDS need their limit raised: per kernel instantiation (the template argument) and per device --
+// function attributes are per device, `darknet -gpus` drives several from one process -- and only when a launch needs more than the
+// limit set so far, not once per launch.  (The limit counts against 160 KB TOGETHER with the kernel's static LDS: ask for what is needed.)
+template <void (*kern)(const ConvArgs)>
+static inline bool lds_limit_for(size_t lds)
+{
+    static size_t have[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t &h = have[dev & 63];
+    if (lds > 64 * 1024 && lds > h) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        h = lds;
+    }
+    return true;
+}
+template <void (*kern)(const ConvArgs)>
+static inline int launch_big_lds(int grid, int threads, size_t lds, hipStream_t st, const ConvArgs &a)
+{
+    if (!lds_limit_for<kern>(lds)) return MI355_EHIP;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+    return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
+}
