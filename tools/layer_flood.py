@@ -118,7 +118,8 @@ for lo, hi in groups:
     extra = ""
     if sampler:
         tf, pw, ck = sampler.run(lambda: timed(nets, a.reps))
-        extra = f" {pw:.0f} W, {ck:.0f} MHz |" if pw is not None else ""
+        ts, pws, cks = sampler.run(lambda: timed(nets[:1], a.reps))  # the same launch back to back on ONE instance: power / clock of the kernel alone
+        extra = (f" flood {pw:.0f} W, {ck:.0f} MHz | serial {pws:.0f} W, {cks:.0f} MHz |" if pw is not None and pws is not None else "")
     else:
         tf = timed(nets, a.reps)
     tot_s += ts; tot_f += tf

@@ -840,6 +840,12 @@ static int rows_launch_cfg(ConvArgs &a, hipStream_t st)
     return hipGetLastError() == hipSuccess ? MI355_OK : MI355_EHIP;
 }
 
+// Round 4, measured and not kept (profiles/r04_rows_12wave_ab.log): the 128 x 384 tile on TWELVE waves (2 x 6 of 64 x 64 wave tiles: 163
+// registers, three waves per SIMD instead of two; rows_launch_cfg<128, 384, 2, 6, RS, 3> with launch bounds (768, 3) and four DMA
+// waves) -- rocprofv3 averages over 53 launches of the L12 shape: 55.00 us against 55.06 us.  Together with conv_rows16.hip's
+// variants (other MFMA shape, A operand from global memory, four waves of 128 x 96) that is four structurally different K loops
+// within 3 % of each other on the same operand bytes, and all of them 20-25 % faster on constant operands: on these layers the clock
+// the power management grants under matrix load sets the time, not the loop.
 template <int RS, int KS>
 static int rows_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
 {
