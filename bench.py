@@ -451,6 +451,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         nets[i % ninfl].forward()
+    # (round 4, measured and not kept: one host thread per instance queues its steps -- host_issue_ms 1.2-1.9 -> 0.55-0.64 for 20 steps, the
+    # region itself 0.285-0.291 -> 0.291-0.302 ms per step: what a 20-step region loses against a long run is the fill and drain of a
+    # four-deep pipeline, not the host)
+    t_issued = time.perf_counter() - t0  # host time to queue the K steps (reported as `host_issue_ms`: launch-bound if close to the total)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -721,6 +725,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "warmup_passes_effective": args.warmup + (ninfl * args.selfcheck_passes if selfcheck else 0),  # the self-check passes are queued right in front of the warmup steps
                "ms_per_step": round(ms_per_step, 4),
+               "host_issue_ms": round(t_issued * 1e3, 3),  # host time to queue the K steps of the timed region (its total is ms_per_step * steps)
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x s8 -> int32 (f64 requant)",
                "data": "synthetic",
                "config": {"workload": "yolov3-tiny full net (cfg/yolov3-tiny_quant.cfg, leaky, per-channel quant), "
