@@ -51,8 +51,10 @@ extern "C" {
 
 /* accumulation semantics */
 #define MI355_ACC_EXACT 0    /* exact int32 on V_MFMA_I32_*_I8: the integers the reference's formula defines; equals the default build
-                                wherever its fp32 accumulation is exact (pinned: tests/test_gpu_refpin.py) and, by cblas_gemm_s16s16s32's
-                                contract, the MKL flavour's accumulators (that flavour is unbuildable here: unpinned) */
+                                wherever its fp32 accumulation is exact (pinned: tests/test_gpu_refpin.py) and the MKL flavour's
+                                accumulators: that flavour cannot be built here, but the MKL entry point it calls is in the image --
+                                cblas_gemm_s16s16s32 with the argument lists of ref :557-569 returns exactly these integers beyond 2^24
+                                as well (tests/test_mkl_pin.py: the GEMM half pinned against the real library, the epilogue not) */
 #define MI355_ACC_REF_F32 1  /* bit-faithful emulation of ref src/gemm.c:279-299 (fp32 step-wise accumulate,
                                 two passes); slow verification kernel, never on the throughput path */
 

@@ -775,6 +775,8 @@ static int small_launch_kern(ConvArgs &a, hipStream_t st, int grid, size_t lds)
         if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess && fa.numRegs > 0) {
             const int alloc = (fa.numRegs + 7) & ~7;
             pc = 512 / alloc < 1 ? 1 : 512 / alloc;
+        } else {
+            (void)hipGetLastError();  // not fatal: the launch below must not report this query's error as its own
         }
     }
     if (grid > 256 * pc) grid = 256 * pc;
