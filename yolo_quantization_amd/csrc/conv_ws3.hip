@@ -203,7 +203,6 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     // B-fragment read, one cell apart, hit 16 different 16-byte bank groups).  Every tap / channel-block offset of a
     // K-step is then a compile-time immediate of the ds_read.  RS < nrows only for tiles that are one whole image:
     // the pad row below it aliases the pad row above it.
-    const int srows = min(nrows, RS);
 
     TS3(1);
     // ---- per-channel parameters of the workgroup's filters
