@@ -11,6 +11,14 @@
 //     such a run would drag in two mostly unused rows) an 8 x 16 patch.  Either way the input is a dense image of
 //     nrows x ncell cells incl. one halo cell all round, DMAed (global_load_lds) into a double buffered LDS plane per
 //     16-channel piece while the previous tile computes.
+//   * an LDS image row is DE-INTERLEAVED: its even cells x = 0, 2, .. sit in slots 0 .., its odd cells in slots hc ..  The lanes of
+//     a B read are consecutive POOLED pixels, i.e. image cells two apart: in a plain row image their 16-byte fragments are 32 B apart
+//     and every ds_read_b128 is a two-way bank conflict (SQ_LDS_BANK_CONFLICT was 35-50 % of SQ_LDS_IDX_ACTIVE on layers 2 / 4 / 6,
+//     profiles/r04_v2_pmc_sq2_plan1.txt); split by column parity they are consecutive slots.  The DMA's per-lane SOURCE address
+//     carries the permutation (its LDS side is contiguous by construction), the tap offsets of the reads absorb it: window column jx
+//     + tap column dx = e -> slot offset (e & 1) * hc + (e >> 1).  The row pitch is chosen so that a wave's second pooled row
+//     (patches: 2 * pitch = 0 mod 16) or its wrap into the next pooled row (flat tiles: 2 * pitch = OW mod 16) continues the same
+//     sequence of 16-byte bank groups.
 //   * lane l of a wave owns pooled pixel 32*wave + l; the four 32-column MFMA sub-tiles of the wave are the four window
 //     positions, so the 2x2 window of every (pixel, channel) sits in ONE lane: the pool is three v_max_i32, no
 //     cross-lane traffic and no pre-pool tensor.
@@ -141,7 +149,9 @@ __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)
 // variant that needed 170 put the third workgroup of every CU into a second round -- L2 38 -> 53 us; forced back to 168 with three
 // spilled dwords 39-40 us, and no gain where it fitted (profiles/r04_l2_occupancy.log): not kept.)
 template <int C, int NM, int ACT, bool SAT, int MODE = 0, bool VDZ = false>
-__global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs a)
+// (the throughput-plan form of the 16-channel, 32-filter kernel is launched three workgroups per CU: its RELU / RELU6 instantiations, left
+// to a budget of 256 registers, take 184-186 and lose the third; bounded to three waves per SIMD they fit in 166-167 without scratch)
+__global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv_small_pool_kernel(const ConvArgs a)
 {
     constexpr bool POOL = MODE == 0;
     constexpr int NJ = MODE == 2 ? 1 : 4;  // window positions computed
@@ -159,7 +169,9 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
     constexpr bool DZM = (C == 16) && !VDZ;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ncell = a.sm_ncell;     // cells of an LDS image row (flat tiles: W + 2, x = -1 .. W; patches: 34)
+    const int ncell = a.sm_ncell;     // slots of an LDS image row = its pitch (>= the image cells: flat tiles W + 2, x = -1 .. W; patches 34)
+    const int lcell = a.sm_lcell;     // image cells of a row
+    const int hc = a.sm_hc, hcb = hc * 16;  // slot / byte offset of the row's first odd cell (rows are de-interleaved by column parity)
     const int rowb = ncell * 16;      // bytes between image rows inside a piece plane
     const int pieceb = a.sm_pieceb;   // bytes of one 16-channel piece plane (rows_cap * ncell cells)
     const int bbytes = PIECES * pieceb;
@@ -231,12 +243,18 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
 
     // tap byte offsets inside the row image.  C == 16: lane-dependent (k-half = tap parity; tap 9 does not exist, its
     // weights are zero and the lane re-reads tap 8).  C == 32: uniform per step, the k-half selects the piece plane.
-    int toff[KST];
+    // Per window column jx: cell lcol + jx + dx of the de-interleaved row = slot (lcol >> 1) + (e & 1) * hc + (e >> 1), e = jx + dx
+    // (lcol, the cell of the left window column's left tap, is even for every lane).
+    int toff[2][KST];
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
         int t = (C == 16) ? 2 * s + kh : s;
         if (t > 8) t = 8;
-        toff[s] = (t / 3) * rowb + (t % 3) * 16;
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx) {
+            const int e = jx + t % 3;
+            toff[jx][s] = (t / 3) * rowb + (e & 1) * hcb + (e >> 1) * 16;
+        }
     }
 
     // DMA of a tile's image: instruction k fills cells [64k, 64k + 64) of every piece plane (the last one is shifted
@@ -248,7 +266,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
         const int k = wave + 4 * i;
         dstart[i] = min(k * 64, a.rows_cap * ncell - 64);
         const int slot = dstart[i] + lane;
-        const int r = slot / ncell, c = slot - r * ncell;
+        const int r = slot / ncell, cs = slot - r * ncell;
+        const int c = min(cs < hc ? 2 * cs : 2 * (cs - hc) + 1, lcell - 1);  // slot -> image cell (pad slots repeat the last cell)
         doff[i] = r * W1 + c;
     }
     auto issue_tile = [&](int gr_first, int col0, int nrows, int parity) {
@@ -375,18 +394,22 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
             pcol = prem - prow * OW;
         }
         const int lrow = b * (a.H + 1) + 2 * prow + 1 - gr_first;  // image row of the window's top row's top tap
-        const int lcol = 2 * pcol - 1 - col0;                        // image cell of the window's left column's left tap
-        int base[4], sx[4];
+        const int lch = (2 * pcol - 1 - col0) >> 1;                  // half the (even) image cell of the window's left column's left tap
+        int base[2], sx[4];                                          // base: per window ROW (the window column is in the tap offsets)
+#pragma unroll
+        for (int jy = 0; jy < 2; ++jy) base[jy] = (lrow + jy) * rowb + lch * 16 + ((C == 32) ? kh * pieceb : 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int rr = lrow + (j >> 1), cc = lcol + (j & 1);
-            base[j] = rr * rowb + cc * 16 + ((C == 32) ? kh * pieceb : 0);
+            const int rr = lrow + (j >> 1);
             int t = 0;
             if (!DZM) {
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) t += ldsS[(rr + dy) * ncell + cc + dx];
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int e = (j & 1) + dx;
+                        t += ldsS[(rr + dy) * ncell + lch + (e & 1) * hc + (e >> 1)];
+                    }
             }
             sx[j] = t;
         }
@@ -414,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_pool_kernel(const ConvArgs 
             for (int s = 0; s < KST; ++s)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const v4i bf = *reinterpret_cast<const v4i *>(X + base[j] + toff[s]);
+                    const v4i bf = *reinterpret_cast<const v4i *>(X + base[j >> 1] + toff[j & 1][s]);
                     acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[mt][s], bf, acc[j], 0, 0, 0);
                     if (DZM) {
                         // tap 2s + kh: the k-half of the nonexistent tap 9 carries a zero constant
@@ -519,7 +542,8 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
     constexpr int NJ = MODE == 2 ? 1 : 4;
     constexpr int KST = 18, PIECES = 4, GMAX = SM_GMAX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ncell = a.sm_ncell, rowb = ncell * 16, pieceb = a.sm_pieceb;
+    const int ncell = a.sm_ncell, rowb = ncell * 16, pieceb = a.sm_pieceb;  // ncell: slots per LDS row (pitch)
+    const int lcell = a.sm_lcell, hc = a.sm_hc, hcb = hc * 16;              // image cells per row; rows de-interleaved by column parity (see the file header)
     const bool patch = a.tiles_x > 0;
     const int N = a.n;
     int *ldsS = reinterpret_cast<int *>(smem + PIECES * pieceb);          // [rows_cap * ncell] per-cell channel sums
@@ -572,7 +596,8 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         for (int k = wave; k * 64 < ncells; k += nwave) {
             const int start = min(k * 64, a.rows_cap * ncell - 64);
             const int slot = start + lane;
-            const int r = slot / ncell, c = slot - r * ncell;
+            const int r = slot / ncell, cs = slot - r * ncell;
+            const int c = min(cs < hc ? 2 * cs : 2 * (cs - hc) + 1, lcell - 1);  // slot -> image cell (pad slots repeat the last cell)
             long f = org + (long)r * W1 + c;
             f = f < 0 ? 0 : (f > a.in_cells - 1 ? a.in_cells - 1 : f);
             const unsigned voff = (unsigned)(f * a.in_cs);
@@ -622,8 +647,8 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
             pcol = prem - prow * OW;
         }
         const int rr = b * (a.H + 1) + 2 * prow + 1 - gr_first + (j >> 1);
-        const int cc = 2 * pcol - 1 - col0 + (j & 1);
-        ldsBase[idx] = rr * rowb + cc * 16;
+        const int lch = (2 * pcol - 1 - col0) >> 1;  // half the (even) cell of the left window column's left tap; the window column is in the tap offsets
+        ldsBase[idx] = rr * rowb + lch * 16;
         if (j == 0)  // output cell: the pooled pixel, or (no pool) the top-left of its four conv pixels
             ldsCell[g * 32 + l] = !valid ? -1L
                                   : POOL ? (long)a.pool_lead + ((long)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol
@@ -649,12 +674,16 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
     }
     __syncthreads();
     for (int idx = tid; idx < G * 128; idx += NT) {
-        const int c0 = ldsBase[idx] >> 4;  // cell index of tap (0,0): rr * ncell + cc
+        const int c0 = ldsBase[idx] >> 4;  // slot of the window row's even cell lcol: rr * ncell + (lcol >> 1)
+        const int jx = (idx >> 5) & 1;
         int t = 0;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) t += ldsS[c0 + dy * ncell + dx];
+            for (int dx = 0; dx < 3; ++dx) {
+                const int e = jx + dx;
+                t += ldsS[c0 + dy * ncell + (e & 1) * hc + (e >> 1)];
+            }
         ldsSX[idx] = t;
     }
     __syncthreads();
@@ -686,7 +715,8 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
             const int soff = ((s >> 1) / 3) * rowb + (s & 1) * 2 * pieceb;  // scalar
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const v4i bf = *reinterpret_cast<const v4i *>(X + base[j] + soff + ((s >> 1) % 3) * 16);
+                const int e = (j & 1) + (s >> 1) % 3;  // window column + tap column -> parity half and slot of the de-interleaved row
+                const v4i bf = *reinterpret_cast<const v4i *>(X + base[j] + soff + (e & 1) * hcb + (e >> 1) * 16);
                 acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s], bf, acc[j], 0, 0, 0);
             }
             if (s & 1) __builtin_amdgcn_sched_barrier(0);  // keep the B fragments of at most two K-steps live (registers)
@@ -834,17 +864,22 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
     if (OW >= 64) {  // wide map: 8 x 16 pooled patches (a flat run of 128 would load two mostly unused rows)
         a.tiles_x = (OW + 15) / 16;
         a.tiles_y = (OH + 7) / 8;
-        a.sm_ncell = 34;
+        a.sm_lcell = 34;
+        a.sm_ncell = 40;  // pitch: the wave's second pooled row (two image rows down) starts on the same 16-byte bank group (2 * 40 = 0 mod 16)
         a.rows_cap = 18;
         ntiles = a.B * a.tiles_x * a.tiles_y;
     } else {
         // rows of a 128-pooled-pixel run: pooled rows it can touch, two image rows each, one pad row per image boundary
         // crossed, one halo row above and below
         a.tiles_x = a.tiles_y = 0;
-        a.sm_ncell = a.W + 2;
+        a.sm_lcell = a.W + 2;
+        // pitch: a wave whose pixels wrap into the next pooled row (slot + 2 * pitch - OW) continues the sequence of bank groups when
+        // 2 * pitch = OW mod 16 (even OW; with an odd one the wrap costs a conflict)
+        a.sm_ncell = a.sm_lcell + ((OW & 1) ? 0 : ((OW / 2 - a.sm_lcell) % 8 + 8) % 8);
         a.rows_cap = 2 * ((SM_PPB - 2 + OW) / OW + 1) + (SM_PPB - 2 + OH * OW) / (OH * OW) + 2;
         ntiles = (int)((total_p + SM_PPB - 1) / SM_PPB);
     }
+    a.sm_hc = a.sm_lcell / 2;  // (W is even: so is the cell count)
     a.sm_pieceb = a.rows_cap * a.sm_ncell * 16;
     if (c == 64) {  // channels split over n / 32 waves x 2 sets, one single-buffered tile per workgroup
         int tp = SM_PPB;

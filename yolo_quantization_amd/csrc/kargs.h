@@ -37,7 +37,9 @@ struct ConvArgs {
     int lds_param_off;       // conv_rows: byte offset of the staged per-channel epilogue parameters in LDS
     int debug;               // timing-ablation switches (results are wrong when non-zero): see mi355_debug_flags
     const int8_t *ws;        // conv_small: weights-stationary A fragments [m-tile][k-step][lane][16 B] or null
-    int sm_ncell, sm_pieceb; // conv_small: cells per LDS image row; bytes of one 16-channel piece plane
+    int sm_ncell, sm_pieceb; // conv_small: slots (16 B per piece plane) per LDS image row = its pitch; bytes of one 16-channel piece plane
+    int sm_lcell, sm_hc;     // conv_small: image cells per row (<= sm_ncell) and the slot of the row's first ODD cell: a row holds its even
+                             // cells 0, 2, .. in slots 0 .., its odd cells in slots sm_hc .. (see conv_small.hip: conflict-free stride-2 reads)
     int sm_tp;               // conv_mid_pool: pooled pixels per tile
     int sm_nq, sm_red_off;   // conv_ws3: filter quads (waves) per K part and workgroup; LDS offset of the K-part partial sums
     int pool_mode;           // conv_ws3: 0 = none, 2 = fused 2x2 / stride-2 maxpool (ypool = the pooled map), 1 = fused 2x2 / stride-1
