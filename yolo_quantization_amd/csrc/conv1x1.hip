@@ -250,6 +250,14 @@ int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
     // pixels pays for two groups (LDS, MFMAs, the workgroup's copy of the A fragments) anyway; fewer, full workgroups cost the chip
     // less and the other batches' launches fill the CUs this one leaves free (layer 13: 252 -> 169 workgroups)
     if (a.plan == MI355_PLAN_THROUGHPUT && !(mi355_debug_flags_get() & (1 << 29))) tp = (tp + 31) & ~31;
+    // ... and where a workgroup's copy of the A fragments (256 KB for 1024 -> 256) outweighs its pixels, more pixels per workgroup: chip
+    // time per launch is (A load + pixels) x workgroups.  Layer 13 at 128 pixels: flood 9.8 -> 8.5 us per launch, in-flight step
+    // -4 us (same box, profiles/r04_conv1x1_tp_ab_flood.log); alone it is slower (15 -> 23 us: 85 workgroups), which is the latency
+    // plan's concern.  Layer 18 (256 -> 128: 32 KB of A) is better off at 64.
+    if (a.plan == MI355_PLAN_THROUGHPUT && rounds == 1 && !(mi355_debug_flags_get() & (1 << 29))) {
+        const long abytes = (long)(n32 < 256 ? n32 : 256) * c;
+        while (abytes > 2L * tp * c && (long)(c / 64) * 2 * ((tp + 32) / 32) * 1024 <= 128 * 1024) tp += 32;
+    }
     const int ntiles = (int)((total + tp - 1) / tp);
     const int G = (tp + 31) / 32;
     a.sm_tp = tp;

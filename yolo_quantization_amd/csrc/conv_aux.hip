@@ -8,6 +8,7 @@
 //    pass 1 with the weights then pass 2 with -zp_w; k order (ci,ky,kx) of ref src/im2col.c:33-37).
 //    One thread per output element; a verification kernel, never on the throughput path.
 #include "kargs.h"
+#include <type_traits>
 
 
 __global__ __launch_bounds__(256) void conv_first_u8_kernel(const AuxArgs a)
@@ -288,6 +289,39 @@ __device__ __forceinline__ uint32_t first_pool_exact_path(const v4i (&acc)[4], c
     return pack4_biased(m[0], m[1], m[2], m[3]);
 }
 
+#ifdef MI355_ABLATE
+// per-wave shader-clock sums of the first-layer kernel's phases (tools/l0_phases.py): [0] barrier, [1] deferred stores + prefetch issue,
+// [2] / [4] B reads + MFMA chain of pooled row 0 / 1, [3] / [5] their epilogues, [6] staging wait + LDS writes, [7] tiles
+__device__ long long g_l0_ph[4096][4][10];
+#define L0P_DECL long long l0p[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long l0t = __builtin_readcyclecounter()
+#define L0P_MARK(k)                                                  \
+    do {                                                             \
+        asm volatile("" ::: "memory");                               \
+        const long long n_ = __builtin_readcyclecounter();           \
+        l0p[k] += n_ - l0t;                                          \
+        l0t = n_;                                                    \
+    } while (0)
+#define L0P_MARK_V(k, v)                                             \
+    do {                                                             \
+        asm volatile("s_nop 0" ::"v"(v));                            \
+        L0P_MARK(k);                                                 \
+    } while (0)
+#define L0P_STORE()                                                                                  \
+    do {                                                                                             \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                            \
+            for (int k = 0; k < 10; ++k) g_l0_ph[blockIdx.x][threadIdx.x >> 6][k] = l0p[k];           \
+    } while (0)
+extern "C" int mi355_debug_read_l0ph(long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l0_ph), sizeof(long long) * 4096 * 4 * 10) == hipSuccess ? 0 : -5;
+}
+#else
+#define L0P_DECL do { } while (0)
+#define L0P_MARK(k) do { } while (0)
+#define L0P_MARK_V(k, v) do { } while (0)
+#define L0P_STORE() do { } while (0)
+#endif
+
 template <int ACT, bool SAT, int NM, bool PLANAR>
 __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxArgs a)
 {
@@ -402,20 +436,33 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     const uint32_t zsplat = (uint32_t)a.zp_in * 0x01010101u;
     const size_t plane_sz = (size_t)a.H * a.W;
     const int planar_off = (prow_ix - 1) * a.W + 4 * pq - 4;  // byte offset of this thread's group from the tile's (16 ty, 32 tx)
+    // (the kernel is bound by its instruction ISSUE: VALU + scalar + LDS + memory instructions x 4 clocks account for its run time,
+    // SQ counters in profiles/ -- so the common case pays for as few of any kind as possible: tiles that do not touch the image border
+    // load without per-lane tests, everything a launch decides once is decided outside the tile loop)
+    const unsigned offv = (unsigned)(planar_off + (int)plane_sz);  // the thread's group from (tile origin - one plane): never negative
     auto fetch = [&](const Pos &p, uint32_t(&v)[3]) {  // cell indices fit an int (the launcher checks in_cells)
         if constexpr (PLANAR) {
-            // wave-uniform tile base on the scalar unit + the thread's loop-invariant 32-bit offset (scalar-base loads);
-            // out-of-image groups read a clamped in-image address and are replaced by the pad value
-            const int y = 16 * p.ty - 1 + prow_ix, x0 = 32 * p.tx - 4 + 4 * pq;
-            const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x0 < (unsigned)a.W && tid < 180;
+            // wave-uniform tile base on the scalar unit + the thread's loop-invariant 32-bit offset (scalar-base loads)
             // (32-bit: the launcher refuses inputs of 2 GiB and more)
             const unsigned tb = ((unsigned)p.b * 3u) * (unsigned)plane_sz + (unsigned)(16 * p.ty) * (unsigned)a.W + 32u * (unsigned)p.tx;
-            const uint8_t *tbase = a.x + (size_t)tb;
-            const unsigned off = inside ? (unsigned)(planar_off + (int)plane_sz) : (unsigned)plane_sz;  // biased by one plane: never negative
+            const uint8_t *tbase = a.x + (size_t)tb - plane_sz;
+            // rows 16 ty - 1 .. 16 ty + 16, columns 32 tx - 4 .. 32 tx + 35 all inside the image: no lane needs the pad value
+            const bool tin = p.ty >= 1 && 16 * p.ty + 16 < a.H && p.tx >= 1 && 32 * p.tx + 32 < a.W;
+            if (tin) {
+                if (tid < 180) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const uint32_t t = *reinterpret_cast<const uint32_t *>(tbase - plane_sz + off + (size_t)k * plane_sz);
-                v[k] = inside ? t : zsplat;
+                    for (int k = 0; k < 3; ++k) v[k] = *reinterpret_cast<const uint32_t *>(tbase + offv + (size_t)k * plane_sz);
+                }
+            } else {  // out-of-image groups are the input zero point
+                const int y = 16 * p.ty - 1 + prow_ix, x0 = 32 * p.tx - 4 + 4 * pq;
+                const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x0 < (unsigned)a.W && tid < 180;
+                if (inside) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) v[k] = *reinterpret_cast<const uint32_t *>(tbase + offv + (size_t)k * plane_sz);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) v[k] = zsplat;
+                }
             }
         } else {
             const int org = a.in_lead + (p.b * (a.H + 1) + 16 * p.ty) * W1 + 32 * p.tx - 1;  // image cell (0, 0)
@@ -428,12 +475,14 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
             if (tid < 180) {
                 uint4 c;
                 // byte i of the three plane dwords -> cell i = (c0, c1, c2, 0), then x' = x - 128 (pad byte: weight 0)
-                const uint32_t lo01 = __builtin_amdgcn_perm(v[1], v[0], 0x05010400u);  // (p0.b0, p1.b0, p0.b1, p1.b1)
-                const uint32_t hi01 = __builtin_amdgcn_perm(v[1], v[0], 0x07030602u);  // (p0.b2, p1.b2, p0.b3, p1.b3)
-                c.x = __builtin_amdgcn_perm(v[2], lo01, 0x0c040100u) ^ 0x80808080u;    // (lo01.b0, lo01.b1, p2.b0, 0)
-                c.y = __builtin_amdgcn_perm(v[2], lo01, 0x0c050302u) ^ 0x80808080u;
-                c.z = __builtin_amdgcn_perm(v[2], hi01, 0x0c060100u) ^ 0x80808080u;
-                c.w = __builtin_amdgcn_perm(v[2], hi01, 0x0c070302u) ^ 0x80808080u;
+                // (the bias is applied to the three plane dwords, not to the four cells: the pad byte stays 0, its weight is 0)
+                const uint32_t v0 = v[0] ^ 0x80808080u, v1 = v[1] ^ 0x80808080u, v2 = v[2] ^ 0x80808080u;
+                const uint32_t lo01 = __builtin_amdgcn_perm(v1, v0, 0x05010400u);  // (p0.b0, p1.b0, p0.b1, p1.b1)
+                const uint32_t hi01 = __builtin_amdgcn_perm(v1, v0, 0x07030602u);  // (p0.b2, p1.b2, p0.b3, p1.b3)
+                c.x = __builtin_amdgcn_perm(v2, lo01, 0x0c040100u);                // (lo01.b0, lo01.b1, p2.b0, 0)
+                c.y = __builtin_amdgcn_perm(v2, lo01, 0x0c050302u);
+                c.z = __builtin_amdgcn_perm(v2, hi01, 0x0c060100u);
+                c.w = __builtin_amdgcn_perm(v2, hi01, 0x0c070302u);
                 uint32_t *dst = &img[buf][prow_ix * ROWC + 4 * pq + 1];
                 dst[0] = c.x; dst[1] = c.y; dst[2] = c.z; dst[3] = c.w;
             }
@@ -464,126 +513,195 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     // s_waitcnt vmcnt(0) in front of the first MFMA of the (shared) loop body, which then also waits for the image
     // prefetch issued a few instructions earlier and for the previous tile's stores -- a memory round trip per tile.
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    int buf = 0;
-    for (; tile < tend; tile += tstride, buf ^= 1, cur = nxp) {
-        __syncthreads();  // this tile's image is complete; every wave is past the previous tile
-        const bool more = tile + tstride < tend;
-        advance(nxp);
-        if (more) fetch(nxp, nxt);
-        const int b = cur.b, ty = cur.ty, tx = cur.tx;
-        // byte offset of the patch's first pooled cell: wave-uniform 32-bit arithmetic on the scalar unit (the launcher refuses pooled
-        // tensors of 4 GiB and more), once per tile; a pooled row further down is one row pitch on.  The store then is
-        // "scalar base + the lane's loop-invariant 32-bit offset".
-        const unsigned tile_off = (unsigned)(a.pool_lead + (b * (OH + 1) + 8 * ty + 1) * (OW + 1) + 16 * tx) * (unsigned)a.pool_cs;
-        const unsigned rowpitch = (unsigned)(OW + 1) * (unsigned)a.pool_cs;
-        const bool colvalid = 16 * tx + pc < OW;
+    // A tile's packed bytes are stored one tile LATE, right after the next tile's prefetch: vmcnt counts loads and stores alike, the
+    // stores sit behind exec-masked branches (so the compiler cannot count them and guards the staging registers with vmcnt(0)), and
+    // issued in place they put a store round trip to HBM in front of every tile's staging wait.  Issued behind the prefetch they have a
+    // whole tile to drain, like the prefetch (in front of it they would be what the compiler's vmcnt(0) ahead of the loads waits for).
+    uint32_t dpk[2][NM];
+    uint8_t *dout[2] = {a.ypool, a.ypool};
+    bool dvalid[2] = {false, false};
+    bool dall = false;  // wave-uniform: every lane of the deferred tile stores
+    auto flush_stores = [&]() {
+        if (dall) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int pr = 2 * wave + s;  // pooled row inside the patch
-            const bool valid = colvalid && 8 * ty + pr < OH;
-            // two image rows x four cells (x = 2 pcol - 1 .. 2 pcol + 2) feed the four window positions of this lane's k-group:
-            // one aligned 16-byte operand per row (8-byte aligned in LDS: two dwords each from a ds_read2_b64)
-            const uint32_t *p0 = img[buf] + (2 * pr + (g < 3 ? g : 2)) * ROWC + 2 * pc + XO;
-            v4i bf[2];
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int jy = 0; jy < 2; ++jy) {
-                const uint2 q0 = *reinterpret_cast<const uint2 *>(p0 + jy * ROWC), q1 = *reinterpret_cast<const uint2 *>(p0 + jy * ROWC + 2);
-                bf[jy] = v4i{(int)q0.x, (int)q0.y, (int)q1.x, (int)q1.y};
-            }
-            uint8_t *const outp = a.ypool + (size_t)(tile_off + (unsigned)pr * rowpitch);  // wave-uniform
+                for (int mt = 0; mt < NM; ++mt) *reinterpret_cast<uint32_t *>(dout[s] + (pc_off + (unsigned)chq[mt])) = dpk[s][mt];
+        } else {
 #pragma unroll
-            for (int mt = 0; mt < NM; ++mt) {
-                v4i acc[4];
-                if (!(a.debug_flags & 131072)) __builtin_amdgcn_s_setprio(3);  // the MFMA chain outranks the other waves' requantisation
+            for (int s = 0; s < 2; ++s)
+                if (dvalid[s]) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[mt][j & 1], bf[j >> 1], cb[mt], 0, 0, 0);
-                // the correction passes as their own rounds over the four (independent) window positions; the dz = 128
-                // pass is chosen once, not behind a branch after every MFMA
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd1[mt][j & 1], bf[j >> 1], acc[j], 0, 0, 0);
-                if (need_d2) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt][j & 1], bf[j >> 1], acc[j], 0, 0, 0);
+                    for (int mt = 0; mt < NM; ++mt) *reinterpret_cast<uint32_t *>(dout[s] + (pc_off + (unsigned)chq[mt])) = dpk[s][mt];
                 }
-                __builtin_amdgcn_s_setprio(0);
-                // accumulators are biased by lo: one unsigned maximum gives the range test and the window maximum (common.h)
-                uint32_t umax[4];
-                // the four range tests as wave masks on the scalar unit (one v_cmp each; no per-lane flag to build and ballot)
-                uint64_t badm = never ? ~0ull : 0ull;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    umax[r] = max(max((uint32_t)acc[0][r], (uint32_t)acc[1][r]), max((uint32_t)acc[2][r], (uint32_t)acc[3][r]));
-                    badm |= __builtin_amdgcn_ballot_w64(umax[r] > (uint32_t)hi[mt][r]);
-                }
-                uint32_t packed;
-                if (badm == 0 && pow2) {
-                    if (INTRQ && use_int) {  // two integer instructions per value instead of convert / FP64 multiply / convert
-                        // f = floor(a * M0 / 2^(32 + sh)), a = u + lo:  v_mad_u64_u32 (u * M0 + lo * M0, exact mod 2^64: |a * M0| < 2^53),
-                        // then an arithmetic shift of the high dword
-                        int32_t f[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const uint64_t p = (uint64_t)umax[r] * (uint64_t)(uint32_t)qm0[mt][r] + (uint64_t)qc[mt][r];
-                            f[r] = (int32_t)(uint32_t)(p >> 32) >> qsh[mt][r];
-                        }
-#ifndef MI355_L0_LEAKY_ARITH
-                        if constexpr (LUT) {
-                            uint32_t bt[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) bt[r] = lut[f[r] + LUTQ_OFF];
-                            packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
-                        } else
-#else
-                        if constexpr (LUT) {  // A/B build: LEAKY in four VALU instructions on the floor form instead of the table's LDS round trip
-                            packed = pack4_biased(leaky_of_floor(f[0], a.zp_act), leaky_of_floor(f[1], a.zp_act), leaky_of_floor(f[2], a.zp_act),
-                                                  leaky_of_floor(f[3], a.zp_act));
-                        } else
+        }
+    };
+    const unsigned rowpitch = (unsigned)(OW + 1) * (unsigned)a.pool_cs;
+    const unsigned wave_row_off = (unsigned)(2 * wave) * rowpitch;  // this wave's first pooled row inside a patch
+    const int lane_b = ((g < 3 ? g : 2) * ROWC + 2 * pc + XO) * 4 + 2 * wave * 2 * ROWC * 4;  // the lane's operand bytes inside an image buffer
+    L0P_DECL;
+    // FASTC: power-of-two shifts, no channel without a wrap-safe range and (where the activation has an integer requantisation) every
+    // channel passed its exactness conditions -- decided once per launch, so that the tile loop carries none of these tests; D2C: some
+    // channel's zero-point correction is 128 (a third MFMA round).  Four instantiations of the loop, one runs.
+    auto run = [&](auto fast_c, auto d2_c) {
+        constexpr bool FASTC = decltype(fast_c)::value, D2C = decltype(d2_c)::value;
+        int buf = 0;
+        for (; tile < tend; tile += tstride, buf ^= 1, cur = nxp) {
+            L0P_MARK(6);
+            __syncthreads();  // this tile's image is complete; every wave is past the previous tile
+            L0P_MARK(0);
+            const bool more = tile + tstride < tend;
+            advance(nxp);
+            if (more) fetch(nxp, nxt);
+            L0P_MARK(1);
+#ifndef MI355_L0_STORES_IN_PLACE
+            flush_stores();
 #endif
-                        {  // RELU6: zp + max(q, 0) == zp + max(f, 0); SAT clamps
-                            int32_t v[4];
+            L0P_MARK(2);
+            const int b = cur.b, ty = cur.ty, tx = cur.tx;
+            // byte offset of the patch's first pooled cell: wave-uniform 32-bit arithmetic on the scalar unit (the launcher refuses pooled
+            // tensors of 4 GiB and more), once per tile; a pooled row further down is one row pitch on.  The store then is
+            // "scalar base + the lane's loop-invariant 32-bit offset".
+            const unsigned tile_off = (unsigned)(a.pool_lead + (b * (OH + 1) + 8 * ty + 1) * (OW + 1) + 16 * tx) * (unsigned)a.pool_cs;
+            uint8_t *const outp0 = a.ypool + (size_t)(tile_off + wave_row_off);  // wave-uniform
+            const bool tall = 16 * tx + 16 <= OW && 8 * ty + 8 <= OH;           // the whole patch lies inside the pooled map
+            const char *const ib = reinterpret_cast<const char *>(img[buf]) + lane_b;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // two image rows x four cells (x = 2 pcol - 1 .. 2 pcol + 2) feed the four window positions of this lane's k-group:
+                // one aligned 16-byte operand per row (8-byte aligned in LDS: two dwords each from a ds_read2_b64)
+                const uint32_t *p0 = reinterpret_cast<const uint32_t *>(ib + s * 2 * ROWC * 4);
+                v4i bf[2];
+#pragma unroll
+                for (int jy = 0; jy < 2; ++jy) {
+                    const uint2 q0 = *reinterpret_cast<const uint2 *>(p0 + jy * ROWC), q1 = *reinterpret_cast<const uint2 *>(p0 + jy * ROWC + 2);
+                    bf[jy] = v4i{(int)q0.x, (int)q0.y, (int)q1.x, (int)q1.y};
+                }
+#pragma unroll
+                for (int mt = 0; mt < NM; ++mt) {
+                    v4i acc[4];
+                    __builtin_amdgcn_s_setprio(3);  // the MFMA chain outranks the other waves' requantisation
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[mt][j & 1], bf[j >> 1], cb[mt], 0, 0, 0);
+                    // the correction passes as their own rounds over the four (independent) window positions
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd1[mt][j & 1], bf[j >> 1], acc[j], 0, 0, 0);
+                    if constexpr (D2C) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt][j & 1], bf[j >> 1], acc[j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                    L0P_MARK_V(2 + 2 * s, acc[3][0]);
+                    // accumulators are biased by lo: one unsigned maximum gives the range test and the window maximum (common.h)
+                    uint32_t umax[4];
+                    // the four range tests as wave masks on the scalar unit (one v_cmp each; no per-lane flag to build and ballot)
+                    uint64_t badm = (!FASTC && never) ? ~0ull : 0ull;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        umax[r] = max(max((uint32_t)acc[0][r], (uint32_t)acc[1][r]), max((uint32_t)acc[2][r], (uint32_t)acc[3][r]));
+                        badm |= __builtin_amdgcn_ballot_w64(umax[r] > (uint32_t)hi[mt][r]);
+                    }
+                    uint32_t packed;
+                    if (badm == 0 && (FASTC || pow2)) {
+                        if (INTRQ && (FASTC || use_int)) {  // two integer instructions per value instead of convert / FP64 multiply / convert
+                            // f = floor(a * M0 / 2^(32 + sh)), a = u + lo:  v_mad_u64_u32 (u * M0 + lo * M0, exact mod 2^64: |a * M0| < 2^53),
+                            // then an arithmetic shift of the high dword
+                            int32_t f[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                v[r] = a.zp_act + max(f[r], 0);
-                                if (SAT) v[r] = min(v[r], 255);
+                                const uint64_t p = (uint64_t)umax[r] * (uint64_t)(uint32_t)qm0[mt][r] + (uint64_t)qc[mt][r];
+                                f[r] = (int32_t)(uint32_t)(p >> 32) >> qsh[mt][r];
                             }
-                            packed = pack4_biased(v[0], v[1], v[2], v[3]);
+#ifndef MI355_L0_LEAKY_ARITH
+                            if constexpr (LUT) {
+                                uint32_t bt[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) bt[r] = lut[f[r] + LUTQ_OFF];
+                                packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
+                            } else
+#else
+                            if constexpr (LUT) {  // A/B build: LEAKY in four VALU instructions on the floor form instead of the table's LDS round trip
+                                packed = pack4_biased(leaky_of_floor(f[0], a.zp_act), leaky_of_floor(f[1], a.zp_act), leaky_of_floor(f[2], a.zp_act),
+                                                      leaky_of_floor(f[3], a.zp_act));
+                            } else
+#endif
+                            {  // RELU6: zp + max(q, 0) == zp + max(f, 0); SAT clamps
+                                int32_t v[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    v[r] = a.zp_act + max(f[r], 0);
+                                    if (SAT) v[r] = min(v[r], 255);
+                                }
+                                packed = pack4_biased(v[0], v[1], v[2], v[3]);
+                            }
+                        } else if constexpr (LUT) {  // q of a window inside the safe range lies inside the table (common.h)
+                            int32_t amax[4][1];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
+                            // four independent chains, issued pass by pass: left alone the compiler threads all four conversions through
+                            // one register pair and every FP64 instruction waits out the latency of the one before it
+                            uint32_t bt[4];
+                            double dd[4];
+                            int32_t qq[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dd[r] = (double)amax[r][0];
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dd[r] = dd[r] * mp[mt][r];
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) qq[r] = (int32_t)dd[r];
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) bt[r] = lut[qq[r] + LUTQ_OFF];
+                            packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
+                        } else {
+                            int32_t amax[4][1], v1[4][1];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
+                            requant_values<ACT, SAT, 1>(amax, mp[mt], a.zp_act, v1);
+                            packed = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
                         }
-                    } else if constexpr (LUT) {  // q of a window inside the safe range lies inside the table (common.h)
-                        int32_t amax[4][1];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
-                        // four independent chains, issued pass by pass: left alone the compiler threads all four conversions through
-                        // one register pair and every FP64 instruction waits out the latency of the one before it
-                        uint32_t bt[4];
-                        double dd[4];
-                        int32_t qq[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dd[r] = (double)amax[r][0];
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dd[r] = dd[r] * mp[mt][r];
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) qq[r] = (int32_t)dd[r];
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) bt[r] = lut[qq[r] + LUTQ_OFF];
-                        packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
-                    } else {
-                        int32_t amax[4][1], v1[4][1];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
-                        requant_values<ACT, SAT, 1>(amax, mp[mt], a.zp_act, v1);
-                        packed = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
+                    } else {  // some window of this wave may wrap (or odd shifts): the reference's order, bytes first, then the maximum
+                        packed = first_pool_exact_path<ACT, SAT>(acc, lo[mt], mp[mt], a.mval + chq[mt], a.sval + chq[mt], a.zp_act, pow2);
                     }
-                } else {  // some window of this wave may wrap (or odd shifts): the reference's order, bytes first, then the maximum
-                    packed = first_pool_exact_path<ACT, SAT>(acc, lo[mt], mp[mt], a.mval + chq[mt], a.sval + chq[mt], a.zp_act, pow2);
+                    dpk[s][mt] = packed;
+                    L0P_MARK_V(3 + 2 * s, packed);
                 }
-                if (valid) *reinterpret_cast<uint32_t *>(outp + (pc_off + (unsigned)chq[mt])) = packed;
+                dout[s] = outp0 + s * rowpitch;
             }
+            dall = tall;
+            if (!tall) {
+                const bool colvalid = 16 * tx + pc < OW;
+                dvalid[0] = colvalid && 8 * ty + 2 * wave < OH;
+                dvalid[1] = colvalid && 8 * ty + 2 * wave + 1 < OH;
+            }
+#ifdef MI355_L0_STORES_IN_PLACE  // A/B builds: the stores in place, in front of the staging wait
+            flush_stores();
+#endif
+#ifdef MI355_ABLATE
+            L0P_MARK(6);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            L0P_MARK(8);  // the prefetch (and the deferred stores) landed
+#endif
+            if (more) stash(buf ^ 1, nxt);
+#ifdef MI355_ABLATE
+            L0P_MARK(9);  // staging: permutes + LDS writes
+            l0p[7] += 1;
+#endif
         }
-        if (more) stash(buf ^ 1, nxt);
+    };
+    const bool fastc = pow2 && !never && (!INTRQ || use_int);
+    if (fastc) {
+        if (need_d2) run(std::true_type{}, std::true_type{});
+        else run(std::true_type{}, std::false_type{});
+    } else {
+        if (need_d2) run(std::false_type{}, std::true_type{});
+        else run(std::false_type{}, std::false_type{});
     }
+    flush_stores();
+    L0P_MARK(6);
+    L0P_STORE();
 }
 
 // The same kernel without the pool: the first layer of the non-tiny networks (YOLOv3's 3 -> 32 at full resolution) stores
