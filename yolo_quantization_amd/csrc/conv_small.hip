@@ -816,8 +816,10 @@ static int small_launch_kern(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 template <int C, int NM, int ACT, int POOL>
 static int small_launch_sat2(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 {
+#ifndef MI355_SMALL_NO_VDZ  // (A/B builds: the MFMA form of the zero-point correction under both plans)
     if (C == 16 && POOL == 0 && a.plan == MI355_PLAN_THROUGHPUT && a.store_mode != MI355_STORE_SATURATE)
         return small_launch_kern<conv_small_pool_kernel<C, NM, ACT, false, POOL, (C == 16)>>(a, st, grid, lds);
+#endif
     if (a.store_mode == MI355_STORE_SATURATE) return small_launch_kern<conv_small_pool_kernel<C, NM, ACT, true, POOL>>(a, st, grid, lds);
     return small_launch_kern<conv_small_pool_kernel<C, NM, ACT, false, POOL>>(a, st, grid, lds);
 }
