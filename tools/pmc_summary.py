@@ -10,7 +10,7 @@ for r in rows:
     k = r.get("Kernel_Name", "?").split("(")[0][:70]
     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
-    if "conv_" not in k and "maxpool" not in k:
+    if "conv" not in k and "maxpool" not in k:
         continue
     print(k)
     for c, v in sorted(cs.items()):

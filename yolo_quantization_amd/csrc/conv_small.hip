@@ -88,7 +88,13 @@ __device__ __forceinline__ uint32_t pool_requant_quad(const int32_t (&accb)[4][4
 // channels allow it (common.h intrq_make; use_int is workgroup-uniform) -- 11 VALU per pooled output instead of ~21 on the fast path.
 // u[r][j] = biased accumulator of channel r at window position j; lo / rg = lower end and width of the safe range; `never`: some
 // channel of the launch has no safe range at all.
-template <int ACT, bool SAT>
+// `never` is the launch's "always take the exact path" flag: a channel without a safe range, shifts that are not powers of two, or (where
+// the activation has the integer form) a channel that failed its exactness conditions -- folded into ONE wave-uniform flag by the caller, so
+// that the common path tests nothing else per group of four channels (the kernels are close to instruction-issue bound, DESIGN.md 4.5;
+// such launches requantise every window value: slower, same bytes).
+// FOLD = false keeps the separate tests (pow2, use_int) on the common path: the 16-channel kernel's LEAKY instantiations need 17 registers
+// more without them (bigger basic blocks) and lose their third workgroup per CU or spill (layer 2: 34.7 -> 37.1 us; layer 4, FOLD: 22.1 -> 20.4).
+template <int ACT, bool SAT, bool FOLD>
 __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)[4][4], const int (&lo)[4], const int (&rg)[4], bool never,
                                                              bool use_int, const int (&m0)[4], const int (&sh)[4], const double *ldsMP4,
                                                              int zp_act, bool pow2, const double *mval4, const double *sval4)
@@ -100,11 +106,11 @@ __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)
         umax[r] = max(max(u[r][0], u[r][1]), max(u[r][2], u[r][3]));
         bad |= umax[r] > (uint32_t)rg[r];
     }
-    if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {  // no window of this wave can wrap: requantise the maxima
+    if (__builtin_amdgcn_ballot_w64(bad) == 0 && (FOLD || pow2)) {  // no window of this wave can wrap (FOLD: never == false says the rest)
         int32_t amax[4][1], v[4][1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[r]);
-        if ((ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT && use_int) {
+        if ((ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT && (FOLD || use_int)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int32_t f = intrq_floor(amax[r][0], m0[r], sh[r]);
@@ -220,8 +226,11 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
         ldsM0[tid] = m0;
         ldsSH[tid] = sh;
     }
-    const bool never = POOL && __syncthreads_or(never_l) != 0;
+    // one wave-uniform flag for "this launch requantises every window value" (see pool_requant_quad_biased)
+    constexpr bool INTRQC = (ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT;
+    constexpr bool FOLD = C == 32;
     const bool use_int = POOL && __syncthreads_or(noint_l) == 0;
+    const bool never = POOL && (__syncthreads_or(never_l) != 0 || (FOLD && (!pow2 || (INTRQC && !use_int))));
 
     // ---- stationary A fragments: plane ws = [m-tile][k-step][lane][16 B]
     v4i wf[NM][KST];
@@ -432,7 +441,10 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
             // the wave inside its MFMA chain outranks the co-resident waves that requantise: its MFMAs get their issue slot at
             // once (one in eight) and the others' VALU work fills the rest, instead of the matrix pipe idling behind an older
             // wave's VALU stream (issue arbitration is by priority, then age)
-            if (!(a.debug & 131072)) __builtin_amdgcn_s_setprio(3);
+#ifdef MI355_ABLATE
+            if (!(a.debug & 131072))
+#endif
+                __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int s = 0; s < KST; ++s)
 #pragma unroll
@@ -477,8 +489,8 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ub[r][j] = (uint32_t)accb[r][j];
-                    pk[mt][grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, use_int, m0v, shv, ldsMP + ch0, a.zp_act, pow2,
-                                                                     a.mval + ch0, a.sval + ch0);
+                    pk[mt][grp] = pool_requant_quad_biased<ACT, SAT, FOLD>(ub, lov, hiv, never, use_int, m0v, shv, ldsMP + ch0, a.zp_act, pow2,
+                                                                           a.mval + ch0, a.sval + ch0);
                 } else if constexpr (MODE == 2) {  // stride 2: one value per (pixel, channel), plain requantisation
                     int32_t a1[4][1], v1[4][1];
 #pragma unroll
