@@ -240,13 +240,18 @@ __device__ __forceinline__ void leaky_lut_build(uint8_t *lut, int zp_act, int ti
 // (intrq_make); a channel that fails keeps the FP64 form for the whole launch.  What consumes f: the LEAKY byte table indexed by f
 // (leaky_lutf_build: entry f holds the byte of q = f + (f < 0)), or RELU6's zp + max(f, 0) == zp + max(q, 0).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool intrq_make(double mval, int s, int32_t lo, int32_t hi, int32_t &m0, int32_t &sh)
+// neg_any (RELU / RELU6): every negative accumulator is stored as the zero point whatever its q -- zp + max(f, 0) only needs f < 0 there, which
+// floor(a * M0 / 2^(31+s)) is for every a < 0 -- so the conditions apply to the non-negative end of the range only.  (Without this a RELU6
+// layer never qualified: its wrap-safe range reaches down to the clamp at -2^30, and 2^30 * M0 is far beyond 2^53.)
+__device__ __forceinline__ bool intrq_make(double mval, int s, int32_t lo, int32_t hi, int32_t &m0, int32_t &sh, bool neg_any = false)
 {
     m0 = 0; sh = 0;
     if (!(mval > 0.0 && mval < 1.0) || s < 1 || s > 31) return false;
     const double t = mval * 2147483648.0;   // exact: a power-of-two scaling
     const int32_t m = (int32_t)t;
     if ((double)m != t || m <= 0) return false;   // M_value is not an int32 * 2^-31
+    if (neg_any && lo < 0) lo = 0;
+    if (hi < lo) hi = lo;
     const long amax = (-(long)lo > (long)hi) ? -(long)lo : (long)hi;
     if (amax < 0 || (unsigned long)amax * (unsigned long)m >= (1ul << 53)) return false;  // FP64 product not provably exact
     const int tz = __builtin_ctz((unsigned)m);

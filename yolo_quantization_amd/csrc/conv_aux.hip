@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
             int32_t lb = 0; uint32_t rg = 0;
             if (!biased_safe_range(l, h, lb, rg)) never_l = 1;
             qm0[mt][r] = qsh[mt][r] = 0;
-            if (INTRQ && (!pow2 || !intrq_make(a.mval[c2], shiftp[c2], lb, (int32_t)((uint32_t)lb + rg), qm0[mt][r], qsh[mt][r]))) noint_l = 1;
+            if (INTRQ && (!pow2 || !intrq_make(a.mval[c2], shiftp[c2], lb, (int32_t)((uint32_t)lb + rg), qm0[mt][r], qsh[mt][r], ACT == MI355_ACT_RELU6))) noint_l = 1;
             qc[mt][r] = (int64_t)lb * (int64_t)qm0[mt][r];
             asm volatile("" : "+v"(qc[mt][r]));  // opaque: the compiler otherwise factors u * M0 + lo * M0 back into (u + lo) * M0 as a 64 x 32 multiply
             cb[mt][r] = (int32_t)((uint32_t)a.cwb[c2] - (uint32_t)lb);  // accumulators biased by the safe range's lower end (common.h)

@@ -85,18 +85,15 @@ __device__ __forceinline__ uint32_t pool_requant_quad(const int32_t (&accb)[4][4
 // Round 4: the same on accumulators BIASED by the lower end of the wrap-safe range (the seed cw + bias - lo is the MFMA's C operand /
 // the accumulator's start value: free), common.h biased_safe_range: one unsigned maximum over the window is the range test and the
 // maximum (3 VALU per pooled output instead of 8), and the maximum is requantised with two integer instructions where the launch's
-// channels allow it (common.h intrq_make; use_int is workgroup-uniform) -- 11 VALU per pooled output instead of ~21 on the fast path.
-// u[r][j] = biased accumulator of channel r at window position j; lo / rg = lower end and width of the safe range; `never`: some
-// channel of the launch has no safe range at all.
+// channels allow it (common.h intrq_make) -- 11 VALU per pooled output instead of ~21 on the fast path.
+// u[r][j] = biased accumulator of channel r at window position j; lo / rg = lower end and width of the safe range.
 // `never` is the launch's "always take the exact path" flag: a channel without a safe range, shifts that are not powers of two, or (where
 // the activation has the integer form) a channel that failed its exactness conditions -- folded into ONE wave-uniform flag by the caller, so
 // that the common path tests nothing else per group of four channels (the kernels are close to instruction-issue bound, DESIGN.md 4.5;
 // such launches requantise every window value: slower, same bytes).
-// FOLD = false keeps the separate tests (pow2, use_int) on the common path: the 16-channel kernel's LEAKY instantiations need 17 registers
-// more without them (bigger basic blocks) and lose their third workgroup per CU or spill (layer 2: 34.7 -> 37.1 us; layer 4, FOLD: 22.1 -> 20.4).
-template <int ACT, bool SAT, bool FOLD>
+template <int ACT, bool SAT>
 __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)[4][4], const int (&lo)[4], const int (&rg)[4], bool never,
-                                                             bool use_int, const int (&m0)[4], const int (&sh)[4], const double *ldsMP4,
+                                                             const int (&m0)[4], const int (&sh)[4], const double *ldsMP4,
                                                              int zp_act, bool pow2, const double *mval4, const double *sval4)
 {
     uint32_t umax[4];
@@ -106,11 +103,11 @@ __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)
         umax[r] = max(max(u[r][0], u[r][1]), max(u[r][2], u[r][3]));
         bad |= umax[r] > (uint32_t)rg[r];
     }
-    if (__builtin_amdgcn_ballot_w64(bad) == 0 && (FOLD || pow2)) {  // no window of this wave can wrap (FOLD: never == false says the rest)
+    if (__builtin_amdgcn_ballot_w64(bad) == 0) {  // no window of this wave can wrap (and never == false: power-of-two shifts, integer form valid)
         int32_t amax[4][1], v[4][1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[r]);
-        if ((ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT && (FOLD || use_int)) {
+        if ((ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int32_t f = intrq_floor(amax[r][0], m0[r], sh[r]);
@@ -135,14 +132,19 @@ __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)
 #pragma unroll
         for (int r = 0; r < 4; ++r) m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
     } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
+        // A ROLLED loop over a private array: unrolled, these sixteen two-step requantisations (global multiplier loads, two FP64 chains
+        // each) were what the register allocator sized the whole kernel by -- 8 to 17 registers of the common path (the 16-channel kernel
+        // sits at its three-workgroups-per-CU edge).  Slow, and only ever run by models the reference's preparation does not produce.
+        int32_t tmp[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int32_t t = 0;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                t = max(t, (int32_t)requant_u8(accb[r][j], 0, mval4[r], sval4[r], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
-            m[r] = t;
-        }
+            for (int j = 0; j < 4; ++j) tmp[4 * r + j] = accb[r][j];
+#pragma unroll 1
+        for (int idx = 0; idx < 16; ++idx)
+            tmp[idx] = (int32_t)requant_u8(tmp[idx], 0, mval4[idx >> 2], sval4[idx >> 2], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = max(max(tmp[4 * r], tmp[4 * r + 1]), max(tmp[4 * r + 2], tmp[4 * r + 3]));
     }
     return pack4_biased(m[0], m[1], m[2], m[3]);
 }
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
         if constexpr (POOL) {
             int32_t lb = 0; uint32_t rg = 0;
             if (!biased_safe_range(lo, hi, lb, rg)) never_l = 1;
-            if (!(pow2 && intrq_make(a.mval[tid], a.shift[tid], lb, (int32_t)((uint32_t)lb + rg), m0, sh))) noint_l = 1;
+            if (!(pow2 && intrq_make(a.mval[tid], a.shift[tid], lb, (int32_t)((uint32_t)lb + rg), m0, sh, ACT == MI355_ACT_RELU6))) noint_l = 1;
             ldsCB[tid] = (int32_t)((uint32_t)a.cwb[tid] - (uint32_t)lb);
             ldsLO[tid] = lb;
             ldsHI[tid] = (int32_t)rg;
@@ -228,9 +230,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
     }
     // one wave-uniform flag for "this launch requantises every window value" (see pool_requant_quad_biased)
     constexpr bool INTRQC = (ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT;
-    constexpr bool FOLD = C == 32;
-    const bool use_int = POOL && __syncthreads_or(noint_l) == 0;
-    const bool never = POOL && (__syncthreads_or(never_l) != 0 || (FOLD && (!pow2 || (INTRQC && !use_int))));
+    const bool never = POOL && (__syncthreads_or(never_l | (INTRQC ? noint_l : 0)) != 0 || !pow2);
 
     // ---- stationary A fragments: plane ws = [m-tile][k-step][lane][16 B]
     v4i wf[NM][KST];
@@ -489,8 +489,8 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ub[r][j] = (uint32_t)accb[r][j];
-                    pk[mt][grp] = pool_requant_quad_biased<ACT, SAT, FOLD>(ub, lov, hiv, never, use_int, m0v, shv, ldsMP + ch0, a.zp_act, pow2,
-                                                                           a.mval + ch0, a.sval + ch0);
+                    pk[mt][grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, m0v, shv, ldsMP + ch0, a.zp_act, pow2,
+                                                                     a.mval + ch0, a.sval + ch0);
                 } else if constexpr (MODE == 2) {  // stride 2: one value per (pixel, channel), plain requantisation
                     int32_t a1[4][1], v1[4][1];
 #pragma unroll
