@@ -42,47 +42,9 @@ constexpr int SM_GMAX = 8;    // conv_mid_pool_kernel: groups of 32 pooled pixel
 constexpr int SM_KMAX = 6;    // DMA instructions per wave and piece per tile image (image <= 4 * 6 * 64 cells)
 
 
-// The pooled store of four channels x one 2x2 window held by a lane: accb[r][j] = accumulator (bias and zero-point terms
-// included) of channel r at window position j.  Wave-uniform control flow inside (ballots): call it from uniform code.
-template <int ACT, bool SAT>
-__device__ __forceinline__ uint32_t pool_requant_quad(const int32_t (&accb)[4][4], const double (&mp)[4], const int (&lov)[4],
-                                                      const int (&hiv)[4], int zp_act, bool pow2, const double *mval4,
-                                                      const double *sval4)
-{
-    int32_t amax[4][1];
-    bool bad = false;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int32_t mx = max(max(accb[r][0], accb[r][1]), max(accb[r][2], accb[r][3]));
-        const int32_t mn = min(min(accb[r][0], accb[r][1]), min(accb[r][2], accb[r][3]));
-        bad |= (mx > hiv[r]) | (mn < lov[r]);
-        amax[r][0] = mx;
-    }
-    int32_t m[4];
-    if (__builtin_amdgcn_ballot_w64(bad) == 0 && pow2) {  // no window of this wave can wrap: requantise the maxima
-        int32_t v[4][1];
-        requant_values<ACT, SAT, 1>(amax, mp, zp_act, v);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = v[r][0];
-    } else if (pow2) {  // some window of this wave wraps: the reference's order, bytes first, then the max
-        int32_t v[4][4];
-        requant_values<ACT, SAT, 4>(accb, mp, zp_act, v);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
-    } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int32_t t = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                t = max(t, (int32_t)requant_u8(accb[r][j], 0, mval4[r], sval4[r], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
-            m[r] = t;
-        }
-    }
-    return pack4_biased(m[0], m[1], m[2], m[3]);
-}
-
-// Round 4: the same on accumulators BIASED by the lower end of the wrap-safe range (the seed cw + bias - lo is the MFMA's C operand /
+// The pooled store of four channels x one 2x2 window held by a lane (wave-uniform control flow inside: call it from uniform code).
+// Rounds 1-3 tested the window's minimum and maximum against the wrap-safe range [lo, hi] and requantised the maximum in FP64;
+// round 4 keeps the accumulators BIASED by the lower end of the wrap-safe range (the seed cw + bias - lo is the MFMA's C operand /
 // the accumulator's start value: free), common.h biased_safe_range: one unsigned maximum over the window is the range test and the
 // maximum (3 VALU per pooled output instead of 8), and the maximum is requantised with two integer instructions where the launch's
 // channels allow it (common.h intrq_make) -- 11 VALU per pooled output instead of ~21 on the fast path.
@@ -565,7 +527,8 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
     double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier
     int *ldsDZ = reinterpret_cast<int *>(ldsMP + N);
     int *ldsCB = ldsDZ + N;
-    int *ldsLO = ldsCB + N, *ldsHI = ldsLO + N;
+    int *ldsLO = ldsCB + N, *ldsHI = ldsLO + N;                           // POOL: lower end and width of the wrap-safe range (biased accumulators)
+    int *ldsM0 = ldsHI + N, *ldsSH = ldsM0 + N;                           // integer requantisation: M0, s - 1 (common.h intrq_make)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
     const int tid = threadIdx.x, NT = blockDim.x;
@@ -622,16 +585,33 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         }
     }
     // ---- per-channel parameters, wrap-safe ranges, this wave's A fragments (overlap the DMA)
+    // (POOL: accumulators biased by the safe range's lower end, window maxima requantised with two integer instructions where every channel
+    // qualifies -- pool_requant_quad_biased, as in conv_small_pool_kernel)
+    constexpr bool INTRQC = (ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT;
+    int never_l = 0;
     for (int i = tid; i < N; i += NT) {
         const double mp = a.mprime[i];
         ldsMP[i] = mp;
         ldsDZ[i] = a.dzp[i];
-        ldsCB[i] = a.cwb[i];
         int32_t lo = -2147483647 - 1, hi = 2147483647;
         if (!SAT && POOL) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
-        ldsLO[i] = lo;
-        ldsHI[i] = hi;
+        int32_t m0 = 0, sh = 0;
+        if constexpr (POOL) {
+            int32_t lb = 0; uint32_t rg = 0;
+            if (!biased_safe_range(lo, hi, lb, rg)) never_l = 1;
+            if (INTRQC && !(pow2 && intrq_make(a.mval[i], a.shift[i], lb, (int32_t)((uint32_t)lb + rg), m0, sh, ACT == MI355_ACT_RELU6))) never_l = 1;
+            ldsCB[i] = (int32_t)((uint32_t)a.cwb[i] - (uint32_t)lb);
+            ldsLO[i] = lb;
+            ldsHI[i] = (int32_t)rg;
+        } else {
+            ldsCB[i] = a.cwb[i];
+            ldsLO[i] = lo;
+            ldsHI[i] = hi;
+        }
+        ldsM0[i] = m0;
+        ldsSH[i] = sh;
     }
+    const bool never = POOL && (__syncthreads_or(never_l) != 0 || !pow2);
     v4i wf[KST];
 #pragma unroll
     for (int s = 0; s < KST; ++s) wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(wq * KST + s) * 64 + lane) * 16);
@@ -751,7 +731,16 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
                 for (int j = 0; j < 4; ++j) accb[r][j] = j >= NJ ? 0 : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
             }
             if constexpr (POOL) {
-                const uint32_t packed = pool_requant_quad<ACT, SAT>(accb, mp, lov, hiv, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
+                const int4 m04 = *reinterpret_cast<const int4 *>(ldsM0 + ch0);
+                const int4 sh4 = *reinterpret_cast<const int4 *>(ldsSH + ch0);
+                const int m0v[4] = {m04.x, m04.y, m04.z, m04.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+                uint32_t ub[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ub[r][j] = (uint32_t)accb[r][j];
+                const uint32_t packed = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, m0v, shv, ldsMP + ch0, a.zp_act, pow2,
+                                                                           a.mval + ch0, a.sval + ch0);
                 if (pcell >= 0) *reinterpret_cast<uint32_t *>(a.ypool + (size_t)pcell * a.pool_cs + ch0) = packed;
             } else if constexpr (MODE == 2) {  // stride 2: window position 0 is the output pixel
                 int32_t a1[4][1], v1[4][1];
@@ -913,7 +902,7 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
         size_t l64 = 4 * (size_t)a.sm_pieceb + (size_t)((a.rows_cap * a.sm_ncell + 1) & ~1) * 4 + SM_GMAX * 128 * 8 + SM_GMAX * 32 * 8;
         l64 = (l64 + 15) & ~(size_t)15;
         a.lds_param_off = (int)l64;
-        l64 += (size_t)a.n * 24;
+        l64 += (size_t)a.n * 32;
         if (l64 > 160 * 1024) return MI355_EINVAL;
         const int threads = 2 * (a.n / 32) * 64;
         if (a.act == MI355_ACT_LEAKY) return mid_launch_sat<MI355_ACT_LEAKY>(a, st, ntiles, threads, l64);
