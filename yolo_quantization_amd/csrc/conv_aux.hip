@@ -276,15 +276,17 @@ __device__ __forceinline__ uint32_t first_pool_exact_path(const v4i (&acc)[4], c
         requant_values<ACT, SAT, 4>(accb, mp, zp_act, v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
-    } else {
+    } else {  // (a rolled loop: unrolled, these sixteen two-step requantisations size the whole kernel's registers -- conv_small.hip)
+        int32_t tmp[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int32_t t = 0;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                t = max(t, (int32_t)requant_u8(accb[r][j], 0, mval4[r], sval4[r], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP));
-            m[r] = t;
-        }
+            for (int j = 0; j < 4; ++j) tmp[4 * r + j] = accb[r][j];
+#pragma unroll 1
+        for (int idx = 0; idx < 16; ++idx)
+            tmp[idx] = (int32_t)requant_u8(tmp[idx], 0, mval4[idx >> 2], sval4[idx >> 2], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = max(max(tmp[4 * r], tmp[4 * r + 1]), max(tmp[4 * r + 2], tmp[4 * r + 3]));
     }
     return pack4_biased(m[0], m[1], m[2], m[3]);
 }
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                             packed = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
                         }
                     } else {  // some window of this wave may wrap (or odd shifts): the reference's order, bytes first, then the maximum
-                        packed = first_pool_exact_path<ACT, SAT>(acc, lo[mt], mp[mt], a.mval + chq[mt], a.sval + chq[mt], a.zp_act, pow2);
+                        packed = first_pool_exact_path<ACT, SAT>(acc, lo[mt], mp[mt], a.mval + chq[mt], a.sval + chq[mt], a.zp_act, FASTC ? true : pow2);
                     }
                     dpk[s][mt] = packed;
                     L0P_MARK_V(3 + 2 * s, packed);
