@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     // staging of one tile's image (and, for the workgroup's first tile, its A fragments behind the first image batch)
     auto stage = [&](int tile, auto with_a_c) {
         constexpr bool WITH_A = decltype(with_a_c)::value;
-        constexpr int UB = WITH_A ? WS3_UB : 4;  // later tiles stage with fewer loads in flight: the A fragments hold 144 VGPRs
+        constexpr int UB = WITH_A ? WS3_UB : 4;  // later tiles stage with fewer loads in flight: the A fragments hold 144 VGPRs (6 / 8 measured: no gain)
         const int p0 = tile * TP, p1 = min(p0 + TP, total_u);  // this tile's pixels (PM == 2: windows) [p0, p1)
 
         // ---- tile geometry: image rows [first - 1, last + 1] of the flattened (b, y) row space, columns -1 .. W
@@ -369,14 +369,20 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
                 }
             }
         } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
+            // (the sixteen two-step requantisations as a ROLLED loop over a private array: unrolled, this cold path took part in sizing the
+            // kernel's registers -- it sits at the 256-register limit, three of its instantiations with spills; see conv_small.hip)
+            int32_t tmp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmp[i] = acc[i];
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                const int cl = lw + 8 * (i >> 2) + 4 * kh + (i & 3);
+                tmp[i] = (int32_t)requant_u8(tmp[i] + __mul24(ldsDZ[cl], sx), 0, a.mval[f0 + cl], a.sval[f0 + cl], a.zp_act, ACT,
+                                             SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+            }
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
-                const int cl = lw + 8 * grp + 4 * kh, ch0 = f0 + cl;
-                int32_t v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = (int32_t)requant_u8(acc[grp * 4 + r] + __mul24(ldsDZ[cl + r], sx), 0, a.mval[ch0 + r], a.sval[ch0 + r],
-                                               a.zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+                const int32_t v[4] = {tmp[4 * grp], tmp[4 * grp + 1], tmp[4 * grp + 2], tmp[4 * grp + 3]};
                 uint32_t o = pack4_biased(v[0], v[1], v[2], v[3]);
                 if (a.res) o = shortcut4_biased(o, resv[grp], a.sc_ka, a.sc_kb, a.sc_k0);
                 if (cell >= 0) *reinterpret_cast<uint32_t *>(dst + 8 * grp) = o;
