@@ -37,6 +37,39 @@
                  "s"(sbase_ptr)                                                                                  \
                  : "memory")
 
+#ifdef MI355_ABLATE
+// per-wave shader-clock sums of conv_small_pool_kernel's phases (tools/small_phases.py): [0] image wait + barrier, [1] deferred stores + next
+// tile's DMA issue, [2] cell sums + barrier (VALU correction form), [3] lane geometry + box sums, [4] MFMA chains, [5] epilogues, [6] rest, [7] tiles
+__device__ long long g_sm_ph[4096][4][8];
+#define SMP_DECL long long smp[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long smt = __builtin_readcyclecounter()
+#define SMP_MARK(k)                                              \
+    do {                                                         \
+        asm volatile("" ::: "memory");                           \
+        const long long n_ = __builtin_readcyclecounter();       \
+        smp[k] += n_ - smt;                                      \
+        smt = n_;                                                \
+    } while (0)
+#define SMP_MARK_V(k, v)                                         \
+    do {                                                         \
+        asm volatile("s_nop 0" ::"v"(v));                        \
+        SMP_MARK(k);                                             \
+    } while (0)
+#define SMP_STORE()                                                                             \
+    do {                                                                                        \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                       \
+            for (int k = 0; k < 8; ++k) g_sm_ph[blockIdx.x][threadIdx.x >> 6][k] = smp[k];      \
+    } while (0)
+extern "C" int mi355_debug_read_smph(long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sm_ph), sizeof(long long) * 4096 * 4 * 8) == hipSuccess ? 0 : -5;
+}
+#else
+#define SMP_DECL do { } while (0)
+#define SMP_MARK(k) do { } while (0)
+#define SMP_MARK_V(k, v) do { } while (0)
+#define SMP_STORE() do { } while (0)
+#endif
+
 constexpr int SM_PPB = 128;  // pooled pixels per workgroup tile (4 waves x 32 lanes)
 constexpr int SM_GMAX = 8;    // conv_mid_pool_kernel: groups of 32 pooled pixels per tile (tile <= 256 pooled pixels)
 constexpr int SM_KMAX = 6;    // DMA instructions per wave and piece per tile image (image <= 4 * 6 * 64 cells)
@@ -318,12 +351,15 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
                 for (int grp = 0; grp < 4; ++grp) *reinterpret_cast<uint32_t *>(pk_outp + 32 * mt + 8 * grp + 4 * kh) = pk[mt][grp];
         }
     };
+    SMP_DECL;
     for (; tile < ntiles; tile += gridDim.x, parity ^= 1, cur = nxp) {
+        SMP_MARK(6);
         tile_geom(tile, cur, gr_first, col0, nrows);
         const char *X = smem + parity * bbytes;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the tile's image has landed (and the parameters, first time round); every wave is past the
                           // previous tile, so its buffer may be overwritten
+        SMP_MARK(0);
         flush_stores();
         advance(nxp);
         if (tile + gridDim.x < ntiles) {
@@ -332,6 +368,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
             issue_tile(g2, c2, n2, parity ^ 1);
         }
 
+        SMP_MARK(1);
         // ---- per-cell channel sums S (the receptive-field sum of x' is the 3x3 box sum of S)
         if (!DZM) for (int id = tid; id < nrows * ncell; id += 256) {
             int t = 0;
@@ -346,6 +383,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
             ldsS[id] = t;
         }
         if (!DZM) __syncthreads();
+        SMP_MARK(2);
 
         // ---- this lane's pooled pixel and its 2x2 window in the image
         int b, prow, pcol;
@@ -387,6 +425,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
         const size_t pcell = (size_t)a.pool_lead + ((size_t)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol;
         uint8_t *outp = a.ypool + pcell * a.pool_cs;
 
+        SMP_MARK_V(3, sx[3]);
 #pragma unroll
         for (int mt = 0; mt < NM; ++mt) {
             // accumulators start at cw + bias: register grp*4+r of a 32x32 tile is channel row 8*grp + 4*kh + r
@@ -425,6 +464,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
                     }
                 }
             __builtin_amdgcn_s_setprio(0);
+            SMP_MARK_V(4, acc[NJ - 1][15]);
             // ---- epilogue: window max, one requantisation per (pixel, channel), biased packed store
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
@@ -492,10 +532,16 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
                 }
             }
         }
+        SMP_MARK_V(5, pk[NM - 1][3]);
         pk_outp = outp;
+#ifdef MI355_ABLATE
+        smp[7] += 1;
+#endif
         pk_valid = valid && POOL;
     }
     flush_stores();
+    SMP_MARK(6);
+    SMP_STORE();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
