@@ -19,6 +19,9 @@
 //     + tap column dx = e -> slot offset (e & 1) * hc + (e >> 1).  The row pitch is chosen so that a wave's second pooled row
 //     (patches: 2 * pitch = 0 mod 16) or its wrap into the next pooled row (flat tiles: 2 * pitch = OW mod 16) continues the same
 //     sequence of 16-byte bank groups.
+//   * the A rows of a 32-filter m-tile are PERMUTED (ws_row_filter below, applied by mi355_conv_pack): the accumulator rows a lane holds,
+//     8 grp + 4 kh + r, are then the sixteen CONSECUTIVE filters 16 kh + 4 grp + r -- one 16-byte store per lane and m-tile instead of four
+//     4-byte ones (memory-instruction issue is 11-16 % of these kernels' time, tools/small_phases.py);
 //   * lane l of a wave owns pooled pixel 32*wave + l; the four 32-column MFMA sub-tiles of the wave are the four window
 //     positions, so the 2x2 window of every (pixel, channel) sits in ONE lane: the pool is three v_max_i32, no
 //     cross-lane traffic and no pre-pool tensor.
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
     bool need_d2 = false;
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt) {
-        const int dz = a.dzp[32 * mt + lj];
+        const int dz = a.dzp[32 * mt + ws_row_filter(lj)];  // (the lane's A row is filter ws_row_filter(lj) of the m-tile)
         const int d1 = dz > 127 ? 127 : dz, d2 = dz - d1;
         wd1[mt] = (int)((uint32_t)(d1 & 0xFF) * 0x01010101u);
         wd2[mt] = (int)((uint32_t)(d2 & 0xFF) * 0x01010101u);
@@ -347,8 +350,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
         if (pk_valid) {
 #pragma unroll
             for (int mt = 0; mt < NM; ++mt)
-#pragma unroll
-                for (int grp = 0; grp < 4; ++grp) *reinterpret_cast<uint32_t *>(pk_outp + 32 * mt + 8 * grp + 4 * kh) = pk[mt][grp];
+                *reinterpret_cast<uint4 *>(pk_outp + 32 * mt + 16 * kh) = uint4{pk[mt][0], pk[mt][1], pk[mt][2], pk[mt][3]};  // filters 16 kh .. + 15
         }
     };
     SMP_DECL;
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
             v16i acc[4];
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
-                const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + 32 * mt + 8 * grp + 4 * kh);
+                const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + 32 * mt + 16 * kh + 4 * grp);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     acc[j][grp * 4 + 0] = c4.x; acc[j][grp * 4 + 1] = c4.y;
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
             // ---- epilogue: window max, one requantisation per (pixel, channel), biased packed store
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
-                const int ch0 = 32 * mt + 8 * grp + 4 * kh;
+                const int ch0 = 32 * mt + 16 * kh + 4 * grp;  // accumulator rows 8 grp + 4 kh + r hold filters 16 kh + 4 grp + r (ws_row_filter)
                 const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
                 const int4 lo4 = *reinterpret_cast<const int4 *>(ldsLO + ch0);
                 const int4 hi4 = *reinterpret_cast<const int4 *>(ldsHI + ch0);
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         v16i acc[4];
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
-            const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + chw + 8 * grp + 4 * kh);
+            const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + chw + 16 * kh + 4 * grp);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 acc[j][grp * 4 + 0] = c4.x; acc[j][grp * 4 + 1] = c4.y;
@@ -760,9 +762,10 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
             if (s & 1) __builtin_amdgcn_sched_barrier(0);  // keep the B fragments of at most two K-steps live (registers)
         }
         __builtin_amdgcn_s_setprio(0);
+        uint32_t pk4[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
-            const int ch0 = chw + 8 * grp + 4 * kh;
+            const int ch0 = chw + 16 * kh + 4 * grp;  // (ws_row_filter)
             const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
             const int4 lo4 = *reinterpret_cast<const int4 *>(ldsLO + ch0);
             const int4 hi4 = *reinterpret_cast<const int4 *>(ldsHI + ch0);
@@ -785,9 +788,9 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ub[r][j] = (uint32_t)accb[r][j];
-                const uint32_t packed = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, m0v, shv, ldsMP + ch0, a.zp_act, pow2,
-                                                                           a.mval + ch0, a.sval + ch0);
-                if (pcell >= 0) *reinterpret_cast<uint32_t *>(a.ypool + (size_t)pcell * a.pool_cs + ch0) = packed;
+                pk4[grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, m0v, shv, ldsMP + ch0, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
+                if (grp == 3 && pcell >= 0)  // the lane's sixteen consecutive filters 16 kh .. + 15 (ws_row_filter): one store
+                    *reinterpret_cast<uint4 *>(a.ypool + (size_t)pcell * a.pool_cs + chw + 16 * kh) = uint4{pk4[0], pk4[1], pk4[2], pk4[3]};
             } else if constexpr (MODE == 2) {  // stride 2: window position 0 is the output pixel
                 int32_t a1[4][1], v1[4][1];
 #pragma unroll

@@ -121,6 +121,9 @@ int yolo_detections_launch(const float *out, int B, int n, int classes, int h, i
 int conv_igemm_launch(ConvArgs &a, hipStream_t st);
 int conv_rows_launch(ConvArgs &a, hipStream_t st, int bm, int bn);
 int conv_small_pool_launch(ConvArgs &a, hipStream_t st);
+// conv_small.hip's weights-stationary plane: A row R of a 32-filter m-tile holds filter ws_row_filter(R), so that the accumulator rows of
+// one lane (8 grp + 4 kh + r in the 32 x 32 MFMA's D layout) are sixteen consecutive filters 16 kh + 4 grp + r
+__host__ __device__ constexpr int ws_row_filter(int R) { return 16 * ((R >> 2) & 1) + 4 * (R >> 3) + (R & 3); }
 bool conv_small_eligible(int n, int c, int ksize);
 int conv1x1_ws_launch(ConvArgs &a, hipStream_t st);
 bool conv1x1_ws_eligible(int n, int c, int ksize);

@@ -454,7 +454,7 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
         for (int mt = 0; mt < n / 32; ++mt)
             for (int s = 0; s < kst; ++s)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int oc = 32 * mt + (lane & 31), khalf = lane >> 5;
+                    const int oc = 32 * mt + ws_row_filter(lane & 31), khalf = lane >> 5;  // (rows permuted: kargs.h)
                     // c 16: the k-half is the tap parity (tap 9: zeros); c 32: one tap per step; c 64: two steps per tap
                     const int tap = (c == 16) ? 2 * s + khalf : (c == 32 ? s : s / 2);
                     int8_t *dst = ws + ((size_t)(mt * kst + s) * 64 + lane) * 16;
