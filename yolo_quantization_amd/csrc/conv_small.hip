@@ -147,6 +147,25 @@ __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)
     return pack4_biased(m[0], m[1], m[2], m[3]);
 }
 
+// sixteen two-step requantisations (shift_value not a power of two: never produced by the reference's own preparation) as a ROLLED loop
+// over a private array -- unrolled, this cold path sizes the kernel's registers (see pool_requant_quad_biased)
+template <int ACT, bool SAT>
+__device__ __forceinline__ void requant16_two_step(const int32_t (&accb)[4][4], const double *mval4, const double *sval4, int zp_act, int32_t (&v)[4][4])
+{
+    int32_t tmp[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tmp[4 * r + j] = accb[r][j];
+#pragma unroll 1
+    for (int idx = 0; idx < 16; ++idx)
+        tmp[idx] = (int32_t)requant_u8(tmp[idx], 0, mval4[idx >> 2], sval4[idx >> 2], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[r][j] = tmp[4 * r + j];
+}
+
 // MODE 0: conv + 2x2/2 maxpool.  1: no pool, the four window positions of a lane are four output pixels.  2: stride-2
 // convolution = the stride-1 output at the even positions = window position 0 only (a quarter of the MFMAs), stored on the
 // pooled geometry (the output map of a stride-2 3x3 pad-1 convolution on an even map is the pooled map).
@@ -468,6 +487,8 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
             __builtin_amdgcn_s_setprio(0);
             SMP_MARK_V(4, acc[NJ - 1][15]);
             // ---- epilogue: window max, one requantisation per (pixel, channel), biased packed store
+            uint32_t po[POOL ? 1 : NJ][4];  // no-pool / stride-2 modes: the packed bytes of the four channel groups, stored together
+            (void)po;
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
                 const int ch0 = 32 * mt + 16 * kh + 4 * grp;  // accumulator rows 8 grp + 4 kh + r hold filters 16 kh + 4 grp + r (ws_row_filter)
@@ -507,9 +528,10 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
                             v1[r][0] = (int32_t)requant_u8(a1[r][0], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
                                                            SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
                     }
-                    if (valid)
-                        *reinterpret_cast<uint32_t *>(a.y + ((size_t)a.out_lead + ((size_t)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol) * a.out_cs + ch0) =
-                            pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
+                    po[0][grp] = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
+                    if (grp == 3 && valid)  // the lane's sixteen consecutive filters (ws_row_filter): one 16-byte store
+                        *reinterpret_cast<uint4 *>(a.y + ((size_t)a.out_lead + ((size_t)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol) * a.out_cs + 32 * mt + 16 * kh) =
+                            uint4{po[0][0], po[0][1], po[0][2], po[0][3]};
                 } else {
                     // no pool behind this layer (the 3x3 layers of the non-tiny nets' residual blocks): the four window
                     // positions of the lane are four output pixels, all sixteen values are requantised and stored
@@ -517,19 +539,15 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
                     if (pow2) {
                         requant_values<ACT, SAT, 4>(accb, mp, a.zp_act, v);
                     } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                v[r][j] = (int32_t)requant_u8(accb[r][j], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
-                                                              SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+                        requant16_two_step<ACT, SAT>(accb, a.mval + ch0, a.sval + ch0, a.zp_act, v);
                     }
-                    if (valid) {
-                        uint8_t *oy = a.y + ((size_t)a.out_lead + ((size_t)b * (a.H + 1) + (2 * prow + 1)) * W1 + 2 * pcol) * a.out_cs + ch0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) po[j][grp] = pack4_biased(v[0][j], v[1][j], v[2][j], v[3][j]);
+                    if (grp == 3 && valid) {  // four output pixels x the lane's sixteen consecutive filters (ws_row_filter): four 16-byte stores
+                        uint8_t *oy = a.y + ((size_t)a.out_lead + ((size_t)b * (a.H + 1) + (2 * prow + 1)) * W1 + 2 * pcol) * a.out_cs + 32 * mt + 16 * kh;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            *reinterpret_cast<uint32_t *>(oy + ((size_t)(j >> 1) * W1 + (j & 1)) * a.out_cs) =
-                                pack4_biased(v[0][j], v[1][j], v[2][j], v[3][j]);
+                            *reinterpret_cast<uint4 *>(oy + ((size_t)(j >> 1) * W1 + (j & 1)) * a.out_cs) = uint4{po[j][0], po[j][1], po[j][2], po[j][3]};
                     }
                 }
             }
@@ -763,6 +781,8 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         }
         __builtin_amdgcn_s_setprio(0);
         uint32_t pk4[4] = {0, 0, 0, 0};
+        uint32_t pj[POOL ? 1 : NJ][4];  // no-pool / stride-2 modes: packed bytes of the four channel groups, stored together
+        (void)pj; (void)pk4;
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
             const int ch0 = chw + 16 * kh + 4 * grp;  // (ws_row_filter)
@@ -803,25 +823,23 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
                         v1[r][0] = (int32_t)requant_u8(a1[r][0], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
                                                        SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
                 }
-                if (pcell >= 0)
-                    *reinterpret_cast<uint32_t *>(a.y + (size_t)pcell * a.out_cs + ch0) = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
+                pj[0][grp] = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
+                if (grp == 3 && pcell >= 0)
+                    *reinterpret_cast<uint4 *>(a.y + (size_t)pcell * a.out_cs + chw + 16 * kh) = uint4{pj[0][0], pj[0][1], pj[0][2], pj[0][3]};
             } else {  // no pool: four output pixels per lane, sixteen requantisations
                 int32_t v[4][4];
                 if (pow2) {
                     requant_values<ACT, SAT, 4>(accb, mp, a.zp_act, v);
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            v[r][j] = (int32_t)requant_u8(accb[r][j], 0, a.mval[ch0 + r], a.sval[ch0 + r], a.zp_act, ACT,
-                                                          SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+                    requant16_two_step<ACT, SAT>(accb, a.mval + ch0, a.sval + ch0, a.zp_act, v);
                 }
-                if (pcell >= 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pj[j][grp] = pack4_biased(v[0][j], v[1][j], v[2][j], v[3][j]);
+                if (grp == 3 && pcell >= 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        *reinterpret_cast<uint32_t *>(a.y + (size_t)(pcell + (j >> 1) * W1 + (j & 1)) * a.out_cs + ch0) =
-                            pack4_biased(v[0][j], v[1][j], v[2][j], v[3][j]);
+                        *reinterpret_cast<uint4 *>(a.y + (size_t)(pcell + (j >> 1) * W1 + (j & 1)) * a.out_cs + chw + 16 * kh) =
+                            uint4{pj[j][0], pj[j][1], pj[j][2], pj[j][3]};
                 }
             }
         }
