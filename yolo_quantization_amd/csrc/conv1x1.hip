@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(con
         v16i acc;
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
-            const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + chw + 8 * grp + 4 * kh);
+            const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + chw + 16 * kh + 4 * grp);  // accumulator rows 8 grp + 4 kh + r hold filters 16 kh + 4 grp + r (kargs.h ws_row_filter)
             acc[grp * 4 + 0] = c4.x; acc[grp * 4 + 1] = c4.y; acc[grp * 4 + 2] = c4.z; acc[grp * 4 + 3] = c4.w;
         }
         int sxr = 0;
@@ -142,9 +142,10 @@ __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(con
         const bool valid = ocell >= 0;
         const int b = ldsImg[g * 32 + lj], rem = ldsRem[g * 32 + lj];
         const int up = a.up;
+        uint32_t pk[4];  // the lane's sixteen consecutive filters 16 kh .. + 15 of its quad, stored together
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
-            const int ch0 = chw + 8 * grp + 4 * kh;
+            const int ch0 = chw + 16 * kh + 4 * grp;
             const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
             const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
             int32_t accb[4][1], v[4][1];
@@ -162,21 +163,26 @@ __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(con
                     v[r][0] = (int32_t)requant_u8(accb[r][0], 0, a.mval[f0 + ch0 + r], a.sval[f0 + ch0 + r], a.zp_act, ACT,
                                                   SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
             }
-            if (valid && f0 + ch0 < a.out_w) {
-                const uint32_t packed = pack4_biased(v[0][0], v[1][0], v[2][0], v[3][0]);
+            pk[grp] = pack4_biased(v[0][0], v[1][0], v[2][0], v[3][0]);
+            // (out_w is a multiple of 16: the lane's 16-byte run lies inside the cell or outside it as a whole)
+            if (grp == 3 && valid && f0 + chw + 16 * kh < a.out_w) {
+                const uint4 packed = {pk[0], pk[1], pk[2], pk[3]};
+                const size_t co = (size_t)(f0 + chw + 16 * kh);
 #ifdef MI355_ABLATE
                 if (a.debug & 1) {  // timing ablation: no stores (keep the value alive)
-                    if (packed == 0x12345678u) a.y[0] = 1;
+                    if (packed.x == 0x12345678u) a.y[0] = 1;
                 } else
 #endif
                 if (up == 1) {
-                    *reinterpret_cast<uint32_t *>(a.y + (size_t)ocell * a.out_cs + f0 + ch0) = packed;
+                    *reinterpret_cast<uint4 *>(a.y + (size_t)ocell * a.out_cs + co) = packed;
                 } else {
                     const int rowc = up * a.W + 1;
                     for (int uy = 0; uy < up; ++uy)
                         for (int ux = 0; ux < up; ++ux)
-                            *reinterpret_cast<uint32_t *>(a.y + (size_t)(ocell + uy * rowc + ux) * a.out_cs + f0 + ch0) = packed;
+                            *reinterpret_cast<uint4 *>(a.y + (size_t)(ocell + uy * rowc + ux) * a.out_cs + co) = packed;
                 }
+            }
+            if (valid && f0 + ch0 < a.out_w) {
                 if (a.y_f32 || a.yolo_out) {  // quant_stop tail (ref :752-760) and, fused, the yolo layer's activations (y_f32 may be
                                               // null then: the head's own float tensor is an intermediate nobody reads)
 #pragma unroll

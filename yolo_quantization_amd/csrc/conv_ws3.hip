@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     auto seed_bias = [&](v16i &acc) {
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
-            const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + lw + 8 * grp + 4 * kh);
+            const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + lw + 16 * kh + 4 * grp);  // rows 8 grp + 4 kh + r = filters 16 kh + 4 grp + r (kargs.h ws_row_filter)
             acc[grp * 4 + 0] = c4.x; acc[grp * 4 + 1] = c4.y; acc[grp * 4 + 2] = c4.z; acc[grp * 4 + 3] = c4.w;
         }
     };
@@ -320,23 +320,24 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
         const int sx = ldsSX[g * 32 + lj];
         const int cell = (PM && !a.y) ? -1 : ldsCell[g * 32 + lj];
         // (+ 32 B per quad: the slots are a multiple of 128 B apart, and the pool pass reads one pixel's 32 dwords of all quads at once)
-        char *pt = ldsPT + (size_t)((wset * NQ + wq) * gsmax + i) * a.sm_pt_stride + (wq & 3) * 32 + lj * 36 + 4 * kh;
-        uint8_t *dst = a.y + (size_t)(cell < 0 ? 0 : cell) * a.out_cs + f0 + lw + 4 * kh;
+        char *pt = ldsPT + (size_t)((wset * NQ + wq) * gsmax + i) * a.sm_pt_stride + (wq & 3) * 32 + lj * 36 + 16 * kh;
+        // the lane's sixteen consecutive filters 16 kh .. + 15 of its quad: one 16-byte store (and one 16-byte residual load) per group of pixels
+        uint8_t *dst = a.y + (size_t)(cell < 0 ? 0 : cell) * a.out_cs + f0 + lw + 16 * kh;
         // fused residual add: the `from` tensor's bytes of the same pixel and channels, fetched before the requantisation
         uint32_t resv[4] = {0, 0, 0, 0};
         if (a.res) {
-            const uint8_t *rp = a.res + (size_t)(cell < 0 ? 0 : cell + a.res_delta) * a.res_cs + f0 + lw + 4 * kh;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) resv[j] = *reinterpret_cast<const uint32_t *>(rp + 8 * j);
+            const uint4 r4 = *reinterpret_cast<const uint4 *>(a.res + (size_t)(cell < 0 ? 0 : cell + a.res_delta) * a.res_cs + f0 + lw + 16 * kh);
+            resv[0] = r4.x; resv[1] = r4.y; resv[2] = r4.z; resv[3] = r4.w;
         }
 #ifdef MI355_ABLATE
         if (a.debug & (1 << 18)) {  // timing ablation: stores only
             if (cell >= 0)
-                for (int grp = 0; grp < 4; ++grp) *reinterpret_cast<uint32_t *>(dst + 8 * grp) = acc[grp * 4] + sx;
+                for (int grp = 0; grp < 4; ++grp) *reinterpret_cast<uint32_t *>(dst + 4 * grp) = acc[grp * 4] + sx;
             return;
         }
         if (a.debug & (1 << 19)) return;  // timing ablation: no epilogue at all
 #endif
+        uint32_t o4[4];
         if (pow2) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {  // 8 channels per call: eight independent chains, one fallback ballot
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
                 double mp[8];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int grp = 2 * half + h, cl = lw + 8 * grp + 4 * kh;
+                    const int grp = 2 * half + h, cl = lw + 16 * kh + 4 * grp;
                     const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + cl);
                     const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
 #pragma unroll
@@ -359,14 +360,8 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
                     o0 = shortcut4_biased(o0, resv[2 * half], a.sc_ka, a.sc_kb, a.sc_k0);
                     o1 = shortcut4_biased(o1, resv[2 * half + 1], a.sc_ka, a.sc_kb, a.sc_k0);
                 }
-                if (cell >= 0) {
-                    *reinterpret_cast<uint32_t *>(dst + 16 * half) = o0;
-                    *reinterpret_cast<uint32_t *>(dst + 16 * half + 8) = o1;
-                }
-                if (PM) {
-                    *reinterpret_cast<uint32_t *>(pt + 16 * half) = o0;
-                    *reinterpret_cast<uint32_t *>(pt + 16 * half + 8) = o1;
-                }
+                o4[2 * half] = o0;
+                o4[2 * half + 1] = o1;
             }
         } else {  // shift_value not a power of two: the reference's two-step form (never produced by its own prep)
             // (the sixteen two-step requantisations as a ROLLED loop over a private array: unrolled, this cold path took part in sizing the
@@ -376,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
             for (int i = 0; i < 16; ++i) tmp[i] = acc[i];
 #pragma unroll 1
             for (int i = 0; i < 16; ++i) {
-                const int cl = lw + 8 * (i >> 2) + 4 * kh + (i & 3);
+                const int cl = lw + 16 * kh + i;  // group i >> 2, channel i & 3 of it
                 tmp[i] = (int32_t)requant_u8(tmp[i] + __mul24(ldsDZ[cl], sx), 0, a.mval[f0 + cl], a.sval[f0 + cl], a.zp_act, ACT,
                                              SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
             }
@@ -385,9 +380,13 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
                 const int32_t v[4] = {tmp[4 * grp], tmp[4 * grp + 1], tmp[4 * grp + 2], tmp[4 * grp + 3]};
                 uint32_t o = pack4_biased(v[0], v[1], v[2], v[3]);
                 if (a.res) o = shortcut4_biased(o, resv[grp], a.sc_ka, a.sc_kb, a.sc_k0);
-                if (cell >= 0) *reinterpret_cast<uint32_t *>(dst + 8 * grp) = o;
-                if (PM) *reinterpret_cast<uint32_t *>(pt + 8 * grp) = o;
+                o4[grp] = o;
             }
+        }
+        if (cell >= 0) *reinterpret_cast<uint4 *>(dst) = uint4{o4[0], o4[1], o4[2], o4[3]};
+        if (PM) {
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) *reinterpret_cast<uint32_t *>(pt + 4 * grp) = o4[grp];
         }
     };
     if (KP == 1) {

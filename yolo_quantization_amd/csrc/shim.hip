@@ -427,7 +427,7 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
         for (int q = 0; q < (n + 31) / 32; ++q)
             for (int s = 0; s < kst; ++s)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int oc = 32 * q + (lane & 31), khalf = lane >> 5;
+                    const int oc = 32 * q + ws_row_filter(lane & 31), khalf = lane >> 5;  // (rows permuted: kargs.h)
                     int8_t *dst = ws + ((size_t)(q * kst + s) * 64 + lane) * 16;
                     for (int e = 0; e < 16; ++e)
                         dst[e] = oc < n ? (int8_t)(wq[(size_t)oc * K + 32 * s + 16 * khalf + e] ^ 0x80) : 0;
@@ -440,7 +440,7 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
             for (int kp = 0; kp < kparts; ++kp)
                 for (int s = 0; s < 36; ++s)
                     for (int lane = 0; lane < 64; ++lane) {
-                        const int oc = 32 * q + (lane & 31), khalf = lane >> 5, tap = s >> 2;
+                        const int oc = 32 * q + ws_row_filter(lane & 31), khalf = lane >> 5, tap = s >> 2;  // (rows permuted: kargs.h)
                         int8_t *dst = ws + ((size_t)((q * kparts + kp) * 36 + s) * 64 + lane) * 16;
                         for (int e = 0; e < 16; ++e) {
                             const int ci = 128 * kp + 32 * (s & 3) + 16 * khalf + e;
