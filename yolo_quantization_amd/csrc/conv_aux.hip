@@ -732,7 +732,10 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
     double mp[NM][4];
 #pragma unroll
     for (int mt = 0; mt < NM; ++mt) {
-        const int ch = 16 * mt + pc;
+        // With two m-tiles (32 filters) the A rows are dealt so that a lane's accumulator rows 4 g + r of BOTH tiles are eight consecutive
+        // filters 8 g + 4 mt + r: one 8-byte store per output pixel instead of two 4-byte ones (the kernel's stores are its bottleneck, and
+        // what they cost is their issue: DESIGN.md 4.5).  The weights are read by filter index here, so nothing changes at pack time.
+        const int ch = NM == 2 ? 8 * (pc >> 2) + 4 * mt + (pc & 3) : 16 * mt + pc;
         const int dz = a.dzp[ch];
         const int d1 = dz > 127 ? 127 : dz, d2 = dz - d1;  // dz in [-127, 128]
         const uint32_t m1 = (uint32_t)(d1 & 0xFF) * 0x00010101u, m2 = (uint32_t)(d2 & 0xFF) * 0x00010101u;
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
             wd1[mt][dx] = real ? (int)m1 : 0;
             wd2[mt][dx] = real ? (int)m2 : 0;
         }
-        chq[mt] = 16 * mt + 4 * g;
+        chq[mt] = NM == 2 ? 8 * g + 4 * mt : 16 * mt + 4 * g;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c2 = chq[mt] + r;
@@ -874,6 +877,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
             // wave-uniform part of the output cells (scalar arithmetic) + the lane's column (precomputed byte offset)
             const long rowcell = (long)a.out_lead + ((long)b * (a.H + 1) + (2 * prow + 1)) * W1 + 32 * tx;
             uint8_t *outp = a.y + rowcell * a.out_cs + pc_off;
+            uint32_t pkj[NM][4];
 #pragma unroll
             for (int mt = 0; mt < NM; ++mt) {
                 v4i acc[4];
@@ -907,19 +911,34 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
                     for (int j = 0; j < 4; ++j) accb[r][j] = acc[j][r];
                 if (pow2) {
                     requant_values<ACT, SAT, 4>(accb, mp[mt], a.zp_act, v);
-                } else {
+                } else {  // (rolled: unrolled, this cold two-step form takes part in sizing the kernel's registers)
+                    int32_t tmp[16];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            v[r][j] = (int32_t)requant_u8(accb[r][j], 0, a.mval[chq[mt] + r], a.sval[chq[mt] + r], a.zp_act, ACT,
-                                                          SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
-                }
-                if (valid) {
+                        for (int j = 0; j < 4; ++j) tmp[4 * r + j] = accb[r][j];
+#pragma unroll 1
+                    for (int idx = 0; idx < 16; ++idx)
+                        tmp[idx] = (int32_t)requant_u8(tmp[idx], 0, a.mval[chq[mt] + (idx >> 2)], a.sval[chq[mt] + (idx >> 2)], a.zp_act, ACT,
+                                                       SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        *reinterpret_cast<uint32_t *>(outp + ((size_t)(j >> 1) * W1 + (j & 1)) * a.out_cs + chq[mt]) =
-                            pack4_biased(v[0][j], v[1][j], v[2][j], v[3][j]);
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[r][j] = tmp[4 * r + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pkj[mt][j] = pack4_biased(v[0][j], v[1][j], v[2][j], v[3][j]);
+            }
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint8_t *o = outp + ((size_t)(j >> 1) * W1 + (j & 1)) * a.out_cs;
+                    if constexpr (NM == 2) {
+                        *reinterpret_cast<uint2 *>(o + 8 * g) = uint2{pkj[0][j], pkj[1][j]};
+                    } else {
+#pragma unroll
+                        for (int mt = 0; mt < NM; ++mt) *reinterpret_cast<uint32_t *>(o + chq[mt]) = pkj[mt][j];
+                    }
                 }
             }
         }
