@@ -135,6 +135,14 @@ int mi355_tensor_to_nchw(const mi355_tensor *t, uint8_t *nchw, void *stream);
 size_t mi355_conv_pack_size(int n, int c, int ksize);
 int mi355_conv_pack(int n, int c, int ksize, const uint8_t *weights_uint8, const uint8_t *zp_w,
                     const int32_t *biases_int32, const double *M_value, const double *shift_value, void *blob);
+/* Optional second packing step, on the same HOST blob before it is uploaded: the per-channel constants of the requantise
+ * epilogue (ref: src/convolutional_layer.c:726-751) that the fused conv + maxpool kernels need for ONE (activation, zero
+ * point) -- the range of accumulators whose stored byte cannot wrap (:737-749, where max-pooling commutes with the
+ * requantisation) and the integer form M0 / shift of M_value (ref: src/blas.c:387-418).  Without it (or when a launch's
+ * activation / zp_act differ from the packed ones, or the store saturates) every workgroup derives them itself: same bytes,
+ * a quarter to a third of the first layer's run time.  RELU is stored as LINEAR (the reference's integer
+ * path treats them alike, :740-742). */
+int mi355_conv_pack_epilogue(int n, int c, int ksize, int activation, int zp_act, void *blob);
 
 typedef struct mi355_conv_desc {
     int n, c, ksize, stride, pad; /* filters, input channels, 1|3, 1|2, ksize/2 (stride 2: plain exact-mode convs, c % 16 == 0) */

@@ -135,6 +135,8 @@ void mi355_bind_network(network *net, int gpu, int accum_mode, int store_mode)
             void *host = malloc(sz);
             chk(mi355_conv_pack(l->n, l->c, l->size, l->weights_uint8, l->weight_data_uint8_zero_point, l->biases_int32,
                                 l->M_value, l->M0_right_shift_value, host), "mi355_conv_pack");
+            chk(mi355_conv_pack_epilogue(l->n, l->c, l->size, l->activation, l->activ_data_uint8_zero_point[0], host),
+                "mi355_conv_pack_epilogue");
             chk(mi355_alloc(&s->blob, sz), "alloc blob");
             chk(mi355_h2d(s->blob, host, sz, G.stream), "upload blob");
             chk(mi355_stream_sync(G.stream), "sync");

@@ -385,9 +385,11 @@ def test_layout_roundtrip_and_pads():
 @pytest.mark.parametrize("c,n,H,W,act", [(3, 16, 20, 36, "leaky"), (16, 32, 24, 40, "leaky"), (32, 64, 16, 16, "relu6"),
                                          (48, 32, 10, 34, "linear"), (3, 32, 34, 70, "relu6"), (3, 16, 18, 30, "linear")])
 @pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
-def test_conv_fused_maxpool_equals_conv_then_pool(c, n, H, W, act, store):
+@pytest.mark.parametrize("ept", [False, True], ids=["derive-in-kernel", "epilogue-table"])
+def test_conv_fused_maxpool_equals_conv_then_pool(c, n, H, W, act, store, ept):
     """mi355_conv_pool_forward == conv + requant + 2x2/2 maxpool of the oracle (pre-pool tensor too), including
-    wrap-on-store values inside pooling windows (max is taken AFTER the uint8 wrap, as the reference does)."""
+    wrap-on-store values inside pooling windows (max is taken AFTER the uint8 wrap, as the reference does).
+    ept: the blob carries the host-derived epilogue table (mi355_conv_pack_epilogue) or the workgroups derive it."""
     import ctypes as C
     rng = np.random.default_rng(c * 100 + n + H)
     B = 3
@@ -395,7 +397,7 @@ def test_conv_fused_maxpool_equals_conv_then_pool(c, n, H, W, act, store):
     wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3, 2.0 ** -9 if c == 3 else 2.0 ** -11, 2.0 ** -6 if c == 3 else 2.0 ** -7)
     zp_in, zp_act = 9, 23
     xt = binding.DevTensor.from_nchw(x, zp_in)
-    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv))
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv, *((binding.ACT[act], zp_act) if ept else ())))
     y = binding.DevTensor(B, H, W, n, zp_act)
     yp = binding.DevTensor(B, H // 2, W // 2, n, zp_act)
     d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT[act], store, binding.ACC_EXACT, zp_in, zp_act, 1.0)
@@ -417,7 +419,8 @@ def test_conv_fused_maxpool_equals_conv_then_pool(c, n, H, W, act, store):
                                          (64, 128, 6, 6, "leaky")])
 @pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
 @pytest.mark.parametrize("gain", ["no-wrap", "some-wrap", "much-wrap"])
-def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain):
+@pytest.mark.parametrize("ept", [False, True], ids=["derive-in-kernel", "epilogue-table"])
+def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain, ept):
     """The weights-stationary few-channel kernels (conv_small.hip: 3x3, c 16|32 with n 32|64, c 64 with n 64..128 split
     over the waves; pooled output only).  It requantises only the maximum accumulator of a 2x2 window when no accumulator of the window can
     wrap on store, and falls back to the reference's order (wrap, then max) per wave otherwise: all three regimes --
@@ -436,7 +439,8 @@ def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain):
         bias = (bias // 16).astype(np.int32)
     zp_in, zp_act = 9, (23 if act != "linear" else 128)
     xt = binding.DevTensor.from_nchw(x, zp_in)
-    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv))
+    # (ept with a zero point other than the launch's: the key does not match and the kernel must derive the constants itself)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv, *((binding.ACT[act], zp_act if n != 96 else zp_act + 1) if ept else ())))
     yp = binding.DevTensor(B, H // 2, W // 2, n, zp_act)
     d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT[act], store, binding.ACC_EXACT, zp_in, zp_act, 1.0)
     binding.check(binding.shim().mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, None, yp.ref(), None), "conv_pool")

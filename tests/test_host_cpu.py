@@ -358,3 +358,74 @@ net.replica()   # not prepared: error()
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 255, (r.returncode, r.stderr[-500:])
     assert "darknet_q: network_replica: the parent network is not prepared" in r.stderr
+
+
+@pytest.mark.parametrize("n,c,act", [(16, 3, "leaky"), (32, 16, "leaky"), (64, 32, "relu6"), (128, 64, "linear"), (32, 3, "relu6"), (64, 16, "relu")])
+def test_pack_epilogue_table(n, c, act):
+    """mi355_conv_pack_epilogue (host side of the C-ABI, no GPU): per channel the table's range [lb, lb + rg] must be wrap-safe under the
+    oracle's requantisation (ref src/convolutional_layer.c:726-751), and wherever it offers the integer form (m0 != 0) that form must equal the
+    FP64 one over the whole range -- checked at both ends, around zero and on random accumulators, over multipliers / shifts that straddle
+    intrq_make's accept / reject conditions (large shifts, few and many trailing zero bits of M0, tiny M)."""
+    rng = np.random.default_rng(n + c)
+    K = c * 9
+    wq = rng.integers(0, 256, (n, K), dtype=np.uint8)
+    zp_w = rng.integers(0, 256, n, dtype=np.uint8)
+    bias = rng.integers(-5000, 5000, n).astype(np.int32)
+    # M_value = M0 * 2^-31 with M0 in [2^30, 2^31): as the reference builds it from a float (>= 7 trailing zeros), plus odd M0s
+    m0s = rng.integers(1 << 30, (1 << 31) - 1, n, dtype=np.int64)
+    m0s[::2] &= ~np.int64(0x7F)
+    m0s[1::4] = (m0s[1::4] >> 20) << 20
+    mv = m0s.astype(np.float64) * 2.0 ** -31
+    s = rng.integers(1, 20, n)
+    s[:4] = [1, 2, 30, 31]
+    sv = 2.0 ** -s.astype(np.float64)
+    zp_act = 23 if act != "linear" else 128
+    blob = binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv, binding.ACT[act], zp_act)
+    off_ept = int(np.frombuffer(blob, np.uint64, 1, 144)[0])
+    total = int(np.frombuffer(blob, np.uint64, 1, 96)[0])
+    assert off_ept and total == blob.size
+    mpad = int(np.frombuffer(blob, np.int32, 1, 16)[0])
+    key, flags = [int(v) for v in np.frombuffer(blob, np.uint32, 2, off_ept)]
+    kact = binding.ACT["linear"] if act == "relu" else binding.ACT[act]
+    assert key == (0x45500000 | (kact << 8) | zp_act)
+    ent = np.frombuffer(blob, np.int32, mpad * 8, off_ept + 16).reshape(mpad, 8)
+    oact = oracle.ACT[act]
+    accepted = 0
+    for ch in range(n):
+        lb = int(ent[ch, 0]); rg = int(np.uint32(ent[ch, 1])); m0 = int(ent[ch, 2]); sh = int(ent[ch, 3])
+        qc = int(np.frombuffer(ent[ch, 4:6].tobytes(), np.int64)[0]); cbl = int(ent[ch, 6])
+        assert qc == lb * m0
+        hi = lb + rg
+        assert -(1 << 30) <= lb and hi < (1 << 30)
+        cand = np.unique(np.clip(np.concatenate([[lb, lb + 1, hi - 1, hi, -1, 0, 1], rng.integers(lb, hi + 1, 400)]), lb, hi)).astype(np.int64)
+        # accumulators as the kernel sees them: cw + bias + sum; the oracle adds `bias` itself, so feed acc = a - bias
+        acc = (cand - int(bias[ch])).astype(np.int64)
+        ok = np.abs(acc) < (1 << 31)
+        cand, acc = cand[ok], acc[ok].astype(np.int32).reshape(1, -1)
+        one = lambda arr: np.ascontiguousarray(arr[ch:ch + 1])
+        wrap = oracle.requant(acc, one(bias), one(mv), one(sv), zp_act, oact, oracle.STORE_WRAP)
+        sat = oracle.requant(acc, one(bias), one(mv), one(sv), zp_act, oact, oracle.STORE_SATURATE)
+        if not (flags & 1):
+            assert np.array_equal(wrap, sat), f"channel {ch}: a byte inside the table's range wraps"
+        if m0:
+            accepted += 1
+            assert m0 == int(m0s[ch]) and sh == int(s[ch]) - 1
+            # the integer form: f = floor(a * M0 / 2^(32 + sh)); q = trunc(fl(a * M_value) * 2^-s) in FP64
+            for a in cand.tolist():
+                if act == "relu6" and a < 0:
+                    assert (a * m0) >> (32 + sh) < 0  # only the sign matters below zero (neg_any)
+                    continue
+                f = (a * m0) >> (32 + sh)
+                q = int(np.trunc(np.float64(a) * mv[ch] * sv[ch]))
+                assert q == (f + 1 if (a < 0 and (a * m0) % (1 << (32 + sh))) else f), (ch, a)
+    assert bool(flags & 2) == (accepted < n)
+    if c == 3 and act == "leaky":  # the first layer's byte table: entry i <-> f (all channels integer) or q = i - 3072
+        lut = np.frombuffer(blob, np.uint8, 4096, off_ept + 16 + 32 * mpad)
+        for i in (0, 1, 3000, 3071, 3072, 3073, 3300, 4095):
+            v = i - 3072
+            q = v + 1 if (v < 0 and not (flags & 2)) else v
+            want = (zp_act + (q if q >= 0 else -((-q + 5) // 10))) & 0xFF
+            assert lut[i] == want ^ 0x80
+    # a blob packed without the second step carries no key
+    plain = binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv)
+    assert int(np.frombuffer(plain, np.uint32, 1, off_ept)[0]) == 0

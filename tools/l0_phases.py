@@ -34,16 +34,17 @@ for _ in range(20):
 for nk in nets:
     nk.sync()
 S = binding.shim()
-ph = np.zeros((4096, 4, 10), np.int64)
+ph = np.zeros((4096, 4, 12), np.int64)
 S.mi355_debug_read_l0ph.argtypes = [C.c_void_p]
 assert S.mi355_debug_read_l0ph(ph.ctypes.data) == 0
 nb = int((ph[:, 0, 7] > 0).sum())
 w = ph[:nb].astype(np.float64)
 tiles = w[:, :, 7].mean()
-tot = (w[:, :, :7].sum(axis=2) + w[:, :, 8:].sum(axis=2)).mean()
+tot = (w[:, :, :7].sum(axis=2) + w[:, :, 8:10].sum(axis=2)).mean()
 names = ["barrier", "deferred stores + prefetch issue", "row 0: B reads + MFMA chain", "row 0: epilogue", "row 1: B reads + MFMA chain",
          "row 1: epilogue", "bookkeeping + loop", None, "wait: prefetch + deferred stores landed", "staging: permutes + LDS writes"]
 print(f"workgroups {nb}, tiles per workgroup {tiles:.1f}, shader clocks per wave {tot:.0f} = {tot / tiles:.0f} per tile ({a.inflight} in flight)")
+print(f"  prologue (kernel entry -> tile loop) {w[:, :, 10].mean():.0f} clocks per wave; whole wave {w[:, :, 11].mean():.0f} clocks; tile loop share {100 * tot / w[:, :, 11].mean():.1f} %")
 for k, nm in enumerate(names):
     if nm is None:
         continue

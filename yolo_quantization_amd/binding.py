@@ -75,6 +75,8 @@ def shim():
         L.mi355_conv_pack_size.restype = sz
         L.mi355_conv_pack_size.argtypes = [ci, ci, ci]
         L.mi355_conv_pack.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        if hasattr(L, "mi355_conv_pack_epilogue"):  # (absent from older A/B builds under build_ab/; conv_pack(..., activation) then raises)
+            L.mi355_conv_pack_epilogue.argtypes = [ci, ci, ci, ci, ci, vp]
         L.mi355_conv_forward.argtypes = [C.POINTER(ConvDesc), C.POINTER(Tensor), vp, vp, vp, C.POINTER(Tensor), vp, vp, vp]
         L.mi355_conv_set_tile.argtypes = [ci, ci]
         L.mi355_conv_pool_forward.argtypes = [C.POINTER(ConvDesc), C.POINTER(Tensor), vp, C.POINTER(Tensor), C.POINTER(Tensor), vp]
@@ -175,8 +177,9 @@ class DevTensor:
         return C.byref(self.t)
 
 
-def conv_pack(wq, zp_w, c, ksize, biases_int32, M_value, shift_value):
-    """Host-side packing -> numpy uint8 blob."""
+def conv_pack(wq, zp_w, c, ksize, biases_int32, M_value, shift_value, activation=None, zp_act=None):
+    """Host-side packing -> numpy uint8 blob.  With activation / zp_act the blob also gets the conv + maxpool kernels' epilogue
+    table (mi355_conv_pack_epilogue); without, those kernels derive the constants per workgroup (same bytes)."""
     wq = np.ascontiguousarray(wq, np.uint8)
     n = wq.shape[0]
     sz = shim().mi355_conv_pack_size(n, c, ksize)
@@ -189,6 +192,8 @@ def conv_pack(wq, zp_w, c, ksize, biases_int32, M_value, shift_value):
     sv = np.ascontiguousarray(shift_value, np.float64)
     check(shim().mi355_conv_pack(n, c, ksize, wq.ctypes.data, zp_w.ctypes.data, b.ctypes.data, mv.ctypes.data,
                                  sv.ctypes.data, blob.ctypes.data), "conv_pack")
+    if activation is not None:
+        check(shim().mi355_conv_pack_epilogue(n, c, ksize, int(activation), int(zp_act), blob.ctypes.data), "conv_pack_epilogue")
     return blob
 
 

@@ -35,7 +35,54 @@ struct ConvBlobHeader {
     uint64_t off_ws;     // conv_small.hip shapes only (3x3, c 16|32 with n 32|64, c 64 with n 64..128), else 0: A fragments of
                          // every K-step in MFMA lane order, [n/32][k-step][64 lanes][16 B] (c 16: 5 steps of two taps;
                          // c 32: 9 taps; c 64: 18 steps, two per tap)
+    uint64_t off_ept;    // EptHeader + EptEntry[mpad] (+ the first layer's 4 KiB LEAKY byte table): the pooled kernels' per-channel epilogue
+                         // constants for ONE (activation, zero point), written by mi355_conv_pack_epilogue; key 0 = not prepared
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// Epilogue table (round 5).  The conv + maxpool kernels (conv_first_mfma_pool, conv_small_pool, conv_mid_pool) requantise a window's
+// MAXIMUM when no byte of the window can wrap; the per-channel constants of that test and of the integer requantisation -- the wrap-safe
+// accumulator range (small_safe_range, biased_safe_range), M0 and shift (intrq_make) -- depend on the layer's multipliers, activation and
+// zero point only.  Rounds 2-4 derived them in every workgroup's prologue (FP64 divisions, verification loops, 64-bit products: measured
+// at 26-36 % of the first layer's run time, tools/l0_phases.py); mi355_conv_pack_epilogue derives them ONCE on the host with the same
+// functions (below: __host__ __device__) and the kernels load 32 bytes per channel.  A blob whose key does not match the launch's
+// (activation, zero point) -- mi355_conv_pack alone, or a saturating store -- takes the in-kernel derivation: same bytes either way,
+// because ANY sub-range of the true safe range is safe (it only decides which windows take the exact path).
+// ---------------------------------------------------------------------------------------------------------
+struct EptHeader {
+    uint32_t key;        // ept_key(activation, zp_act), 0 = not prepared
+    uint32_t flags;      // EPT_NEVER: some channel has no wrap-safe range;  EPT_NOINT: some channel fails the integer form's conditions (or !pow2)
+    uint32_t pad_[2];
+};
+struct EptEntry {        // 32 bytes per channel, WRAP store
+    int32_t lb;          // lower end of the (clamped) wrap-safe range: accumulators are kept biased by it
+    uint32_t rg;         // its width
+    int32_t m0, sh;      // integer requantisation: f = mulhi(a, m0) >> sh  (0, 0 when the channel does not qualify)
+    int64_t qc;          // lb * m0 (first layer: u * m0 + qc = a * m0 in one v_mad_u64_u32)
+    int32_t cbl;         // cw + bias - lb: the biased accumulator's seed
+    int32_t pad_;
+};
+#define EPT_NEVER 1u
+#define EPT_NOINT 2u
+#define EPT_POW2 4u      // the header's pow2 flag, repeated here so that the kernels' prologue reads one place
+#define EPT_D2 8u        // first layer: some channel's zero-point correction is 128 (a third MFMA round)
+// First-layer blobs carry, behind the entries and the 4 KiB LEAKY byte table, the kernel's whole per-lane state in MFMA lane order -- one
+// 256-byte record per (m-tile, lane): the prologue of conv_first_mfma_pool_kernel is then sixteen independent 16-byte loads from ONE
+// address instead of dependent loads of zero points, weights, multipliers and entries with their selects (the kernel starts 1 024
+// workgroups at once and nothing runs beside their prologues).  Lane (pc = lane & 15, g = lane >> 4): A row = channel 16 mt + pc,
+// k-group g; accumulator rows = channels 16 mt + 4 g + r.
+struct L0Lane {
+    int32_t wa[2][4];    // weights w' = w - 128 of window column jx = 0 / 1 (shifted by one cell), zero outside the 3 x 3 x 3 taps
+    int32_t wd1[2][4];   // the zero-point correction's constant min(dz, 127) in every real k slot
+    int32_t wd2[2][4];   // ... and dz - 127 (non-zero only for dz = 128)
+    int32_t cb[4], lo[4], hi[4];   // EptEntry cbl, lb, rg of the lane's four channels
+    int32_t qm0[4], qsh[4];
+    int64_t qc[4];
+    double mp[4];        // folded multiplier M_value * shift_value
+    int32_t pad_[4];
+};
+static_assert(sizeof(L0Lane) == 256, "L0Lane is one 256-byte record");
+__host__ __device__ inline uint32_t ept_key(int act, int zp_act) { return 0x45500000u | ((uint32_t)(act & 0xFF) << 8) | (uint32_t)(zp_act & 0xFF); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Requantise epilogue: ref src/convolutional_layer.c:726-751.  FP64 with two truncations, activation, zero point,
@@ -75,7 +122,7 @@ __device__ __forceinline__ uint32_t requant_u8(int32_t acc, int32_t bias, double
 // (exhaustively verified); the division uses a 24-bit multiply when |q| + 5 < 2^16 and v_mul_hi otherwise.
 // (An FP32 estimate of q with an FP64 fallback for lanes near an integer boundary was tried and measured slower than
 // this single FP64 multiply: the epilogue is bound by instruction count, not by the FP64 rate -- profiles/r01 notes.)
-__device__ __forceinline__ int32_t requant_q_exact(int32_t accb, double Mp) { return (int32_t)((double)accb * Mp); }
+__host__ __device__ __forceinline__ int32_t requant_q_exact(int32_t accb, double Mp) { return (int32_t)((double)accb * Mp); }
 // Stage 2: activation, zero point, store mode (compile-time), uint8 wrap.
 template <int ACT, bool SAT>
 __device__ __forceinline__ uint32_t requant_finish(int32_t q, int zp_act)
@@ -210,7 +257,7 @@ __device__ __forceinline__ void requant_values_mp(const int32_t (&accb)[NV], con
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LUTQ_OFF = 3072, LUTQ_N = 4096;
 template <bool SAT>
-__device__ __forceinline__ uint32_t leaky_byte_biased(int32_t q, int zp_act)
+__host__ __device__ __forceinline__ uint32_t leaky_byte_biased(int32_t q, int zp_act)
 {
     const uint32_t x = (0u - (uint32_t)q) + 5u;
     int32_t v = q < 0 ? zp_act - (int32_t)(x / 10u) : q + zp_act;
@@ -243,7 +290,7 @@ __device__ __forceinline__ void leaky_lut_build(uint8_t *lut, int zp_act, int ti
 // neg_any (RELU / RELU6): every negative accumulator is stored as the zero point whatever its q -- zp + max(f, 0) only needs f < 0 there, which
 // floor(a * M0 / 2^(31+s)) is for every a < 0 -- so the conditions apply to the non-negative end of the range only.  (Without this a RELU6
 // layer never qualified: its wrap-safe range reaches down to the clamp at -2^30, and 2^30 * M0 is far beyond 2^53.)
-__device__ __forceinline__ bool intrq_make(double mval, int s, int32_t lo, int32_t hi, int32_t &m0, int32_t &sh, bool neg_any = false)
+__host__ __device__ __forceinline__ bool intrq_make(double mval, int s, int32_t lo, int32_t hi, int32_t &m0, int32_t &sh, bool neg_any = false)
 {
     m0 = 0; sh = 0;
     if (!(mval > 0.0 && mval < 1.0) || s < 1 || s > 31) return false;
@@ -253,8 +300,10 @@ __device__ __forceinline__ bool intrq_make(double mval, int s, int32_t lo, int32
     if (neg_any && lo < 0) lo = 0;
     if (hi < lo) hi = lo;
     const long amax = (-(long)lo > (long)hi) ? -(long)lo : (long)hi;
-    if (amax < 0 || (unsigned long)amax * (unsigned long)m >= (1ul << 53)) return false;  // FP64 product not provably exact
+    // the FP64 product a * M_value = a * (m >> tz) * 2^(tz - 31) is exact when a * (m >> tz) has at most 53 significant bits (m = round(float * 2^31)
+    // carries >= 7 trailing zeros: the plain a * m < 2^53 rejected channels that are exact and sent their launches down the slow path)
     const int tz = __builtin_ctz((unsigned)m);
+    if (amax < 0 || amax >= (1l << 31) || (unsigned long)amax * (unsigned long)((unsigned)m >> tz) >= (1ul << 53)) return false;  // FP64 product not provably exact
     const int e = 31 + s - tz;   // a * M0 % 2^(31+s) == 0  <=>  a % 2^e == 0
     if (e < 40 && lo < 0 && -(long)lo >= (1l << e)) return false;  // a negative exact multiple inside the range
     m0 = m; sh = s - 1;
@@ -275,7 +324,7 @@ __device__ __forceinline__ void leaky_lutf_build(uint8_t *lut, int zp_act, int t
         reinterpret_cast<uint32_t *>(lut)[i] = w;
     }
 }
-// LEAKY on the floor form, branch free in four VALU instructions, for -65 545 <= f <= 40 000 (always true for window maxima inside the
+// LEAKY on the floor form, branch free in four VALU instructions, for -40 900 <= f <= 40 000 (the int32 product f * 52428 + k; always true for window maxima inside the
 // wrap-safe range: -10 zp - 6 <= f <= 255):  with q = f + (f < 0),
 //     q < 0:  round(q * 0.1) = -((|q| + 5) / 10) = floor((q + 4) / 10) = floor((f + 5) / 10) = ((f + 5) * 52428) >> 19      (arithmetic shift)
 //     q >= 0: q = f
@@ -298,7 +347,7 @@ __device__ __forceinline__ uint32_t pack4_bytes(uint32_t b0, uint32_t b1, uint32
 // ---------------------------------------------------------------------------------------------------------
 // activation + zero point of a requantised value, unwrapped (the byte is this & 0xFF or its clamp)
 template <int ACT>
-__device__ __forceinline__ long small_v_of(int32_t accb, double mp, int zp)
+__host__ __device__ __forceinline__ long small_v_of(int32_t accb, double mp, int zp)
 {
     const int32_t q = requant_q_exact(accb, mp);
     if (ACT == MI355_ACT_LEAKY) {
@@ -313,7 +362,7 @@ __device__ __forceinline__ long small_v_of(int32_t accb, double mp, int zp)
 // [lo, hi]: accumulators (incl. bias and zero-point terms) whose stored byte does not wrap.  Any sub-range of the true
 // one is safe (it only sends more waves down the exact path), so the analytic guess is moved inwards until it verifies.
 template <int ACT>
-__device__ void small_safe_range(double mp, int zp, int32_t &lo, int32_t &hi)
+__host__ __device__ inline void small_safe_range(double mp, int zp, int32_t &lo, int32_t &hi)
 {
     // upper end: zp + q <= 255  <=>  q <= 255 - zp, q = trunc(a * mp)
     double gh = ((double)(256 - zp)) / mp;
@@ -342,7 +391,7 @@ __device__ void small_safe_range(double mp, int zp, int32_t &lo, int32_t &hi)
 // accumulator as long as -2^30 <= lo and hi < 2^30 (no modular alias of an out-of-range value lands in [0, hi - lo]); any
 // sub-range of the true safe range is safe, so the ends are simply clamped.  Returns false when no accumulator is safe for
 // this channel (the caller then requantises every value of every window: the reference's order).
-__device__ __forceinline__ bool biased_safe_range(int32_t lo, int32_t hi, int32_t &lo_b, uint32_t &range)
+__host__ __device__ __forceinline__ bool biased_safe_range(int32_t lo, int32_t hi, int32_t &lo_b, uint32_t &range)
 {
     const int32_t L = lo < -(1 << 30) ? -(1 << 30) : lo, H = hi > (1 << 30) - 1 ? (1 << 30) - 1 : hi;
     lo_b = L;

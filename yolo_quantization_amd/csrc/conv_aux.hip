@@ -294,8 +294,9 @@ __device__ __forceinline__ uint32_t first_pool_exact_path(const v4i (&acc)[4], c
 #ifdef MI355_ABLATE
 // per-wave shader-clock sums of the first-layer kernel's phases (tools/l0_phases.py): [0] barrier, [1] deferred stores + prefetch issue,
 // [2] / [4] B reads + MFMA chain of pooled row 0 / 1, [3] / [5] their epilogues, [6] staging wait + LDS writes, [7] tiles
-__device__ long long g_l0_ph[4096][4][10];
-#define L0P_DECL long long l0p[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long l0t = __builtin_readcyclecounter()
+__device__ long long g_l0_ph[4096][4][12];
+#define L0P_ENTRY const long long l0t_entry = __builtin_readcyclecounter()
+#define L0P_DECL long long l0p[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long l0t = __builtin_readcyclecounter(); l0p[10] = l0t - l0t_entry
 #define L0P_MARK(k)                                                  \
     do {                                                             \
         asm volatile("" ::: "memory");                               \
@@ -311,14 +312,15 @@ __device__ long long g_l0_ph[4096][4][10];
 #define L0P_STORE()                                                                                  \
     do {                                                                                             \
         if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                            \
-            for (int k = 0; k < 10; ++k) g_l0_ph[blockIdx.x][threadIdx.x >> 6][k] = l0p[k];           \
+            for (int k = 0; k < 12; ++k) g_l0_ph[blockIdx.x][threadIdx.x >> 6][k] = k == 11 ? (long long)__builtin_readcyclecounter() - l0t_entry : l0p[k]; \
     } while (0)
 extern "C" int mi355_debug_read_l0ph(long long *host)
 {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l0_ph), sizeof(long long) * 4096 * 4 * 10) == hipSuccess ? 0 : -5;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l0_ph), sizeof(long long) * 4096 * 4 * 12) == hipSuccess ? 0 : -5;
 }
 #else
 #define L0P_DECL do { } while (0)
+#define L0P_ENTRY do { } while (0)
 #define L0P_MARK(k) do { } while (0)
 #define L0P_MARK_V(k, v) do { } while (0)
 #define L0P_STORE() do { } while (0)
@@ -327,6 +329,7 @@ extern "C" int mi355_debug_read_l0ph(long long *host)
 template <int ACT, bool SAT, int NM, bool PLANAR>
 __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxArgs a)
 {
+    L0P_ENTRY;
     constexpr int ROWC = first_stage_rowc(PLANAR), XO = PLANAR ? 4 : 0;
     __shared__ __attribute__((aligned(16))) uint32_t img[2][18 * ROWC];
     // LEAKY, wrapping store: windows inside the safe range take activation + zero point + bias from a byte table (common.h)
@@ -341,8 +344,6 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     const int OH = a.H >> 1, OW = a.W >> 1;
     const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + 7) >> 3, tpi = tiles_x * tiles_y;
     const int ntiles = a.B * tpi;
-    const bool pow2 = a.hdr->pow2 == 1;
-
     // ---- per-lane constants: A fragments (row = channel 16*mt + pc, k-group g), channel parameters of the lane's four
     //      accumulator rows 16*mt + 4*g + r
     // Two A fragments per m-tile: window column jx = 0 reads image cells x-1 .. x+1 = cells 0 .. 2 of the lane's four-cell group, column
@@ -356,53 +357,20 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     constexpr bool INTRQ = LUT || ACT == MI355_ACT_RELU6;
     int32_t qm0[NM][4], qsh[NM][4];
     int64_t qc[NM][4];  // lo * M0: the biased accumulator goes straight into one 64-bit multiply-add (u * M0 + lo * M0 = a * M0)
-    const int32_t *shiftp = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(a.hdr) + a.hdr->off_shift);
-    int never_l = 0, noint_l = 0;
 #pragma unroll
-    for (int mt = 0; mt < NM; ++mt) {
-        const int ch = 16 * mt + pc;
-        const int dz = a.dzp[ch];
-        const int d1 = dz > 127 ? 127 : dz, d2 = dz - d1;  // dz in [-127, 128]
-        const uint32_t m1 = (uint32_t)(d1 & 0xFF) * 0x00010101u, m2 = (uint32_t)(d2 & 0xFF) * 0x00010101u;
-#pragma unroll
-        for (int jx = 0; jx < 2; ++jx)
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const int t = dx - jx;  // tap column of cell dx for window column jx
-                const bool real = g < 3 && t >= 0 && t < 3;
-                wa[mt][jx][dx] = real ? (int)(a.wfirst[ch * 9 + 3 * g + t] ^ 0x00808080u) : 0;  // w' = w - 128 on the three channels
-                wd1[mt][jx][dx] = real ? (int)m1 : 0;
-                wd2[mt][jx][dx] = real ? (int)m2 : 0;
-            }
-        chq[mt] = 16 * mt + 4 * g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c2 = chq[mt] + r;
-            const double m = a.mprime[c2];
-            mp[mt][r] = m;
-            int32_t l = -2147483647 - 1, h = 2147483647;
-            if (!SAT) small_safe_range<ACT>(m, a.zp_act, l, h);
-            int32_t lb = 0; uint32_t rg = 0;
-            if (!biased_safe_range(l, h, lb, rg)) never_l = 1;
-            qm0[mt][r] = qsh[mt][r] = 0;
-            if (INTRQ && (!pow2 || !intrq_make(a.mval[c2], shiftp[c2], lb, (int32_t)((uint32_t)lb + rg), qm0[mt][r], qsh[mt][r], ACT == MI355_ACT_RELU6))) noint_l = 1;
-            qc[mt][r] = (int64_t)lb * (int64_t)qm0[mt][r];
-            asm volatile("" : "+v"(qc[mt][r]));  // opaque: the compiler otherwise factors u * M0 + lo * M0 back into (u + lo) * M0 as a 64 x 32 multiply
-            cb[mt][r] = (int32_t)((uint32_t)a.cwb[c2] - (uint32_t)lb);  // accumulators biased by the safe range's lower end (common.h)
-            lo[mt][r] = lb;
-            hi[mt][r] = (int32_t)rg;  // hi - lo
-        }
+    for (int mt = 0; mt < NM; ++mt) chq[mt] = 16 * mt + 4 * g;
+    // Round 5: the kernel starts 1 024 workgroups at once and nothing runs beside their prologues -- deriving the wrap-safe ranges and the
+    // integer multipliers here (FP64 divisions, verification loops), building the byte table and gathering weights / zero points / multipliers
+    // with dependent loads was 26-36 % of the kernel (tools/l0_phases.py).  mi355_conv_pack_epilogue leaves the whole per-lane state in the
+    // blob (common.h L0Lane, EptHeader): fifteen independent 16-byte loads per m-tile + four table dwords behind the key test (issued with the
+    // first tile's image already on its way); a blob without the table (or packed for another activation / zero point, or a saturating store) takes the derivation below.
+    const bool have_ept = !SAT && a.ept != nullptr;  // launch-uniform (kernel argument)
+    const int mpad4 = (a.n + 3) & ~3;                // the first-layer blob's mpad (shim.hip blob_layout)
+    uint32_t ekey = 0, eflags = 0;
+    if (have_ept) {
+        ekey = a.ept->key;
+        eflags = a.ept->flags;
     }
-    const bool never = __syncthreads_or(never_l) != 0;
-    const bool use_int = INTRQ && __syncthreads_or(noint_l) == 0;
-    if constexpr (LUT) {  // visible after the first __syncthreads of the tile loop
-        if (use_int) leaky_lutf_build<false>(lut, a.zp_act, tid, 256);
-        else leaky_lut_build<false>(lut, a.zp_act, tid, 256);
-    }
-    bool need_d2 = false;
-#pragma unroll
-    for (int mt = 0; mt < NM; ++mt) need_d2 |= __builtin_amdgcn_ballot_w64(wd2[mt][0][0] != 0) != 0;
-
     // ---- staging: thread t owns image dwords t, t + 256, t + 512 (< 612): their cell offsets from the tile origin
     int soff[3];
 #pragma unroll
@@ -414,11 +382,11 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     const uint32_t *xc = reinterpret_cast<const uint32_t *>(a.x);
     // tile walk without per-tile divisions: (b, ty, tx) advances by the decomposition of gridDim.x with carries
     struct Pos { int b, ty, tx; };
-    auto pos_of = [&](int t) {
+    auto pos_of = [&](int t) {  // (divisions by launch constants: common.h FastDiv, set by the launcher)
         Pos p;
-        p.b = t / tpi;
+        p.b = fd_div(t, a.fd_tpi);
         const int r = t - p.b * tpi;
-        p.ty = r / tiles_x;
+        p.ty = fd_div(r, a.fd_tx);
         p.tx = r - p.ty * tiles_x;
         return p;
     };
@@ -507,10 +475,94 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     int tile = tbase_x + (xcd_walk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
     Pos cur = pos_of(tile), nxp = cur;
     uint32_t nxt[3];
-    if (tile < tend) {
-        fetch(cur, nxt);
-        stash(0, nxt);
+    if (tile < tend) fetch(cur, nxt);
+    // (the first tile's image is on its way: the per-lane records below share its latency)
+    const bool ept_ok = have_ept && ekey == ept_key(ACT, a.zp_act);  // workgroup-uniform
+    bool pow2, never, use_int, need_d2;
+    if (ept_ok) {
+        pow2 = (eflags & EPT_POW2) != 0;
+        never = (eflags & EPT_NEVER) != 0;
+        use_int = INTRQ && (eflags & EPT_NOINT) == 0;
+        need_d2 = (eflags & EPT_D2) != 0;
+        const char *after = reinterpret_cast<const char *>(a.ept + 1) + (size_t)mpad4 * sizeof(EptEntry);
+        const L0Lane *ll = reinterpret_cast<const L0Lane *>(after + LUTQ_N);
+#pragma unroll
+        for (int mt = 0; mt < NM; ++mt) {
+            const v4i *rec = reinterpret_cast<const v4i *>(ll + mt * 64 + lane);
+            wa[mt][0] = rec[0]; wa[mt][1] = rec[1];
+            wd1[mt][0] = rec[2]; wd1[mt][1] = rec[3];
+            wd2[mt][0] = rec[4]; wd2[mt][1] = rec[5];
+            cb[mt] = rec[6]; lo[mt] = rec[7]; hi[mt] = rec[8];
+            const v4i m0v = rec[9], shv = rec[10], qc01 = rec[11], qc23 = rec[12], mp01 = rec[13], mp23 = rec[14];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { qm0[mt][r] = m0v[r]; qsh[mt][r] = shv[r]; }
+            qc[mt][0] = (int64_t)(((uint64_t)(uint32_t)qc01[1] << 32) | (uint32_t)qc01[0]);
+            qc[mt][1] = (int64_t)(((uint64_t)(uint32_t)qc01[3] << 32) | (uint32_t)qc01[2]);
+            qc[mt][2] = (int64_t)(((uint64_t)(uint32_t)qc23[1] << 32) | (uint32_t)qc23[0]);
+            qc[mt][3] = (int64_t)(((uint64_t)(uint32_t)qc23[3] << 32) | (uint32_t)qc23[2]);
+            mp[mt][0] = __hiloint2double(mp01[1], mp01[0]); mp[mt][1] = __hiloint2double(mp01[3], mp01[2]);
+            mp[mt][2] = __hiloint2double(mp23[1], mp23[0]); mp[mt][3] = __hiloint2double(mp23[3], mp23[2]);
+        }
+        if constexpr (LUT) {  // visible after the first __syncthreads of the tile loop
+            uint32_t lutw[LUTQ_N / 4 / 256];
+#pragma unroll
+            for (int k = 0; k < LUTQ_N / 4 / 256; ++k) lutw[k] = reinterpret_cast<const uint32_t *>(after)[tid + 256 * k];
+#pragma unroll
+            for (int k = 0; k < LUTQ_N / 4 / 256; ++k) reinterpret_cast<uint32_t *>(lut)[tid + 256 * k] = lutw[k];
+        }
+    } else {
+        pow2 = a.hdr->pow2 == 1;
+        const int32_t *shiftp = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(a.hdr) + a.hdr->off_shift);
+        int never_l = 0, noint_l = 0;
+#pragma unroll
+        for (int mt = 0; mt < NM; ++mt) {
+            const int ch = 16 * mt + pc;
+            const int dz = a.dzp[ch];
+            const int d1 = dz > 127 ? 127 : dz, d2 = dz - d1;  // dz in [-127, 128]
+            const uint32_t m1 = (uint32_t)(d1 & 0xFF) * 0x00010101u, m2 = (uint32_t)(d2 & 0xFF) * 0x00010101u;
+#pragma unroll
+            for (int jx = 0; jx < 2; ++jx)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) {
+                    const int t = dx - jx;  // tap column of cell dx for window column jx
+                    const bool real = g < 3 && t >= 0 && t < 3;
+                    wa[mt][jx][dx] = real ? (int)(a.wfirst[ch * 9 + 3 * g + t] ^ 0x00808080u) : 0;  // w' = w - 128 on the three channels
+                    wd1[mt][jx][dx] = real ? (int)m1 : 0;
+                    wd2[mt][jx][dx] = real ? (int)m2 : 0;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c2 = chq[mt] + r;
+                const double m = a.mprime[c2];
+                mp[mt][r] = m;
+                int32_t l = -2147483647 - 1, h = 2147483647;
+                if (!SAT) small_safe_range<ACT>(m, a.zp_act, l, h);
+                int32_t lb = 0; uint32_t rg = 0;
+                if (!biased_safe_range(l, h, lb, rg)) never_l = 1;
+                qm0[mt][r] = qsh[mt][r] = 0;
+                if (INTRQ && (!pow2 || !intrq_make(a.mval[c2], shiftp[c2], lb, (int32_t)((uint32_t)lb + rg), qm0[mt][r], qsh[mt][r], ACT == MI355_ACT_RELU6))) noint_l = 1;
+                qc[mt][r] = (int64_t)lb * (int64_t)qm0[mt][r];
+                cb[mt][r] = (int32_t)((uint32_t)a.cwb[c2] - (uint32_t)lb);  // accumulators biased by the safe range's lower end (common.h)
+                lo[mt][r] = lb;
+                hi[mt][r] = (int32_t)rg;  // hi - lo
+            }
+        }
+        never = __syncthreads_or(never_l) != 0;
+        use_int = INTRQ && __syncthreads_or(noint_l) == 0;
+        if constexpr (LUT) {  // visible after the first __syncthreads of the tile loop
+            if (use_int) leaky_lutf_build<false>(lut, a.zp_act, tid, 256);
+            else leaky_lut_build<false>(lut, a.zp_act, tid, 256);
+        }
+        need_d2 = false;
+#pragma unroll
+        for (int mt = 0; mt < NM; ++mt) need_d2 |= __builtin_amdgcn_ballot_w64(wd2[mt][0][0] != 0) != 0;
     }
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(qc[mt][r]));  // opaque: the compiler otherwise factors u * M0 + lo * M0 back into (u + lo) * M0 as a 64 x 32 multiply
+
+    if (tile < tend) stash(0, nxt);
     // Every register loaded so far (weights, per-channel constants) is in: without this the compiler has to keep an
     // s_waitcnt vmcnt(0) in front of the first MFMA of the (shared) loop body, which then also waits for the image
     // prefetch issued a few instructions earlier and for the previous tile's stores -- a memory round trip per tile.
@@ -523,18 +575,34 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     uint8_t *dout[2] = {a.ypool, a.ypool};
     bool dvalid[2] = {false, false};
     bool dall = false;  // wave-uniform: every lane of the deferred tile stores
+    // Written by hand in the scalar-base form (wave-uniform row pointer + the lane's loop-invariant 32-bit offset: no 64-bit address add per
+    // store) and, above all, OPAQUE to the compiler's wait-count model: a dword store reads its data register at issue, but when the register
+    // allocator hands that register to the next MFMA chain's accumulators the compiler guards the reuse with s_waitcnt vmcnt(0) -- a full
+    // memory round trip (prefetch loads included) in front of the tile's third MFMA.  Whether that happened was allocation luck: round 5's
+    // prologue change moved one register and the hot loop went from 3 150 to 4 120 clocks per tile (tools/l0_phases.py: "row 0: B reads +
+    // MFMA chain" 485 -> 1 416).  The compiler's own vmcnt counts for the prefetch stay valid: the stores are YOUNGER than the loads they
+    // follow, so a wait for "all but the k youngest loads" can only wait longer, never too short.
+    unsigned st_off[NM];
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt) st_off[mt] = pc_off + (unsigned)chq[mt];
+    auto store_row = [&](const uint8_t *rowp, unsigned off, uint32_t data) {
+        // (the row pointer is wave-uniform by construction; where the compiler cannot prove it, readfirstlane puts it into scalar registers)
+        const uint64_t rp = reinterpret_cast<uint64_t>(rowp);
+        const uint64_t rs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rp);
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(data), "s"(rs) : "memory");
+    };
     auto flush_stores = [&]() {
         if (dall) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int mt = 0; mt < NM; ++mt) *reinterpret_cast<uint32_t *>(dout[s] + (pc_off + (unsigned)chq[mt])) = dpk[s][mt];
+                for (int mt = 0; mt < NM; ++mt) store_row(dout[s], st_off[mt], dpk[s][mt]);
         } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 if (dvalid[s]) {
 #pragma unroll
-                    for (int mt = 0; mt < NM; ++mt) *reinterpret_cast<uint32_t *>(dout[s] + (pc_off + (unsigned)chq[mt])) = dpk[s][mt];
+                    for (int mt = 0; mt < NM; ++mt) store_row(dout[s], st_off[mt], dpk[s][mt]);
                 }
         }
     };
@@ -548,6 +616,13 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     auto run = [&](auto fast_c, auto d2_c) {
         constexpr bool FASTC = decltype(fast_c)::value, D2C = decltype(d2_c)::value;
         int buf = 0;
+        // Every instantiation starts (and ends, below) with no memory operation in flight AS FAR AS THE COMPILER'S WAIT-COUNT MODEL GOES.  The
+        // four loops are exclusive, but jump threading chains them (the exit of one falls into the guard of the next, which then fails), and
+        // along that infeasible path the next loop inherits the previous loop's prefetch as "still pending": when the register allocator
+        // reuses one of THOSE destination registers for an MFMA accumulator the model demands s_waitcnt vmcnt(0) in front of the tile's third
+        // MFMA -- a memory round trip per tile that no executed path needs (round 5: 3 150 -> 4 120 clocks per tile after an unrelated prologue
+        // change moved the allocation; rounds 2-4 met the same effect as "allocation luck").  Executed once per kernel: free.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         for (; tile < tend; tile += tstride, buf ^= 1, cur = nxp) {
             L0P_MARK(6);
             __syncthreads();  // this tile's image is complete; every wave is past the previous tile
@@ -692,18 +767,23 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
             l0p[7] += 1;
 #endif
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
     };
     const bool fastc = pow2 && !never && (!INTRQ || use_int);
+    // each instantiation is followed by its OWN copy of the kernel's tail and a return: no control-flow edge leads from one loop to another
+    // (see the comment at the top of `run`)
+    auto finish = [&]() {
+        flush_stores();
+        L0P_MARK(6);
+        L0P_STORE();
+    };
     if (fastc) {
-        if (need_d2) run(std::true_type{}, std::true_type{});
-        else run(std::true_type{}, std::false_type{});
-    } else {
-        if (need_d2) run(std::false_type{}, std::true_type{});
-        else run(std::false_type{}, std::false_type{});
+        if (need_d2) { run(std::true_type{}, std::true_type{}); finish(); return; }
+        run(std::true_type{}, std::false_type{}); finish(); return;
     }
-    flush_stores();
-    L0P_MARK(6);
-    L0P_STORE();
+    if (need_d2) { run(std::false_type{}, std::true_type{}); finish(); return; }
+    run(std::false_type{}, std::false_type{});
+    finish();
 }
 
 // The same kernel without the pool: the first layer of the non-tiny networks (YOLOv3's 3 -> 32 at full resolution) stores
@@ -770,11 +850,11 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const AuxArgs a
     const uint32_t *xc = reinterpret_cast<const uint32_t *>(a.x);
     // tile walk without per-tile divisions: (b, ty, tx) advances by the decomposition of gridDim.x with carries
     struct Pos { int b, ty, tx; };
-    auto pos_of = [&](int t) {
+    auto pos_of = [&](int t) {  // (divisions by launch constants: common.h FastDiv, set by the launcher)
         Pos p;
-        p.b = t / tpi;
+        p.b = fd_div(t, a.fd_tpi);
         const int r = t - p.b * tpi;
-        p.ty = r / tiles_x;
+        p.ty = fd_div(r, a.fd_tx);
         p.tx = r - p.ty * tiles_x;
         return p;
     };
@@ -984,6 +1064,9 @@ int conv_first_mfma_launch(AuxArgs &a, hipStream_t st)
     if ((long)a.in_cells + 64L * (a.W + 1) >= (1L << 31)) return MI355_EINVAL;  // 32-bit cell arithmetic in the kernel
     const int OH = a.H / 2, OW = a.W / 2;
     const long ntiles = (long)a.B * ((OW + 15) / 16) * ((OH + 7) / 8);
+    if (ntiles >= (1L << 31)) return MI355_EINVAL;
+    a.fd_tx = fastdiv_make((uint32_t)((OW + 15) / 16));
+    a.fd_tpi = fastdiv_make((uint32_t)(((OW + 15) / 16) * ((OH + 7) / 8)));
     const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
     if (a.n == 16) {
         if (a.act == MI355_ACT_LEAKY) return first_mfma_nopool_launch_sat<MI355_ACT_LEAKY, 1>(a, st, grid);
@@ -1006,6 +1089,9 @@ int conv_first_mfma_pool_launch(AuxArgs &a, hipStream_t st)
     if (((long)a.pool_lead + (long)a.B * (OH + 1) * (OW + 1) + OW + 2) * a.pool_cs >= (1L << 32)) return MI355_EINVAL;
     if (a.planar && (long)a.B * 3 * a.H * a.W >= (1L << 31)) return MI355_EINVAL;
     const long ntiles = (long)a.B * ((OW + 15) / 16) * ((OH + 7) / 8);
+    if (ntiles >= (1L << 31)) return MI355_EINVAL;
+    a.fd_tx = fastdiv_make((uint32_t)((OW + 15) / 16));
+    a.fd_tpi = fastdiv_make((uint32_t)(((OW + 15) / 16) * ((OH + 7) / 8)));
     const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // persistent: four workgroups per CU (five measured slower)
     if (a.n == 16) {
         if (a.act == MI355_ACT_LEAKY) return first_mfma_launch_sat<MI355_ACT_LEAKY, 1>(a, st, grid);

@@ -223,31 +223,49 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
     // ---- per-channel parameters and the wrap-safe ranges.  POOL: the accumulators are kept BIASED by the range's lower end (seed
     //      cw + bias - lo), ldsLO / ldsHI hold that end and the range's width (common.h biased_safe_range)
     int never_l = 0, noint_l = 0;
+    // the host's epilogue table for this (activation, zero point), if the blob carries one (mi355_conv_pack_epilogue, common.h): the
+    // ranges and integer multipliers are then 32 bytes per channel to load instead of FP64 divisions and verification loops per workgroup
+    const bool ept_ok = POOL && !SAT && a.ept != nullptr && a.ept->key == ept_key(ACT, a.zp_act);
     if (tid < N) {
         const double mp = a.mprime[tid];
         ldsMP[tid] = mp;
         ldsDZ[tid] = a.dzp[tid];
-        int32_t lo = -2147483647 - 1, hi = 2147483647;
-        if (!SAT && POOL) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
         int32_t m0 = 0, sh = 0;
-        if constexpr (POOL) {
-            int32_t lb = 0; uint32_t rg = 0;
-            if (!biased_safe_range(lo, hi, lb, rg)) never_l = 1;
-            if (!(pow2 && intrq_make(a.mval[tid], a.shift[tid], lb, (int32_t)((uint32_t)lb + rg), m0, sh, ACT == MI355_ACT_RELU6))) noint_l = 1;
-            ldsCB[tid] = (int32_t)((uint32_t)a.cwb[tid] - (uint32_t)lb);
-            ldsLO[tid] = lb;
-            ldsHI[tid] = (int32_t)rg;
+        if (ept_ok) {
+            const EptEntry e = reinterpret_cast<const EptEntry *>(a.ept + 1)[tid];
+            ldsCB[tid] = e.cbl;
+            ldsLO[tid] = e.lb;
+            ldsHI[tid] = (int32_t)e.rg;
+            m0 = e.m0; sh = e.sh;
         } else {
-            ldsCB[tid] = a.cwb[tid];
-            ldsLO[tid] = lo;
-            ldsHI[tid] = hi;
+            int32_t lo = -2147483647 - 1, hi = 2147483647;
+            if (!SAT && POOL) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
+            if constexpr (POOL) {
+                int32_t lb = 0; uint32_t rg = 0;
+                if (!biased_safe_range(lo, hi, lb, rg)) never_l = 1;
+                if (!(pow2 && intrq_make(a.mval[tid], a.shift[tid], lb, (int32_t)((uint32_t)lb + rg), m0, sh, ACT == MI355_ACT_RELU6))) noint_l = 1;
+                ldsCB[tid] = (int32_t)((uint32_t)a.cwb[tid] - (uint32_t)lb);
+                ldsLO[tid] = lb;
+                ldsHI[tid] = (int32_t)rg;
+            } else {
+                ldsCB[tid] = a.cwb[tid];
+                ldsLO[tid] = lo;
+                ldsHI[tid] = hi;
+            }
         }
         ldsM0[tid] = m0;
         ldsSH[tid] = sh;
     }
     // one wave-uniform flag for "this launch requantises every window value" (see pool_requant_quad_biased)
     constexpr bool INTRQC = (ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT;
-    const bool never = POOL && (__syncthreads_or(never_l | (INTRQC ? noint_l : 0)) != 0 || !pow2);
+    bool never_any;
+    if (ept_ok) {
+        never_any = (a.ept->flags & (EPT_NEVER | (INTRQC ? EPT_NOINT : 0u))) != 0;
+        __syncthreads();
+    } else {
+        never_any = __syncthreads_or(never_l | (INTRQC ? noint_l : 0)) != 0;
+    }
+    const bool never = POOL && (never_any || !pow2);
 
     // ---- stationary A fragments: plane ws = [m-tile][k-step][lane][16 B]
     v4i wf[NM][KST];
@@ -655,29 +673,45 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
     // qualifies -- pool_requant_quad_biased, as in conv_small_pool_kernel)
     constexpr bool INTRQC = (ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT;
     int never_l = 0;
+    const bool ept_ok = POOL && !SAT && a.ept != nullptr && a.ept->key == ept_key(ACT, a.zp_act);  // the host's epilogue table (common.h)
     for (int i = tid; i < N; i += NT) {
         const double mp = a.mprime[i];
         ldsMP[i] = mp;
         ldsDZ[i] = a.dzp[i];
-        int32_t lo = -2147483647 - 1, hi = 2147483647;
-        if (!SAT && POOL) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
         int32_t m0 = 0, sh = 0;
-        if constexpr (POOL) {
-            int32_t lb = 0; uint32_t rg = 0;
-            if (!biased_safe_range(lo, hi, lb, rg)) never_l = 1;
-            if (INTRQC && !(pow2 && intrq_make(a.mval[i], a.shift[i], lb, (int32_t)((uint32_t)lb + rg), m0, sh, ACT == MI355_ACT_RELU6))) never_l = 1;
-            ldsCB[i] = (int32_t)((uint32_t)a.cwb[i] - (uint32_t)lb);
-            ldsLO[i] = lb;
-            ldsHI[i] = (int32_t)rg;
+        if (ept_ok) {
+            const EptEntry e = reinterpret_cast<const EptEntry *>(a.ept + 1)[i];
+            ldsCB[i] = e.cbl;
+            ldsLO[i] = e.lb;
+            ldsHI[i] = (int32_t)e.rg;
+            m0 = e.m0; sh = e.sh;
         } else {
-            ldsCB[i] = a.cwb[i];
-            ldsLO[i] = lo;
-            ldsHI[i] = hi;
+            int32_t lo = -2147483647 - 1, hi = 2147483647;
+            if (!SAT && POOL) small_safe_range<ACT>(mp, a.zp_act, lo, hi);
+            if constexpr (POOL) {
+                int32_t lb = 0; uint32_t rg = 0;
+                if (!biased_safe_range(lo, hi, lb, rg)) never_l = 1;
+                if (INTRQC && !(pow2 && intrq_make(a.mval[i], a.shift[i], lb, (int32_t)((uint32_t)lb + rg), m0, sh, ACT == MI355_ACT_RELU6))) never_l = 1;
+                ldsCB[i] = (int32_t)((uint32_t)a.cwb[i] - (uint32_t)lb);
+                ldsLO[i] = lb;
+                ldsHI[i] = (int32_t)rg;
+            } else {
+                ldsCB[i] = a.cwb[i];
+                ldsLO[i] = lo;
+                ldsHI[i] = hi;
+            }
         }
         ldsM0[i] = m0;
         ldsSH[i] = sh;
     }
-    const bool never = POOL && (__syncthreads_or(never_l) != 0 || !pow2);
+    bool never_any;
+    if (ept_ok) {
+        never_any = (a.ept->flags & (EPT_NEVER | (INTRQC ? EPT_NOINT : 0u))) != 0;
+        __syncthreads();
+    } else {
+        never_any = __syncthreads_or(never_l) != 0;
+    }
+    const bool never = POOL && (never_any || !pow2);
     v4i wf[KST];
 #pragma unroll
     for (int s = 0; s < KST; ++s) wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(wq * KST + s) * 64 + lane) * 16);

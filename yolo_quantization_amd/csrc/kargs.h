@@ -54,6 +54,7 @@ struct ConvArgs {
     int res_cs, res_delta;
     int sc_ka, sc_kb, sc_k0;
     int plan;                // MI355_PLAN_*: throughput plan = prefer kernels of which two workgroups fit a CU
+    const EptHeader *ept;    // the blob's epilogue table (common.h) or null
 };
 
 struct AuxArgs {
@@ -79,6 +80,8 @@ struct AuxArgs {
     const int32_t *cwb;         // cw + bias (first-layer MFMA kernel)
     int planar;                 // x is the reference's [B][3][H][W] uint8 planes (no cells, no pads), read in place
     int debug_flags;            // mi355_debug_flags (2048: plain tile walk instead of the XCD-aware one, A/B runs)
+    const EptHeader *ept;       // the blob's epilogue table (common.h) or null
+    FastDiv fd_tpi, fd_tx;      // first-layer MFMA kernels: divisions by tiles per image / tiles per row
 };
 
 struct PoolArgs {

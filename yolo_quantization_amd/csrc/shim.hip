@@ -361,6 +361,11 @@ static int blob_layout(int n, int c, int ksize, ConvBlobHeader *h)
         h->off_ws = off;
         off = align16(off + (size_t)(n / 32) * (c == 16 ? 5 : (c == 32 ? 9 : 18)) * 1024);
     }
+    if (h->first || conv_small_eligible(n, c, ksize)) {  // the conv + maxpool kernels' epilogue table (common.h EptHeader)
+        h->off_ept = off;
+        off = align16(off + sizeof(EptHeader) + (size_t)h->mpad * sizeof(EptEntry) +
+                      (h->first ? (size_t)LUTQ_N + (size_t)((n + 15) / 16) * 64 * sizeof(L0Lane) : 0));
+    }
     h->total = off;
     return MI355_OK;
 }
@@ -488,6 +493,98 @@ int mi355_conv_pack(int n, int c, int ksize, const uint8_t *wq, const uint8_t *z
     return MI355_OK;
 }
 
+extern "C++" {
+template <int ACT>
+static void ept_fill(const ConvBlobHeader &h, char *base, int zp_act)
+{
+    EptHeader *eh = (EptHeader *)(base + h.off_ept);
+    EptEntry *e = (EptEntry *)(eh + 1);
+    const double *mprime = (const double *)(base + h.off_mprime), *mval = (const double *)(base + h.off_mval);
+    const int32_t *shift = (const int32_t *)(base + h.off_shift), *cwb = (const int32_t *)(base + h.off_cwb);
+    uint32_t flags = h.pow2 ? EPT_POW2 : EPT_NOINT;
+    for (int oc = 0; oc < h.n; ++oc) {
+        int32_t lo, hi, lb = 0, m0 = 0, sh = 0;
+        uint32_t rg = 0;
+        small_safe_range<ACT>(mprime[oc], zp_act, lo, hi);
+        if (!biased_safe_range(lo, hi, lb, rg)) flags |= EPT_NEVER;
+        if (!h.pow2 || !intrq_make(mval[oc], shift[oc], lb, (int32_t)((uint32_t)lb + rg), m0, sh, ACT == MI355_ACT_RELU6)) {
+            flags |= EPT_NOINT;
+            m0 = sh = 0;
+        }
+        e[oc].lb = lb; e[oc].rg = rg; e[oc].m0 = m0; e[oc].sh = sh;
+        e[oc].qc = (int64_t)lb * (int64_t)m0;
+        e[oc].cbl = (int32_t)((uint32_t)cwb[oc] - (uint32_t)lb);
+        e[oc].pad_ = 0;
+    }
+    for (int oc = h.n; oc < h.mpad; ++oc) memset(&e[oc], 0, sizeof(EptEntry));
+    if (h.first) {  // the first layer's LEAKY byte table (common.h leaky_lut_build / leaky_lutf_build): indexed by f (integer form) or by q
+        uint8_t *lut = (uint8_t *)(e + h.mpad);
+        const bool by_floor = !(flags & EPT_NOINT);
+        for (int i = 0; i < LUTQ_N; ++i) {
+            const int f = i - LUTQ_OFF;
+            lut[i] = ACT == MI355_ACT_LEAKY ? (uint8_t)leaky_byte_biased<false>(by_floor && f < 0 ? f + 1 : f, zp_act) : 0;
+        }
+        // the first-layer MFMA kernel's per-lane state (common.h L0Lane)
+        L0Lane *ll = (L0Lane *)(lut + LUTQ_N);
+        const uint32_t *wfirst = (const uint32_t *)(base + h.off_wp);
+        const int32_t *dzp = (const int32_t *)(base + h.off_dzp);
+        for (int mt = 0; mt < (h.n + 15) / 16; ++mt)
+            for (int lane = 0; lane < 64; ++lane) {
+                L0Lane &L = ll[mt * 64 + lane];
+                memset(&L, 0, sizeof(L));
+                const int pc = lane & 15, g = lane >> 4, ch = 16 * mt + pc;
+                if (ch < h.n) {
+                    const int dz = dzp[ch];
+                    const int d1 = dz > 127 ? 127 : dz, d2 = dz - d1;  // dz in [-127, 128]
+                    if (d2) flags |= EPT_D2;
+                    const uint32_t m1 = (uint32_t)(d1 & 0xFF) * 0x00010101u, m2 = (uint32_t)(d2 & 0xFF) * 0x00010101u;
+                    for (int jx = 0; jx < 2; ++jx)
+                        for (int dx = 0; dx < 4; ++dx) {
+                            const int t = dx - jx;  // tap column of cell dx for window column jx
+                            if (g < 3 && t >= 0 && t < 3) {
+                                L.wa[jx][dx] = (int32_t)(wfirst[ch * 9 + 3 * g + t] ^ 0x00808080u);
+                                L.wd1[jx][dx] = (int32_t)m1;
+                                L.wd2[jx][dx] = (int32_t)m2;
+                            }
+                        }
+                }
+                for (int r = 0; r < 4; ++r) {
+                    const int c2 = 16 * mt + 4 * g + r;
+                    if (c2 >= h.n) continue;
+                    L.cb[r] = e[c2].cbl; L.lo[r] = e[c2].lb; L.hi[r] = (int32_t)e[c2].rg;
+                    L.qm0[r] = e[c2].m0; L.qsh[r] = e[c2].sh; L.qc[r] = e[c2].qc;
+                    L.mp[r] = mprime[c2];
+                }
+            }
+    }
+    eh->flags = flags;
+    eh->pad_[0] = eh->pad_[1] = 0;
+    eh->key = ept_key(ACT, zp_act);
+}
+}  // extern "C++"
+
+int mi355_conv_pack_epilogue(int n, int c, int ksize, int activation, int zp_act, void *blob)
+{
+    ConvBlobHeader h;
+    if (blob_layout(n, c, ksize, &h) != MI355_OK || !blob) return einval("conv_pack_epilogue: shape / null");
+    ConvBlobHeader have;
+    memcpy(&have, blob, sizeof(have));
+    if (have.magic != MI355_BLOB_MAGIC || have.n != n || have.c != c || have.ksize != ksize || have.total != h.total)
+        return einval("conv_pack_epilogue: not a mi355_conv_pack blob of this shape");
+    if (zp_act < 0 || zp_act > 255) return einval("conv_pack_epilogue: zp_act");
+    if (!h.off_ept) return MI355_OK;  // no kernel of this shape reads the table
+    h.pow2 = have.pow2;
+    char *base = (char *)blob;
+    switch (activation) {
+    case MI355_ACT_LEAKY: ept_fill<MI355_ACT_LEAKY>(h, base, zp_act); break;
+    case MI355_ACT_RELU6: ept_fill<MI355_ACT_RELU6>(h, base, zp_act); break;
+    case MI355_ACT_RELU:  // the integer path stores q + zp for RELU as for LINEAR (ref src/convolutional_layer.c:740-742); the kernels' LINEAR instantiation serves both
+    case MI355_ACT_LINEAR: ept_fill<MI355_ACT_LINEAR>(h, base, zp_act); break;
+    default: return einval("conv_pack_epilogue: activation");
+    }
+    return MI355_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ convolution
 static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, const void *blob, const uint8_t *w_u8,
                              const uint8_t *zp_w, const mi355_tensor *y, const mi355_tensor *ypool, int32_t *acc_out,
@@ -540,6 +637,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
         a.s_act = d->s_act; a.total_n = total_n;
         a.mprime = (const double *)(base + h.off_mprime); a.hdr = (const ConvBlobHeader *)base;
         a.cwb = (const int32_t *)(base + h.off_cwb);
+        a.ept = h.off_ept ? (const EptHeader *)(base + h.off_ept) : nullptr;
         a.ypool = ypool ? (uint8_t *)ypool->data : nullptr; a.pool_cs = ypool ? ypool->cs : 0;
         a.pool_lead = ypool ? ypool->lead : 0;
         if (d->accum_mode == MI355_ACC_REF_F32) {
@@ -592,6 +690,7 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     a.cwb = (const int32_t *)(base + h.off_cwb);
     a.hdr = (const ConvBlobHeader *)base;  // device copy: the kernel reads the data-dependent pow2 flag from it
     a.ws = h.off_ws ? (const int8_t *)(base + h.off_ws) : nullptr;
+    a.ept = h.off_ept ? (const EptHeader *)(base + h.off_ept) : nullptr;
     a.yolo_out = yolo_out; a.yolo_per = yolo_classes + 5;
     a.up = up;
     a.plan = d->plan;

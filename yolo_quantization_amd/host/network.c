@@ -318,6 +318,9 @@ void quantization_prep_host(network *net, float in_scale, uint8_t in_zp)
         check_mi355(mi355_conv_pack(l->n, l->c, l->size, l->weights_uint8, l->weight_data_uint8_zero_point,
                                     l->biases_int32, l->M_value, l->M0_right_shift_value, l->blob_host),
                     "mi355_conv_pack");
+        /* the fused conv + maxpool kernels' per-channel epilogue constants for this layer's activation and zero point */
+        check_mi355(mi355_conv_pack_epilogue(l->n, l->c, l->size, l->activation, l->activ_data_uint8_zero_point[0], l->blob_host),
+                    "mi355_conv_pack_epilogue");
     }
 }
 
@@ -429,6 +432,8 @@ void quantization_weights_and_activations_gpu(network *net, const float *input_g
         prep_conv_layer(net, 0);
         check_mi355(mi355_conv_pack(l0->n, l0->c, l0->size, l0->weights_uint8, l0->weight_data_uint8_zero_point,
                                     l0->biases_int32, l0->M_value, l0->M0_right_shift_value, l0->blob_host), "mi355_conv_pack");
+        check_mi355(mi355_conv_pack_epilogue(l0->n, l0->c, l0->size, l0->activation, l0->activ_data_uint8_zero_point[0], l0->blob_host),
+                    "mi355_conv_pack_epilogue");
         check_mi355(mi355_h2d(l0->blob_gpu, l0->blob_host, l0->blob_bytes, net->stream), "upload blob 0");
         if (zp_changed) check_mi355(mi355_tensor_fill(&net->input_t, zp, net->stream), "fill input");  /* pad cells = zero point */
         check_mi355(mi355_stream_sync(net->stream), "sync");  /* blob_host may be repacked by the next call */
@@ -750,7 +755,7 @@ void network_yolo_detections_gpu(network *net, int i, int imw, int imh, float th
 typedef struct { uint32_t magic; int32_t nlayers; float in_scale; int32_t in_zp; uint64_t total; uint64_t l0_bytes; } pack_head;
 typedef struct { float s_act, s_in; int32_t zp_act, zp_in; uint64_t blob_bytes; } pack_rec;
 typedef struct { int32_t n, c, size, batch_normalize; } pack_l0;
-#define PACK_MAGIC 0x33444B4Eu /* "NKD3": round 4 permuted the A rows of conv_small.hip's weights-stationary plane (kargs.h ws_row_filter) */
+#define PACK_MAGIC 0x34444B4Eu /* "NKD4": round 5 added the epilogue table to the blobs of the conv + maxpool shapes (common.h EptHeader); NKD3: permuted A rows (kargs.h ws_row_filter) */
 
 static size_t l0_record_bytes(const layer *l)
 {
