@@ -133,7 +133,7 @@ def pmc_traffic_per_launch():
     return tot / n, os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(cfg, wts, nimg, omp=False):
+def cpu_baseline(cfg, wts, nimg, omp=False, threads=None):
     """The reference itself (oracle/_ref/libdarknet_ref.so, Makefile-default build, 1 thread; omp=True: its MULTI_CORE=1
     OpenMP flavour on every host core) timed on this box's host cores on a bounded sample; falls back to the CPU
     restatement ('port') if the prebuilt reference is absent."""
@@ -159,7 +159,11 @@ def cpu_baseline(cfg, wts, nimg, omp=False):
         if not refdrv.available(omp):
             raise FileNotFoundError("oracle/_ref not built")
         net = refdrv.RefNet(cfg, wts, omp=omp)
+        if omp and threads:  # the OpenMP runtime the reference's all-cores build is linked against (GNU libgomp)
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
         net.prepare(synth.image_u8_to_float(x))
+        if omp:
+            net.forward()  # thread team start-up is not the reference's per-image cost
         t0 = time.time()
         for _ in range(nimg):
             net.forward()
@@ -176,7 +180,7 @@ def cpu_baseline(cfg, wts, nimg, omp=False):
             onet.forward(x, accum=oracle.ACC_REF_F32)
         dt = time.time() - t0
         kind = "port"
-    return {"value": nimg / dt, "unit": "images/s", "cores": (os.cpu_count() if omp and kind == "reference" else 1), "kind": kind,
+    return {"value": nimg / dt, "unit": "images/s", "cores": ((threads or os.cpu_count()) if omp and kind == "reference" else 1), "kind": kind,
             "sample": f"{nimg} x {os.path.basename(cfg)} {shapes[0].h}x{shapes[0].w} image, whole net, batch 1, {os.cpu_count()} host cores present"}
 
 
@@ -211,16 +215,14 @@ def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): re-run this command under torch.distributed.run,
     one rank per GPU on this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve).  Rank 0 of the child job
     prints the ONE JSON line on the inherited stdout; the launcher's exit code is ours."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL across processes)
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d rendezvous on a port IT binds (127.0.0.1:0) -- no bind-then-close-then-rebind window as with a
+    # port picked here
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           os.path.abspath(__file__)] + sys.argv[1:]
     print("[bench] no launcher around --gpus %d: re-running as  %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
     sys.exit(subprocess.call(cmd, env=env))
 
@@ -490,7 +492,7 @@ def main():
     # whole-chip kernels of rounds 1-2 (128 x 384 row-image tiles, conv_ws3), so that their roofline stays on record next to
     # the half-CU kernels'.  Never part of `value`.
     latency_leg = None
-    if ninfl > 1 and plan == 1 and rank == 0 and not args.graph and not args.no_extra_legs:
+    if ninfl > 1 and plan == 1 and rank == 0 and world == 1 and not args.graph and not args.no_extra_legs:
         net.set("plan", 0)
         for _ in range(4):
             net.forward()
@@ -510,13 +512,15 @@ def main():
     # instances at once (the layer range knob of the host: forward_network_gpu runs that one layer on the tensors the last pass left),
     # wall time / number of launches = what one launch costs the chip when the chip is kept full of this kernel -- no launch gap, fill or
     # tail between dependent launches, which is how the kernel runs in the timed region.  (tools/layer_flood.py does this for every layer.)
-    sustained = None
-    if ninfl > 1 and rank == 0 and not args.graph and rows_layers and not args.no_extra_legs:
-        tot_ops = tot_us = 0.0
-        per = []
-        for i in rows_layers:
+    sustained = sustained33 = energy = None
+    extra_legs = ninfl > 1 and rank == 0 and world == 1 and not args.graph and not args.no_extra_legs  # (world > 1: every other rank would sit in the final barrier meanwhile)
+    s33_layers = [i for i, inf in enumerate(net.info) if inf["type"] == binding.T_CONV and inf["size"] == 3 and inf["stride"] == 1 and inf["c"] > 3]
+    if extra_legs and (rows_layers or s33_layers):
+        per = {}
+        for i in sorted(set(rows_layers) | set(s33_layers)):
+            hi = i + 1 + (1 if (net.fuses_next(i) and net.info[i + 1]["type"] == binding.T_MAXPOOL) else 0)  # a conv + maxpool launch is one launch
             for nk in nets:
-                nk.set("range_lo", i); nk.set("range_hi", i + 1)
+                nk.set("range_lo", i); nk.set("range_hi", hi)
             for _ in range(4):
                 for nk in nets:
                     nk.forward()
@@ -531,14 +535,50 @@ def main():
                 nk.sync()
             us = (time.perf_counter() - t0) / (reps * ninfl) * 1e6
             ops = conv_layer_work(net.info[i], B)[0]
-            per.append({"layer": i, "us_per_launch": round(us, 2), "tops": round(ops / us / 1e6, 1)})
-            tot_ops += ops; tot_us += us
+            per[i] = {"layer": i, "conv": "%d->%d @%d%s" % (net.info[i]["c"], net.info[i]["n"], net.info[i]["out_h"], " + maxpool" if hi > i + 1 else ""),
+                      "us_per_launch": round(us, 2), "tops": round(ops / us / 1e6, 1), "frac": round(ops / us / 1e6 / PEAK_INT8_TOPS, 4), "ops": ops}
         for nk in nets:
             nk.set("range_lo", 0); nk.set("range_hi", 0)
-        sustained = {"achieved": round(tot_ops / tot_us / 1e6, 1), "frac": round(tot_ops / tot_us / 1e6 / PEAK_INT8_TOPS, 4), "launches": per,
-                     "note": f"each row-image launch of the step repeated 40 times on all {ninfl} instances at once; host wall time / launches (no events: "
-                             "the launches overlap).  `frac` above is the strict per-launch figure (one launch alone on the device, launch gap, fill and "
-                             "tail included); this is the rate the kernel sustains when the chip is kept full of it, as in the timed region"}
+
+        def agg(which, note):
+            rows = [per[i] for i in which if i in per]
+            if not rows:
+                return None
+            o, u = sum(r["ops"] for r in rows), sum(r["us_per_launch"] for r in rows)
+            return {"achieved": round(o / u / 1e6, 1), "frac": round(o / u / 1e6 / PEAK_INT8_TOPS, 4), "us": round(u, 2),
+                    "layer_set": "L" + ", L".join(str(r["layer"]) for r in rows),
+                    "launches": [{k: v for k, v in r.items() if k != "ops"} for r in rows], "note": note}
+        sustained = agg(rows_layers, f"the row-image launches of the step ONLY (not the north-star layer set: see conv3x3_s1_aggregate.sustained), each repeated 40 times on all "
+                                     f"{ninfl} instances at once; host wall time / launches (no events: the launches overlap).  `frac` above is the strict per-launch figure "
+                                     "(one launch alone on the device, launch gap, fill and tail included); this is the rate the kernel sustains when the chip is kept full of it, "
+                                     "as in the timed region")
+        sustained33 = agg(s33_layers, f"EVERY 3x3 stride-1 conv with c > 3 (the north-star target's layer set), whichever kernel serves it, its fused maxpool included: each launch "
+                                      f"repeated 40 times on all {ninfl} instances at once, host wall time / launches")
+
+    # ---- energy leg (rank 0, one GPU): the in-flight step repeated for >= 0.3 s with the device's hwmon power / clock files sampled on a host
+    # thread (every 5 ms, second half of the samples: the sensor averages over a window).  Never part of `value`.
+    if extra_legs:
+        from yolo_quantization_amd.hwmon import Sampler
+        smp = Sampler(local_rank)
+        if smp.available():
+            e_steps = max(400, int(0.3 / max(ms_per_step * 1e-3, 1e-6)))
+
+            def region():
+                for nk in nets:
+                    nk.sync()
+                t0 = time.perf_counter()
+                for i in range(e_steps):
+                    nets[i % ninfl].forward()
+                for nk in nets:
+                    nk.sync()
+                return time.perf_counter() - t0
+            region()
+            e_dt, e_w, e_mhz, e_n = smp.run(region)
+            if e_w is not None:
+                energy = {"joules_per_image": round(e_w * e_dt / (e_steps * B), 6), "mean_socket_watts": round(e_w, 1), "mean_shader_mhz": round(e_mhz, 0),
+                          "ms_per_step": round(e_dt / e_steps * 1e3, 4), "steps": e_steps, "samples": e_n,
+                          "note": f"{e_steps} in-flight steps after the timed region, amdgpu hwmon power1_input / freq1_input every 5 ms (second half of the samples); "
+                                  "the chip's cap is 1 400 W: at the cap a step costs its energy, not its instruction count (DESIGN.md 4.4)"}
 
     selfcheck = None
     if args.selfcheck_passes > 0 and not args.graph:
@@ -669,6 +709,15 @@ def main():
                                          "CUs with other batches' kernels, its duration is no longer a measure of the kernel"}
         if sustained:
             roof["sustained"] = sustained
+        if sustained33:
+            roof["conv3x3_s1_aggregate"]["sustained"] = sustained33
+        c33 = roof["conv3x3_s1_aggregate"]
+        roof["north_star_target"] = ("0.40 of the dense INT8 MFMA peak wanted on the 3x3 stride-1 convs; measured over "
+                                     + (sustained33["layer_set"] if sustained33 else "those layers") + ": "
+                                     + (f"{sustained33['frac']} sustained (chip kept full of each launch), " if sustained33 else "")
+                                     + f"{c33['frac']} per launch alone on the device")
+        if energy:
+            roof["energy"] = energy
         if latency_leg and latency_leg[0]:
             n_lat, lat_prof, lat_dt, lat_rows = latency_leg
             l_rows, _, _ = layer_table(lat_prof[0], lat_prof[1], lat_dt, 32)
@@ -715,8 +764,17 @@ def main():
         if not args.no_cpu_omp and cpu and cpu["kind"] == "reference":
             # the reference's own all-cores build (Makefile MULTI_CORE=1: `#pragma omp parallel for` over the GEMM's output rows,
             # ref src/gemm.c:291) on every hardware thread of this host, bounded sample, after the timed region
+            # (its loop is `omp parallel for` over M = the layer's filters, 16 .. 1024: on a 256-thread host every thread count past a few dozen
+            # only adds fork / join cost -- 8, 32 and all threads are timed, the best is reported with its count)
             try:
-                cpu_omp = cpu_baseline(args.cfg, wts, args.cpu_omp_images, omp=True)
+                tried = []
+                for nt in sorted({8, 32, os.cpu_count() or 1}):
+                    if nt > (os.cpu_count() or 1):
+                        continue
+                    r = cpu_baseline(args.cfg, wts, args.cpu_omp_images, omp=True, threads=nt)
+                    tried.append(r)
+                cpu_omp = max(tried, key=lambda r: r["value"])
+                cpu_omp["thread_counts_tried"] = {str(r["cores"]): round(r["value"], 3) for r in tried}
             except Exception as e:  # noqa: BLE001
                 print(f"[bench] all-cores CPU baseline unavailable ({e})", file=sys.stderr)
 
@@ -726,7 +784,7 @@ def main():
                "warmup_passes_effective": args.warmup + (ninfl * args.selfcheck_passes if selfcheck else 0),  # the self-check passes are queued right in front of the warmup steps
                "ms_per_step": round(ms_per_step, 4),
                "host_issue_ms": round(t_issued * 1e3, 3),  # host time to queue the K steps of the timed region (its total is ms_per_step * steps)
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x s8 -> int32 (f64 requant)",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x s8 -> int32 (f64 or exact-integer requant, bit-identical)",
                "data": "synthetic",
                "config": {"workload": "yolov3-tiny full net (cfg/yolov3-tiny_quant.cfg, leaky, per-channel quant), "
                                       f"batch {B}/GPU synthetic uint8 {in_h}x{in_w}, inputs resident in HBM (NCHW uint8)"
@@ -741,7 +799,8 @@ def main():
                                        (f"eager launches, per-layer HIP events on every {prof_stride}th forward of instance 0" if (ninfl == 1 or args.inflight_events)
                                         else "eager launches, no events inside the timed region (per-kernel figures come from the serial leg after it)")),
                           "weight_broadcast_ms": round(bcast_ms, 3)},
-               "roofline": roof, "serial": serial, "cpu_baseline": cpu, "accum_ref_f32_mode": ref_f32, "selfcheck": selfcheck}
+               "roofline": roof, "serial": serial, "cpu_baseline": cpu if world == 1 else "see the n_gpus=1 line (timed on rank 0 at N=1 only)",
+               "accum_ref_f32_mode": ref_f32, "selfcheck": selfcheck}
         if cpu_omp:
             out["cpu_baseline_omp"] = cpu_omp
         if layers:

@@ -121,6 +121,22 @@ def test_bench_self_launch_dry_dist_world2(cfg_dir):
     assert d["image_shards"] == [[0, 64], [64, 128]]
 
 
+def test_bench_self_launch_dry_dist_world8(cfg_dir):
+    """the same with eight ranks -- BASELINE config[3]'s shape (512 images sharded 64 per GPU over 8 GPUs) on gloo: one JSON line, the eight
+    shards are 8 x 64 covering 0..512, every rank ends up with rank 0's packed bytes"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-dist", "--steps", "3", "--cfg",
+                        os.path.join(cfg_dir, "tiny_unit.cfg")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_dist"] and d["n_gpus"] == 8 and d["packed_state_identical_on_all_ranks"] and d["shards_cover_global_batch"]
+    assert d["image_shards"] == [[64 * k, 64 * k + 64] for k in range(8)]
+
+
 def test_bench_rejects_a_world_that_is_not_gpus():
     """a launcher that started another number of ranks than --gpus says is an error (rc 2), not a silent re-launch"""
     import subprocess

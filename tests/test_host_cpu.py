@@ -429,3 +429,14 @@ def test_pack_epilogue_table(n, c, act):
     # a blob packed without the second step carries no key
     plain = binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv)
     assert int(np.frombuffer(plain, np.uint32, 1, off_ept)[0]) == 0
+
+
+def test_first_layer_tile_loop_has_no_memory_wait_inside_its_mfma_chains():
+    """tools/check_l0_waits.py on the sources as they are (cross-compiles conv_aux.hip for gfx950, ~40 s): the 16-filter first-layer kernels must not
+    carry an `s_waitcnt vmcnt` between a tile's B-fragment reads and the last MFMA of the chain -- a register-allocation accident that costs a
+    memory round trip per tile and that no parity test can see."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_l0_waits.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -46,44 +46,13 @@ for k, nk in enumerate(nets):
     nk.sync()
 
 
-import glob
-import threading
+from yolo_quantization_amd.hwmon import Sampler as _Sampler  # noqa: E402
 
 
-class Sampler:
-    """mean socket power (W) and shader clock (MHz) of THIS device from its hwmon files while a phase runs"""
-    def __init__(self):
-        self.dir = None
-        try:
-            import torch
-            pr = torch.cuda.get_device_properties(0)
-            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-            d = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
-            self.dir = d[0] if d else None
-        except Exception as e:  # noqa: BLE001
-            print("power sampler unavailable:", e)
-
+class Sampler(_Sampler):
     def run(self, fn):
-        if not self.dir:
-            return fn(), None, None
-        stop = [False]
-        pw, ck = [], []
-
-        def loop():
-            while not stop[0]:
-                try:
-                    pw.append(int(open(self.dir + "/power1_input").read()) / 1e6)
-                    ck.append(int(open(self.dir + "/freq1_input").read()) / 1e6)
-                except Exception:  # noqa: BLE001
-                    pass
-                time.sleep(0.005)
-        t = threading.Thread(target=loop)
-        t.start()
-        r = fn()
-        stop[0] = True
-        t.join()
-        half = len(pw) // 2  # the second half: the sensor averages over a window
-        return r, (sum(pw[half:]) / max(len(pw[half:]), 1)), (sum(ck[half:]) / max(len(ck[half:]), 1))
+        r, pw, ck, _ = super().run(fn)
+        return r, pw, ck
 
 
 def timed(ns, reps):

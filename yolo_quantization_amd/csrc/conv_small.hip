@@ -897,10 +897,11 @@ static int mid_launch_sat(ConvArgs &a, hipStream_t st, int grid, int threads, si
 template <void (*kern)(const ConvArgs)>
 static int small_launch_kern(ConvArgs &a, hipStream_t st, int grid, size_t lds)
 {
-    static int per_cu_regs[64] = {0};  // per kernel instantiation (the template argument) and per device
+    static std::atomic<int> per_cu_regs[64];  // per kernel instantiation (the template argument) and per device; zero-initialised.  Two host
+                                              // threads that race here both compute the same value (a property of the code object): atomic, no lock
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int &pc = per_cu_regs[dev & 63];
+    int pc = per_cu_regs[dev & 63].load(std::memory_order_relaxed);
     if (pc == 0) {
         hipFuncAttributes fa;
         pc = 8;
@@ -910,6 +911,7 @@ static int small_launch_kern(ConvArgs &a, hipStream_t st, int grid, size_t lds)
         } else {
             (void)hipGetLastError();  // not fatal: the launch below must not report this query's error as its own
         }
+        per_cu_regs[dev & 63].store(pc, std::memory_order_relaxed);
     }
     if (grid > 256 * pc) grid = 256 * pc;
     return launch_big_lds<kern>(grid, 256, lds, st, a);

@@ -1,6 +1,8 @@
 // kargs.h -- kernel argument blocks and host-side launcher prototypes shared by the translation units.
 #pragma once
 #include "common.h"
+#include <atomic>
+#include <mutex>
 
 struct ConvArgs {
     const int8_t *x;
@@ -170,10 +172,14 @@ template <void (*kern)(const ConvArgs)>
 static inline bool lds_limit_for(size_t lds)
 {
     static size_t have[64] = {0};
+    static std::mutex mu;  // host threads that drive replicas of one device may first-launch the same instantiation at the same time:
+                           // the check, the attribute call and the record are one critical section (only taken when the limit has to grow)
     int dev = 0;
     (void)hipGetDevice(&dev);
+    if (lds <= 64 * 1024) return true;
+    std::lock_guard<std::mutex> lk(mu);
     size_t &h = have[dev & 63];
-    if (lds > 64 * 1024 && lds > h) {
+    if (lds > h) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         h = lds;
     }
