@@ -9,6 +9,7 @@ from yolo_quantization_amd import binding, synth
 
 pytestmark = pytest.mark.gpu
 C = binding.C
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -335,3 +336,40 @@ def test_determinism_selfcheck(cfg_dir, tmp_path):
         sums.append(int(ds.to_numpy(np.uint64, 1)[0]))
     want = int((a.astype(object) * (2 * np.arange(5000).astype(object) + 1)).sum() % (1 << 64))
     assert sums[0] == want and sums[1] != sums[0] and sums[2] != sums[0]
+
+
+def test_first_layer_tile_table_many_tiles_per_workgroup():
+    """The pooled first-layer kernel keeps its workgroup's tiles one per LANE (<= 64); the launcher must widen the grid for launches with more
+    tiles than 64 per workgroup.  A child process caps the persistent grid at 8 workgroups (MI355_L0_GRID, read once per process) so that a
+    676-tile launch needs the widening (16 workgroups x 43 tiles, XCD-wise walk) and a 70-tile one walks 9 tiles per workgroup: bytes equal
+    the oracle's conv -> requantise -> maxpool, with the host-derived epilogue table and without, on data with wrapping windows."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
+import numpy as np
+import oracle
+from yolo_quantization_amd import binding
+from test_gpu_r2_kernels import _planar_tensor, _rand_layer
+binding.init(0)
+S = binding.shim()
+for (B, H, W, ept) in ((4, 208, 416, True), (4, 208, 416, False), (2, 40, 224, True)):
+    rng = np.random.default_rng(B + H + W)
+    x = rng.integers(0, 256, (B, 3, H, W), dtype=np.uint8)
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, 16, 3, 3, 2.0 ** -8, 2.0 ** -5)
+    act, zp_act = "leaky", 23
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, 3, 3, bias, mv, sv, *((binding.ACT[act], zp_act) if ept else ())))
+    xt, keep = _planar_tensor(x)
+    d = binding.ConvDesc(16, 3, 3, 1, 1, binding.ACT[act], binding.STORE_WRAP, binding.ACC_EXACT, 7, zp_act, 0.05)
+    want = np.stack([oracle.maxpool_u8(oracle.requant(oracle.conv_acc(x[b], wq, zp_w, 3, 1, 1, 7), bias, mv, sv, zp_act, oracle.ACT[act], binding.STORE_WRAP).reshape(16, H, W), 2, 2, 1)
+                     for b in range(B)])
+    yp = binding.DevTensor(B, H // 2, W // 2, 16, zp_act)
+    binding.check(S.mi355_conv_pool_forward(C.byref(d), C.byref(xt), blob.ptr, None, yp.ref(), None), "conv+pool")
+    assert S.mi355_last_conv_kernel() == 1
+    assert np.array_equal(yp.to_nchw(), want), (B, H, W, ept)
+print("child ok")
+''' % {"root": ROOT}
+    env = dict(os.environ, MI355_L0_GRID="8")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -64,6 +64,8 @@ def main():
                 for k in range(first - 1, max(first - 9, 0), -1):
                     if "ds_read" in body[k]:
                         lo = k
+                if any("global_load" in body[k] or "scratch_load" in body[k] for k in range(lo, last)):
+                    continue  # the cold exact path of a tile (it fetches its FP64 multipliers again between the MFMAs): its waits are its own
                 for k in range(lo, last):
                     if re.search(r"s_waitcnt\s+vmcnt", body[k]):
                         print(f"{name}: `{body[k].strip()}` inside the MFMA chain at function line {first}..{last}")

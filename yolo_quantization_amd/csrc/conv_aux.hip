@@ -257,6 +257,10 @@ int conv_ref_f32_launch(AuxArgs &a, hipStream_t st)
 // cells per LDS image row of the first-layer MFMA kernels: 34 (x = 32 tx - 1 .. + 32) from the 4-byte-cell tensor; 42 when
 // the image is read from the reference's colour planes in place: whole 4-pixel groups x = 32 tx - 4 .. + 35 stored from
 // column 1, so that x = 32 tx - 1 sits at the EVEN column 4 and a lane's five-cell reads stay 8-byte aligned (ds_read_b64)
+// (round 5, measured and not kept: a row pitch of 96 dwords for the planar form.  The B reads are ds_read_b64 -- sixteen lanes x 8 contiguous bytes per
+// cycle = all 32 banks once, whatever the pitch; the kernel's bank conflicts (SQ_LDS_BANK_CONFLICT 1.15 M of 5.9 M LDS cycles per launch) are the
+// staging's ds_write2_b32 pairs (lanes 16 bytes apart, two dwords each: sixteen of the 32 banks, twice) and the byte-table reads, and with a pitch
+// that is a multiple of 32 dwords the staged rows all start in the same bank as well: 2.8 M conflict cycles, 32.9 -> 36 us.)
 __host__ __device__ constexpr int first_stage_rowc(bool planar) { return planar ? 42 : 34; }
 
 // The first-layer pooled kernels' exact path: every value of the 2x2 window requantised, then the maximum of the BYTES (the reference's
@@ -380,24 +384,6 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         soff[k] = r * W1 + c;
     }
     const uint32_t *xc = reinterpret_cast<const uint32_t *>(a.x);
-    // tile walk without per-tile divisions: (b, ty, tx) advances by the decomposition of gridDim.x with carries
-    struct Pos { int b, ty, tx; };
-    auto pos_of = [&](int t) {  // (divisions by launch constants: common.h FastDiv, set by the launcher)
-        Pos p;
-        p.b = fd_div(t, a.fd_tpi);
-        const int r = t - p.b * tpi;
-        p.ty = fd_div(r, a.fd_tx);
-        p.tx = r - p.ty * tiles_x;
-        return p;
-    };
-    const Pos step = pos_of(((gridDim.x & 7) == 0 && !(a.debug_flags & 2048)) ? (int)(gridDim.x >> 3) : (int)gridDim.x);
-    auto advance = [&](Pos &p) {
-        p.tx += step.tx;
-        p.ty += step.ty;
-        p.b += step.b;
-        if (p.tx >= tiles_x) { p.tx -= tiles_x; ++p.ty; }
-        if (p.ty >= tiles_y) { p.ty -= tiles_y; ++p.b; }
-    };
     // PLANAR (the reference's [B][3][H][W] uint8 planes read in place: no layout conversion pass): thread t < 180 owns image
     // row t / 10 and the 4-pixel group t % 10 of the 40-cell LDS row (image x = 32 tx - 4 + 4 q .. + 3): one aligned dword
     // from each colour plane, interleaved into four (c0, c1, c2, 0) cells on the way into LDS.  W % 4 == 0, so a group is
@@ -406,38 +392,74 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
     const uint32_t zsplat = (uint32_t)a.zp_in * 0x01010101u;
     const size_t plane_sz = (size_t)a.H * a.W;
     const int planar_off = (prow_ix - 1) * a.W + 4 * pq - 4;  // byte offset of this thread's group from the tile's (16 ty, 32 tx)
-    // (the kernel is bound by its instruction ISSUE: VALU + scalar + LDS + memory instructions x 4 clocks account for its run time,
-    // SQ counters in profiles/ -- so the common case pays for as few of any kind as possible: tiles that do not touch the image border
-    // load without per-lane tests, everything a launch decides once is decided outside the tile loop)
-    const unsigned offv = (unsigned)(planar_off + (int)plane_sz);  // the thread's group from (tile origin - one plane): never negative
-    auto fetch = [&](const Pos &p, uint32_t(&v)[3]) {  // cell indices fit an int (the launcher checks in_cells)
+    // the thread's group of colour plane k from (tile origin - one plane): never negative, 32 bits (the launcher refuses inputs of 2 GiB and more)
+    unsigned offk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) offk[k] = (unsigned)(planar_off + (int)plane_sz) + (unsigned)k * (unsigned)plane_sz;
+    const uint8_t *const xm1 = a.x - plane_sz;  // (only ever dereferenced one plane or more further on)
+
+    // ---- The workgroup's tiles, ONE LANE PER TILE (round 5).  Rounds 1-4 carried the tile position (b, ty, tx) in scalar registers and advanced it
+    // with carries, then derived the input origin, the "interior tile" test, the output offset and the "whole patch inside the map" test from it:
+    // ~60 scalar instructions per tile, and this kernel runs at one instruction of ANY kind per issue slot -- its scalar stream
+    // was as long as its vector stream (SQ_INSTS_SALU 10.7 M = SQ_INSTS_VALU per launch).  A persistent workgroup walks at most 64 tiles (the
+    // launcher sizes the grid so), so lane l of every wave computes tile l's three words ONCE, in parallel, and the loop fetches them with
+    // v_readlane: input origin, output offset, flags (bit 0: no cell of the 18 x 40 input patch lies outside the image, bit 1: the whole 8 x 16
+    // pooled patch lies inside the pooled map, bits 2-11 tx, bits 12-21 ty for the border cases).
+    // XCD-aware order as before: workgroup id w runs on XCD w % 8 (each with its own L2); neighbouring tiles share the cache lines of their halo
+    // columns / rows, so every XCD takes one CONTIGUOUS eighth of the tiles and its workgroups walk it side by side.
+    const bool xcd_walk = (gridDim.x & 7) == 0 && !(a.debug_flags & 2048);
+    const int per_x = xcd_walk ? (ntiles + 7) >> 3 : ntiles;
+    const int tstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int tbase_x = xcd_walk ? (int)(blockIdx.x & 7) * per_x : 0;
+    const int tend = min(tbase_x + per_x, ntiles);
+    const int tile0 = tbase_x + (xcd_walk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+    unsigned T_in, T_out, T_fl;
+    int nt;
+    {
+        const int t = tile0 + lane * tstride;
+        nt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(t < tend));  // this workgroup's tiles (<= 64)
+        const int tc = min(t, ntiles - 1);
+        const int b = fd_div(tc, a.fd_tpi);  // (divisions by launch constants: common.h FastDiv, set by the launcher)
+        const int r = tc - b * tpi;
+        const int ty = fd_div(r, a.fd_tx), tx = r - ty * tiles_x;
+        if constexpr (PLANAR) T_in = ((unsigned)b * 3u) * (unsigned)plane_sz + (unsigned)(16 * ty) * (unsigned)a.W + 32u * (unsigned)tx;
+        else T_in = (unsigned)(a.in_lead + (b * (a.H + 1) + 16 * ty) * W1 + 32 * tx - 1);  // image cell (0, 0) of the patch (fits an int: the launcher checks in_cells)
+        T_out = (unsigned)(a.pool_lead + (b * (OH + 1) + 8 * ty + 1) * (OW + 1) + 16 * tx) * (unsigned)a.pool_cs;
+        // rows 16 ty - 1 .. 16 ty + 16, columns 32 tx - 4 .. 32 tx + 35 all inside the image: no lane needs the pad value
+        const bool tin = ty >= 1 && 16 * ty + 16 < a.H && tx >= 1 && 32 * tx + 32 < a.W;
+        const bool tall = 16 * tx + 16 <= OW && 8 * ty + 8 <= OH;
+        T_fl = (tin ? 1u : 0u) | (tall ? 2u : 0u) | ((unsigned)tx << 2) | ((unsigned)ty << 12);
+    }
+    auto tile_word = [&](unsigned v, int k) { return (unsigned)__builtin_amdgcn_readlane((int)v, k); };  // wave-uniform k
+
+    auto fetch = [&](unsigned org, unsigned fl, uint32_t(&v)[3]) {
         if constexpr (PLANAR) {
-            // wave-uniform tile base on the scalar unit + the thread's loop-invariant 32-bit offset (scalar-base loads)
-            // (32-bit: the launcher refuses inputs of 2 GiB and more)
-            const unsigned tb = ((unsigned)p.b * 3u) * (unsigned)plane_sz + (unsigned)(16 * p.ty) * (unsigned)a.W + 32u * (unsigned)p.tx;
-            const uint8_t *tbase = a.x + (size_t)tb - plane_sz;
-            // rows 16 ty - 1 .. 16 ty + 16, columns 32 tx - 4 .. 32 tx + 35 all inside the image: no lane needs the pad value
-            const bool tin = p.ty >= 1 && 16 * p.ty + 16 < a.H && p.tx >= 1 && 32 * p.tx + 32 < a.W;
-            if (tin) {
-                if (tid < 180) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) v[k] = *reinterpret_cast<const uint32_t *>(tbase + offv + (size_t)k * plane_sz);
-                }
+            // wave-uniform base on the scalar unit + the thread's loop-invariant 32-bit offsets, in the instruction's scalar-base form.  Written by
+            // hand: the compiler widens the loop-invariant offsets to 64 bits outside the loop and then adds base and offset on the VALU (three
+            // v_lshl_add_u64 per tile, six registers) -- and like the deferred stores these loads are invisible to its wait-count model, which
+            // therefore never has a reason to put a vmcnt wait into the tile loop (see `run`); `land` below is the one wait, right in front of
+            // the staging that consumes the three dwords.
+            const uint64_t tb = reinterpret_cast<uint64_t>(xm1) + (uint64_t)org;
+            const uint64_t tbs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tb);
+            auto load3 = [&]() {
+                asm volatile("global_load_dword %0, %3, %6\n\tglobal_load_dword %1, %4, %6\n\tglobal_load_dword %2, %5, %6"
+                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+                             : "v"(offk[0]), "v"(offk[1]), "v"(offk[2]), "s"(tbs)
+                             : "memory");
+            };
+            if (fl & 1u) {
+                if (tid < 180) load3();
             } else {  // out-of-image groups are the input zero point
-                const int y = 16 * p.ty - 1 + prow_ix, x0 = 32 * p.tx - 4 + 4 * pq;
+                const int tx = (int)((fl >> 2) & 1023u), ty = (int)((fl >> 12) & 1023u);
+                const int y = 16 * ty - 1 + prow_ix, x0 = 32 * tx - 4 + 4 * pq;
                 const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x0 < (unsigned)a.W && tid < 180;
-                if (inside) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) v[k] = *reinterpret_cast<const uint32_t *>(tbase + offv + (size_t)k * plane_sz);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) v[k] = zsplat;
-                }
+                for (int k = 0; k < 3; ++k) v[k] = zsplat;
+                if (inside) load3();
             }
         } else {
-            const int org = a.in_lead + (p.b * (a.H + 1) + 16 * p.ty) * W1 + 32 * p.tx - 1;  // image cell (0, 0)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) v[k] = xc[min(max(org + soff[k], 0), a.in_cells - 1)];
+            for (int k = 0; k < 3; ++k) v[k] = xc[min(max((int)org + soff[k], 0), a.in_cells - 1)];
         }
     };
     auto stash = [&](int buf, const uint32_t(&v)[3]) {
@@ -463,19 +485,13 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         }
     };
 
-    // XCD-aware tile walk: workgroup id b runs on XCD b % 8 (each with its own L2).  Neighbouring tiles share the cache lines
-    // of their halo columns / rows, so every XCD takes one CONTIGUOUS eighth of the tiles and its workgroups walk it side by
-    // side: tile = xcd * per + idx, idx = b / 8 + k * (gridDim / 8).  (Plain b + k * gridDim put neighbours on different
-    // XCDs: 2.3x - 3x the input bytes fetched, profiles/r01_v6_pmc_traffic.json, r02_v1_pmc_traffic.json.)
-    const bool xcd_walk = (gridDim.x & 7) == 0 && !(a.debug_flags & 2048);
-    const int per_x = xcd_walk ? (ntiles + 7) >> 3 : ntiles;
-    const int tstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-    const int tbase_x = xcd_walk ? (int)(blockIdx.x & 7) * per_x : 0;
-    const int tend = min(tbase_x + per_x, ntiles);
-    int tile = tbase_x + (xcd_walk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
-    Pos cur = pos_of(tile), nxp = cur;
-    uint32_t nxt[3];
-    if (tile < tend) fetch(cur, nxt);
+    // the prefetched dwords have landed (PLANAR: hand-written loads, so this is the wait; the operands tie every later use of the registers to it)
+    auto land = [&](uint32_t(&v)[3]) {
+        if constexpr (PLANAR) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])::"memory");
+    };
+    uint32_t nxt[3] = {0, 0, 0};
+    unsigned fl_cur = tile_word(T_fl, 0);
+    if (nt > 0) fetch(tile_word(T_in, 0), fl_cur, nxt);
     // (the first tile's image is on its way: the per-lane records below share its latency)
     const bool ept_ok = have_ept && ekey == ept_key(ACT, a.zp_act);  // workgroup-uniform
     bool pow2, never, use_int, need_d2;
@@ -562,32 +578,34 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
 #pragma unroll
         for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(qc[mt][r]));  // opaque: the compiler otherwise factors u * M0 + lo * M0 back into (u + lo) * M0 as a 64 x 32 multiply
 
-    if (tile < tend) stash(0, nxt);
+    if (nt > 0) {
+        land(nxt);
+        stash(0, nxt);
+    }
     // Every register loaded so far (weights, per-channel constants) is in: without this the compiler has to keep an
     // s_waitcnt vmcnt(0) in front of the first MFMA of the (shared) loop body, which then also waits for the image
     // prefetch issued a few instructions earlier and for the previous tile's stores -- a memory round trip per tile.
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    // A tile's packed bytes are stored one tile LATE, right after the next tile's prefetch: vmcnt counts loads and stores alike, the
-    // stores sit behind exec-masked branches (so the compiler cannot count them and guards the staging registers with vmcnt(0)), and
-    // issued in place they put a store round trip to HBM in front of every tile's staging wait.  Issued behind the prefetch they have a
-    // whole tile to drain, like the prefetch (in front of it they would be what the compiler's vmcnt(0) ahead of the loads waits for).
-    uint32_t dpk[2][NM];
-    uint8_t *dout[2] = {a.ypool, a.ypool};
-    bool dvalid[2] = {false, false};
-    bool dall = false;  // wave-uniform: every lane of the deferred tile stores
-    // Written by hand in the scalar-base form (wave-uniform row pointer + the lane's loop-invariant 32-bit offset: no 64-bit address add per
-    // store) and, above all, OPAQUE to the compiler's wait-count model: a dword store reads its data register at issue, but when the register
-    // allocator hands that register to the next MFMA chain's accumulators the compiler guards the reuse with s_waitcnt vmcnt(0) -- a full
-    // memory round trip (prefetch loads included) in front of the tile's third MFMA.  Whether that happened was allocation luck: round 5's
-    // prologue change moved one register and the hot loop went from 3 150 to 4 120 clocks per tile (tools/l0_phases.py: "row 0: B reads +
-    // MFMA chain" 485 -> 1 416).  The compiler's own vmcnt counts for the prefetch stay valid: the stores are YOUNGER than the loads they
-    // follow, so a wait for "all but the k youngest loads" can only wait longer, never too short.
-    unsigned st_off[NM];
+    // A tile's packed bytes are stored one tile LATE, right after the next tile's prefetch: vmcnt counts loads and stores alike, and issued
+    // in place they put a store round trip to HBM in front of every tile's staging wait.  Issued behind the prefetch they have a whole tile
+    // to drain, like the prefetch.
+    // Written by hand in the scalar-base form (wave-uniform patch pointer + the lane's loop-invariant 32-bit offset: no 64-bit address add per
+    // store) and OPAQUE to the compiler's wait-count model (see the comment at the top of `run`).  The compiler's own vmcnt counts for the
+    // prefetch stay valid: the stores are YOUNGER than the loads they follow, so a wait for "all but the k youngest loads" can only wait
+    // longer, never too short.
+    const unsigned rowpitch = (unsigned)(OW + 1) * (unsigned)a.pool_cs;
+    unsigned st_off[2][NM];  // pooled rows 2 wave, 2 wave + 1 of the patch; the lane's pooled column; channels 16 mt + 4 g ..
 #pragma unroll
-    for (int mt = 0; mt < NM; ++mt) st_off[mt] = pc_off + (unsigned)chq[mt];
-    auto store_row = [&](const uint8_t *rowp, unsigned off, uint32_t data) {
-        // (the row pointer is wave-uniform by construction; where the compiler cannot prove it, readfirstlane puts it into scalar registers)
-        const uint64_t rp = reinterpret_cast<uint64_t>(rowp);
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < NM; ++mt) st_off[s][mt] = (unsigned)(2 * wave + s) * rowpitch + pc_off + (unsigned)chq[mt];
+    uint32_t dpk[2][NM];
+    unsigned d_out = 0;  // wave-uniform: byte offset of the deferred patch's first pooled cell
+    bool dvalid[2] = {false, false};
+    bool dall = false;   // wave-uniform: every lane of the deferred tile stores
+    auto store_patch = [&](unsigned patch_off, unsigned off, uint32_t data) {
+        // (the patch pointer is wave-uniform by construction; readfirstlane puts it into scalar registers where the compiler cannot prove it)
+        const uint64_t rp = reinterpret_cast<uint64_t>(a.ypool) + (uint64_t)patch_off;
         const uint64_t rs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rp);
         asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(data), "s"(rs) : "memory");
     };
@@ -596,18 +614,16 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int mt = 0; mt < NM; ++mt) store_row(dout[s], st_off[mt], dpk[s][mt]);
+                for (int mt = 0; mt < NM; ++mt) store_patch(d_out, st_off[s][mt], dpk[s][mt]);
         } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 if (dvalid[s]) {
 #pragma unroll
-                    for (int mt = 0; mt < NM; ++mt) store_row(dout[s], st_off[mt], dpk[s][mt]);
+                    for (int mt = 0; mt < NM; ++mt) store_patch(d_out, st_off[s][mt], dpk[s][mt]);
                 }
         }
     };
-    const unsigned rowpitch = (unsigned)(OW + 1) * (unsigned)a.pool_cs;
-    const unsigned wave_row_off = (unsigned)(2 * wave) * rowpitch;  // this wave's first pooled row inside a patch
     const int lane_b = ((g < 3 ? g : 2) * ROWC + 2 * pc + XO) * 4 + 2 * wave * 2 * ROWC * 4;  // the lane's operand bytes inside an image buffer
     L0P_DECL;
     // FASTC: power-of-two shifts, no channel without a wrap-safe range and (where the activation has an integer requantisation) every
@@ -621,88 +637,89 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         // along that infeasible path the next loop inherits the previous loop's prefetch as "still pending": when the register allocator
         // reuses one of THOSE destination registers for an MFMA accumulator the model demands s_waitcnt vmcnt(0) in front of the tile's third
         // MFMA -- a memory round trip per tile that no executed path needs (round 5: 3 150 -> 4 120 clocks per tile after an unrelated prologue
-        // change moved the allocation; rounds 2-4 met the same effect as "allocation luck").  Executed once per kernel: free.
+        // change moved the allocation; rounds 2-4 met the same effect as "allocation luck").  Executed once per kernel: free.  (The caller
+        // also ends every instantiation with its own copy of the kernel's tail and a return.)
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        for (; tile < tend; tile += tstride, buf ^= 1, cur = nxp) {
+        // the two image rows x four cells (x = 2 pcol - 1 .. 2 pcol + 2) that feed the four window positions of this lane's k-group for pooled
+        // row s of the wave: one aligned 16-byte operand per row (8-byte aligned in LDS: two dwords each from a ds_read2_b64)
+        auto read_b = [&](const char *ib, int s, v4i (&bf)[2]) {
+            const uint32_t *p0 = reinterpret_cast<const uint32_t *>(ib + s * 2 * ROWC * 4);
+#pragma unroll
+            for (int jy = 0; jy < 2; ++jy) {
+                const uint2 q0 = *reinterpret_cast<const uint2 *>(p0 + jy * ROWC), q1 = *reinterpret_cast<const uint2 *>(p0 + jy * ROWC + 2);
+                bf[jy] = v4i{(int)q0.x, (int)q0.y, (int)q1.x, (int)q1.y};
+            }
+        };
+        auto chain = [&](int mt, const v4i (&bf)[2], v4i (&acc)[4]) {
+            __builtin_amdgcn_s_setprio(3);  // the MFMA chain outranks the other waves' requantisation
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[mt][j & 1], bf[j >> 1], cb[mt], 0, 0, 0);
+            // the correction passes as their own rounds over the four (independent) window positions
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd1[mt][j & 1], bf[j >> 1], acc[j], 0, 0, 0);
+            if constexpr (D2C) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt][j & 1], bf[j >> 1], acc[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        for (int k = 0; k < nt; ++k, buf ^= 1) {
             L0P_MARK(6);
             __syncthreads();  // this tile's image is complete; every wave is past the previous tile
             L0P_MARK(0);
-            const bool more = tile + tstride < tend;
-            advance(nxp);
-            if (more) fetch(nxp, nxt);
+            const bool more = k + 1 < nt;
+            unsigned fl_nxt = 0;
+            if (more) {
+                fl_nxt = tile_word(T_fl, k + 1);
+                fetch(tile_word(T_in, k + 1), fl_nxt, nxt);
+            }
             L0P_MARK(1);
 #ifndef MI355_L0_STORES_IN_PLACE
             flush_stores();
 #endif
             L0P_MARK(2);
-            const int b = cur.b, ty = cur.ty, tx = cur.tx;
-            // byte offset of the patch's first pooled cell: wave-uniform 32-bit arithmetic on the scalar unit (the launcher refuses pooled
-            // tensors of 4 GiB and more), once per tile; a pooled row further down is one row pitch on.  The store then is
-            // "scalar base + the lane's loop-invariant 32-bit offset".
-            const unsigned tile_off = (unsigned)(a.pool_lead + (b * (OH + 1) + 8 * ty + 1) * (OW + 1) + 16 * tx) * (unsigned)a.pool_cs;
-            uint8_t *const outp0 = a.ypool + (size_t)(tile_off + wave_row_off);  // wave-uniform
-            const bool tall = 16 * tx + 16 <= OW && 8 * ty + 8 <= OH;           // the whole patch lies inside the pooled map
             const char *const ib = reinterpret_cast<const char *>(img[buf]) + lane_b;
+            if constexpr (FASTC) {
+                // ---- the common launch: every window's maximum is requantised in its integer / FP64-of-maximum form with NO test in the way;
+                // the range test is carried along as a per-lane minimum (rg -sat- umax == 0 <=> some accumulator of the window lies at or
+                // beyond the end of the wrap-safe range) and looked at ONCE per tile: a wave that sees one redoes its two pooled rows in the
+                // reference's order (bytes first, then the maximum) -- rare, and then exact.
+                uint32_t margin = 0xFFFFFFFFu;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                // two image rows x four cells (x = 2 pcol - 1 .. 2 pcol + 2) feed the four window positions of this lane's k-group:
-                // one aligned 16-byte operand per row (8-byte aligned in LDS: two dwords each from a ds_read2_b64)
-                const uint32_t *p0 = reinterpret_cast<const uint32_t *>(ib + s * 2 * ROWC * 4);
-                v4i bf[2];
+                for (int s = 0; s < 2; ++s) {
+                    v4i bf[2];
+                    read_b(ib, s, bf);
 #pragma unroll
-                for (int jy = 0; jy < 2; ++jy) {
-                    const uint2 q0 = *reinterpret_cast<const uint2 *>(p0 + jy * ROWC), q1 = *reinterpret_cast<const uint2 *>(p0 + jy * ROWC + 2);
-                    bf[jy] = v4i{(int)q0.x, (int)q0.y, (int)q1.x, (int)q1.y};
-                }
+                    for (int mt = 0; mt < NM; ++mt) {
+                        v4i acc[4];
+                        chain(mt, bf, acc);
+                        L0P_MARK_V(2 + 2 * s, acc[3][0]);
+                        uint32_t umax[4];
 #pragma unroll
-                for (int mt = 0; mt < NM; ++mt) {
-                    v4i acc[4];
-                    __builtin_amdgcn_s_setprio(3);  // the MFMA chain outranks the other waves' requantisation
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[mt][j & 1], bf[j >> 1], cb[mt], 0, 0, 0);
-                    // the correction passes as their own rounds over the four (independent) window positions
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd1[mt][j & 1], bf[j >> 1], acc[j], 0, 0, 0);
-                    if constexpr (D2C) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd2[mt][j & 1], bf[j >> 1], acc[j], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_s_setprio(0);
-                    L0P_MARK_V(2 + 2 * s, acc[3][0]);
-                    // accumulators are biased by lo: one unsigned maximum gives the range test and the window maximum (common.h)
-                    uint32_t umax[4];
-                    // the four range tests as wave masks on the scalar unit (one v_cmp each; no per-lane flag to build and ballot)
-                    uint64_t badm = (!FASTC && never) ? ~0ull : 0ull;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        umax[r] = max(max((uint32_t)acc[0][r], (uint32_t)acc[1][r]), max((uint32_t)acc[2][r], (uint32_t)acc[3][r]));
-                        badm |= __builtin_amdgcn_ballot_w64(umax[r] > (uint32_t)hi[mt][r]);
-                    }
-                    uint32_t packed;
-                    if (badm == 0 && (FASTC || pow2)) {
-                        if (INTRQ && (FASTC || use_int)) {  // two integer instructions per value instead of convert / FP64 multiply / convert
-                            // f = floor(a * M0 / 2^(32 + sh)), a = u + lo:  v_mad_u64_u32 (u * M0 + lo * M0, exact mod 2^64: |a * M0| < 2^53),
-                            // then an arithmetic shift of the high dword
+                        for (int r = 0; r < 4; ++r) {
+                            umax[r] = max(max((uint32_t)acc[0][r], (uint32_t)acc[1][r]), max((uint32_t)acc[2][r], (uint32_t)acc[3][r]));
+                            margin = min(margin, __builtin_elementwise_sub_sat((uint32_t)hi[mt][r], umax[r]));
+                        }
+                        uint32_t packed;
+                        if constexpr (INTRQ) {  // f = floor(a * M0 / 2^(32 + sh)), a = u + lo: v_mad_u64_u32 (u * M0 + lo * M0, exact mod 2^64), then a shift of the high dword
                             int32_t f[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const uint64_t p = (uint64_t)umax[r] * (uint64_t)(uint32_t)qm0[mt][r] + (uint64_t)qc[mt][r];
                                 f[r] = (int32_t)(uint32_t)(p >> 32) >> qsh[mt][r];
                             }
-#ifndef MI355_L0_LEAKY_ARITH
                             if constexpr (LUT) {
+#ifndef MI355_L0_LEAKY_ARITH
                                 uint32_t bt[4];
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) bt[r] = lut[f[r] + LUTQ_OFF];
+                                for (int r = 0; r < 4; ++r) bt[r] = lut[f[r] + LUTQ_OFF];  // (a window beyond the range may index anywhere: an LDS read outside the
+                                                                                              // workgroup's allocation returns 0, and the tile is redone below)
                                 packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
-                            } else
-#else
-                            if constexpr (LUT) {  // A/B build: LEAKY in four VALU instructions on the floor form instead of the table's LDS round trip
+#else  // A/B build: LEAKY in four VALU instructions on the floor form instead of the table's LDS round trip
                                 packed = pack4_biased(leaky_of_floor(f[0], a.zp_act), leaky_of_floor(f[1], a.zp_act), leaky_of_floor(f[2], a.zp_act),
                                                       leaky_of_floor(f[3], a.zp_act));
-                            } else
 #endif
-                            {  // RELU6: zp + max(q, 0) == zp + max(f, 0); SAT clamps
+                            } else {  // RELU6: zp + max(q, 0) == zp + max(f, 0); SAT clamps
                                 int32_t v[4];
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
@@ -711,27 +728,6 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                                 }
                                 packed = pack4_biased(v[0], v[1], v[2], v[3]);
                             }
-                        } else if constexpr (LUT) {  // q of a window inside the safe range lies inside the table (common.h)
-                            int32_t amax[4][1];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
-                            // four independent chains, issued pass by pass: left alone the compiler threads all four conversions through
-                            // one register pair and every FP64 instruction waits out the latency of the one before it
-                            uint32_t bt[4];
-                            double dd[4];
-                            int32_t qq[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) dd[r] = (double)amax[r][0];
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) dd[r] = dd[r] * mp[mt][r];
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) qq[r] = (int32_t)dd[r];
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) bt[r] = lut[qq[r] + LUTQ_OFF];
-                            packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
                         } else {
                             int32_t amax[4][1], v1[4][1];
 #pragma unroll
@@ -739,28 +735,135 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                             requant_values<ACT, SAT, 1>(amax, mp[mt], a.zp_act, v1);
                             packed = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
                         }
-                    } else {  // some window of this wave may wrap (or odd shifts): the reference's order, bytes first, then the maximum
-                        packed = first_pool_exact_path<ACT, SAT>(acc, lo[mt], mp[mt], a.mval + chq[mt], a.sval + chq[mt], a.zp_act, FASTC ? true : pow2);
+                        dpk[s][mt] = packed;
+                        L0P_MARK_V(3 + 2 * s, packed);
                     }
-                    dpk[s][mt] = packed;
-                    L0P_MARK_V(3 + 2 * s, packed);
                 }
-                dout[s] = outp0 + s * rowpitch;
+                if (__builtin_amdgcn_ballot_w64(margin == 0u) != 0) {  // some window of this wave may wrap: the reference's order for both pooled rows
+#pragma unroll 1
+                    for (int s = 0; s < 2; ++s) {
+                        v4i bf[2];
+                        read_b(ib, s, bf);
+#pragma unroll
+                        for (int mt = 0; mt < NM; ++mt) {
+                            v4i acc[4];
+                            chain(mt, bf, acc);
+                            uint32_t ex;
+                            if constexpr (INTRQ) {
+                                // (the integer form's hot loop needs neither the FP64 multipliers nor the range's lower end: this cold path fetches
+                                // them again -- lo = (cw + bias) - seed -- instead of holding twelve registers across the loop; the kernel sits at
+                                // the 128-register edge of four waves per SIMD)
+                                double mpr[4];
+                                v4i lor;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    mpr[r] = a.mprime[chq[mt] + r];
+                                    lor[r] = (int32_t)((uint32_t)a.cwb[chq[mt] + r] - (uint32_t)cb[mt][r]);
+                                }
+                                ex = first_pool_exact_path<ACT, SAT>(acc, lor, mpr, a.mval + chq[mt], a.sval + chq[mt], a.zp_act, true);
+                            } else {
+                                ex = first_pool_exact_path<ACT, SAT>(acc, lo[mt], mp[mt], a.mval + chq[mt], a.sval + chq[mt], a.zp_act, true);
+                            }
+                            if (s == 0) dpk[0][mt] = ex; else dpk[1][mt] = ex;
+                        }
+                    }
+                }
+            } else {
+                // ---- the general launch (shifts that are not powers of two, a channel without a wrap-safe range or outside the integer form's
+                // conditions): tested per pooled row, as rounds 2-4 did for every launch
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    v4i bf[2];
+                    read_b(ib, s, bf);
+#pragma unroll
+                    for (int mt = 0; mt < NM; ++mt) {
+                        v4i acc[4];
+                        chain(mt, bf, acc);
+                        L0P_MARK_V(2 + 2 * s, acc[3][0]);
+                        // accumulators are biased by lo: one unsigned maximum gives the range test and the window maximum (common.h)
+                        uint32_t umax[4];
+                        uint64_t badm = never ? ~0ull : 0ull;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            umax[r] = max(max((uint32_t)acc[0][r], (uint32_t)acc[1][r]), max((uint32_t)acc[2][r], (uint32_t)acc[3][r]));
+                            badm |= __builtin_amdgcn_ballot_w64(umax[r] > (uint32_t)hi[mt][r]);
+                        }
+                        uint32_t packed;
+                        if (badm == 0 && pow2) {
+                            if (INTRQ && use_int) {
+                                int32_t f[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const uint64_t p = (uint64_t)umax[r] * (uint64_t)(uint32_t)qm0[mt][r] + (uint64_t)qc[mt][r];
+                                    f[r] = (int32_t)(uint32_t)(p >> 32) >> qsh[mt][r];
+                                }
+                                if constexpr (LUT) {
+                                    uint32_t bt[4];
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) bt[r] = lut[f[r] + LUTQ_OFF];
+                                    packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
+                                } else {  // RELU6: zp + max(q, 0) == zp + max(f, 0); SAT clamps
+                                    int32_t v[4];
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        v[r] = a.zp_act + max(f[r], 0);
+                                        if (SAT) v[r] = min(v[r], 255);
+                                    }
+                                    packed = pack4_biased(v[0], v[1], v[2], v[3]);
+                                }
+                            } else if constexpr (LUT) {  // q of a window inside the safe range lies inside the table (common.h)
+                                int32_t amax[4][1];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
+                                // four independent chains, issued pass by pass: left alone the compiler threads all four conversions through
+                                // one register pair and every FP64 instruction waits out the latency of the one before it
+                                uint32_t bt[4];
+                                double dd[4];
+                                int32_t qq[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dd[r] = (double)amax[r][0];
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dd[r] = dd[r] * mp[mt][r];
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) qq[r] = (int32_t)dd[r];
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) bt[r] = lut[qq[r] + LUTQ_OFF];
+                                packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
+                            } else {
+                                int32_t amax[4][1], v1[4][1];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[mt][r]);
+                                requant_values<ACT, SAT, 1>(amax, mp[mt], a.zp_act, v1);
+                                packed = pack4_biased(v1[0][0], v1[1][0], v1[2][0], v1[3][0]);
+                            }
+                        } else {  // some window of this wave may wrap (or odd shifts): the reference's order, bytes first, then the maximum
+                            packed = first_pool_exact_path<ACT, SAT>(acc, lo[mt], mp[mt], a.mval + chq[mt], a.sval + chq[mt], a.zp_act, pow2);
+                        }
+                        dpk[s][mt] = packed;
+                        L0P_MARK_V(3 + 2 * s, packed);
+                    }
+                }
             }
-            dall = tall;
-            if (!tall) {
+            // the deferred stores of this tile: the patch's first pooled cell (tile word) + per-lane offsets; lanes outside the pooled map
+            // (ragged right / lower patches) are masked
+            d_out = tile_word(T_out, k);
+            dall = (fl_cur & 2u) != 0;
+            if (!dall) {
+                const int tx = (int)((fl_cur >> 2) & 1023u), ty = (int)((fl_cur >> 12) & 1023u);
                 const bool colvalid = 16 * tx + pc < OW;
                 dvalid[0] = colvalid && 8 * ty + 2 * wave < OH;
                 dvalid[1] = colvalid && 8 * ty + 2 * wave + 1 < OH;
             }
+            fl_cur = fl_nxt;
 #ifdef MI355_L0_STORES_IN_PLACE  // A/B builds: the stores in place, in front of the staging wait
             flush_stores();
 #endif
-#ifdef MI355_ABLATE
             L0P_MARK(6);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more) land(nxt);
             L0P_MARK(8);  // the prefetch (and the deferred stores) landed
-#endif
             if (more) stash(buf ^ 1, nxt);
 #ifdef MI355_ABLATE
             L0P_MARK(9);  // staging: permutes + LDS writes
@@ -1092,7 +1195,15 @@ int conv_first_mfma_pool_launch(AuxArgs &a, hipStream_t st)
     if (ntiles >= (1L << 31)) return MI355_EINVAL;
     a.fd_tx = fastdiv_make((uint32_t)((OW + 15) / 16));
     a.fd_tpi = fastdiv_make((uint32_t)(((OW + 15) / 16) * ((OH + 7) / 8)));
-    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // persistent: four workgroups per CU (five measured slower)
+    if ((OW + 15) / 16 > 1023 || (OH + 7) / 8 > 1023) return MI355_EINVAL;  // the kernel's tile words hold tx, ty in ten bits each
+    // persistent: four workgroups per CU (five measured slower) -- and never more than 64 tiles per workgroup (one lane per tile in the kernel's
+    // tile table), whichever eighth of the tiles an XCD takes: (grid / 8) * 64 >= ceil(ntiles / 8)
+    static const int grid_cap = getenv("MI355_L0_GRID") ? atoi(getenv("MI355_L0_GRID")) : 1024;  // (A/B runs)
+    long g = ntiles < grid_cap ? ntiles : grid_cap;
+    const long need = (((ntiles + 7) / 8 + 63) / 64) * 8;
+    if (g < need) g = need;
+    if (g >= (1L << 31)) return MI355_EINVAL;
+    const int grid = (int)g;
     if (a.n == 16) {
         if (a.act == MI355_ACT_LEAKY) return first_mfma_launch_sat<MI355_ACT_LEAKY, 1>(a, st, grid);
         if (a.act == MI355_ACT_RELU6) return first_mfma_launch_sat<MI355_ACT_RELU6, 1>(a, st, grid);

@@ -553,6 +553,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, (BM / WMW > 64 ? 1 : 2)) void conv_
     using std::integral_constant;
     if (DBG(64)) {
     } else if (fast) {
+#ifdef MI355_EPI_ONE  // A/B build: only the epilogue the benchmarked launch needs is instantiated -- is the cold epilogue an instruction-fetch problem?
+        epi_fast(integral_constant<int, MI355_ACT_LEAKY>{}, integral_constant<int, 0>{});
+    }
+    if (false) {
+#endif
         const bool sat = a.store_mode == MI355_STORE_SATURATE;
         if (a.act == MI355_ACT_LEAKY) {
             if (sat) epi_fast(integral_constant<int, MI355_ACT_LEAKY>{}, integral_constant<int, 1>{});
@@ -564,7 +569,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, (BM / WMW > 64 ? 1 : 2)) void conv_
             if (sat) epi_fast(integral_constant<int, MI355_ACT_LINEAR>{}, integral_constant<int, 1>{});
             else epi_fast(integral_constant<int, MI355_ACT_LINEAR>{}, integral_constant<int, 0>{});
         }
-    } else {
+    }
+#ifndef MI355_EPI_ONE
+    else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int ocl = wm * TM + mi * 16 + 4 * kq;  // 4 consecutive filters held by this lane
@@ -608,6 +615,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (BM / WMW > 64 ? 1 : 2)) void conv_
             for (int ns = 0; ns < NS; ++ns) *reinterpret_cast<uint32_t *>(otile + nl_[ns] * OSTR + ocl) = packed[ns];
         }
     }
+#endif
     __syncthreads();
     TS(4);
     if (a.y && !DBG(128)) {
