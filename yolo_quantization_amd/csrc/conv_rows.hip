@@ -672,6 +672,11 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
     using std::integral_constant;
     if (DBG(64)) {
     } else if (fast) {
+#ifdef MI355_EPI_ONE  // A/B build: only the epilogue the benchmarked launch needs is instantiated
+        epi_fast(integral_constant<int, MI355_ACT_LEAKY>{}, integral_constant<int, 0>{});
+    }
+    if (false) {
+#endif
         const bool sat = a.store_mode == MI355_STORE_SATURATE;
         if (a.act == MI355_ACT_LEAKY) {
             if (sat) epi_fast(integral_constant<int, MI355_ACT_LEAKY>{}, integral_constant<int, 1>{});
@@ -683,7 +688,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
             if (sat) epi_fast(integral_constant<int, MI355_ACT_LINEAR>{}, integral_constant<int, 1>{});
             else epi_fast(integral_constant<int, MI355_ACT_LINEAR>{}, integral_constant<int, 0>{});
         }
-    } else {
+    }
+#ifndef MI355_EPI_ONE
+    else {
     #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
     #pragma unroll
@@ -730,6 +737,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
             }
         }
     }
+#endif
     __syncthreads();
     TS(4);
     if (a.y && !DBG(128)) {

@@ -344,7 +344,16 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
         }
         return p;
     };
-    const Pos pstep = pos_of(gridDim.x);
+    // XCD-aware tile order (round 5): workgroup id w runs on XCD w % 8, each with its own L2, and neighbouring tiles share their halo rows (flat
+    // tiles: whole rows; patches: a row above / below and a cell left / right).  Dealt round-robin (tile = w + k * grid), neighbours sat on
+    // different XCDs and every shared row came from HBM twice: PMC reads 1.53x (layer 2) / 2.0x (layer 4) the input.  Now every XCD takes one
+    // CONTIGUOUS share of the tiles and its workgroups walk it side by side: tile = start_x + (w >> 3) + k * (grid >> 3).
+    const bool xcd_walk = (gridDim.x & 7) == 0 && !(a.debug & 2048);
+    const int tq = ntiles >> 3, tr = ntiles & 7, xcd = (int)(blockIdx.x & 7);
+    const int tstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int tfirst = xcd_walk ? xcd * tq + min(xcd, tr) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int tend = xcd_walk ? (xcd + 1) * tq + min(xcd + 1, tr) : ntiles;
+    const Pos pstep = pos_of(tstride);
     auto advance = [&](Pos &p) {
         p.tx += pstep.tx; p.ty += pstep.ty; p.b += pstep.b;
         if (p.tx >= a.tiles_x) { p.tx -= a.tiles_x; ++p.ty; }
@@ -369,10 +378,10 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
         }
     };
 
-    int tile = blockIdx.x;
+    int tile = tfirst;
     Pos cur = pos_of(tile), nxp = cur;
     int gr_first = 0, col0 = 0, nrows = 0;
-    if (tile < ntiles) {
+    if (tile < tend) {
         tile_geom(tile, cur, gr_first, col0, nrows);
         issue_tile(gr_first, col0, nrows, 0);
     }
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
         }
     };
     SMP_DECL;
-    for (; tile < ntiles; tile += gridDim.x, parity ^= 1, cur = nxp) {
+    for (; tile < tend; tile += tstride, parity ^= 1, cur = nxp) {
         SMP_MARK(6);
         tile_geom(tile, cur, gr_first, col0, nrows);
         const char *X = smem + parity * bbytes;
@@ -401,9 +410,9 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
         SMP_MARK(0);
         flush_stores();
         advance(nxp);
-        if (tile + gridDim.x < ntiles) {
+        if (tile + tstride < tend) {
             int g2, c2, n2;
-            tile_geom(tile + gridDim.x, nxp, g2, c2, n2);
+            tile_geom(tile + tstride, nxp, g2, c2, n2);
             issue_tile(g2, c2, n2, parity ^ 1);
         }
 
@@ -627,7 +636,10 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
     const int total_p = a.B * ohw;
     const int tpi = a.tiles_x * a.tiles_y;
     const bool pow2 = a.hdr->pow2 == 1;
-    const int tile = blockIdx.x;
+    // one tile per workgroup; workgroup id w runs on XCD w % 8: every XCD gets one contiguous share of the tiles (neighbouring tiles share
+    // their halo rows through that XCD's L2 -- see conv_small_pool_kernel)
+    const int tile = (a.debug & 2048) ? (int)blockIdx.x
+                                      : (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + min((int)(blockIdx.x & 7), (int)(gridDim.x & 7)) + (int)(blockIdx.x >> 3);
 
     // ---- tile geometry (as in conv_small_pool_kernel)
     int gr_first, col0, nrows, pb = 0, pty = 0, ptx = 0;
