@@ -80,6 +80,7 @@ if __name__ == "__main__":
     ap.add_argument("--ablate", action="store_true", help="timing ablation of the K loop (results are wrong)")
     ap.add_argument("--timeline1", action="store_true", help="conv1x1_ws: per-workgroup phase timestamps (-DMI355_ABLATE build)")
     ap.add_argument("--timeline16", action="store_true", help="conv_rows16: per-workgroup phase timestamps (-DMI355_ABLATE build)")
+    ap.add_argument("--timelinem", action="store_true", help="conv_mid_pool: per-workgroup phase timestamps (-DMI355_ABLATE build)")
     a = ap.parse_args()
     SHIFT = a.shift
     binding.init(0)
@@ -109,6 +110,24 @@ if __name__ == "__main__":
             d = t[i + 1] - t[i]
             print(f"  {nm:52s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
         d = t[3] - t[0]
+        print(f"  {'whole workgroup':52s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
+    elif a.timelinem:  # conv_mid_pool_kernel (64 -> 128 + pool): needs --pool and the -DMI355_ABLATE build
+        S = binding.shim()
+        r = run(a.c, a.n, a.hw, a.k, a.batch, 1, None, a.mode)
+        S.mi355_stream_sync(None)
+        ts = np.zeros((6, 4096), np.int64)
+        S.mi355_debug_read_tsm.argtypes = [C.c_void_p]
+        assert S.mi355_debug_read_tsm(ts.ctypes.data) == 0
+        nb = int((ts[0] > 0).sum())
+        t = ts[:, :nb].astype(np.float64) / 100.0
+        t0 = t[0].min()
+        print(json.dumps(r))
+        print(f"blocks {nb}; span first start .. last end {t[5].max() - t0:.2f} us; starts: p50 {np.median(t[0]) - t0:.2f}, p90 {np.percentile(t[0], 90) - t0:.2f}, max {t[0].max() - t0:.2f}")
+        for i, nm in [(0, "geometry, image DMA issued"), (1, "parameters to LDS, A fragments issued, pixel tables"), (2, "image / fragments landed, barrier"),
+                      (3, "cell sums, box sums (two barriers)"), (4, "groups: MFMA chains + epilogues + stores issued")]:
+            d = t[i + 1] - t[i]
+            print(f"  {nm:52s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
+        d = t[5] - t[0]
         print(f"  {'whole workgroup':52s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
     elif a.timeline16:
         S = binding.shim()

@@ -84,7 +84,7 @@ extern "C" int mi355_debug_read_wp(long long *host)
 // A(g), A(g+1) are being read while A(g+2) .. A(g+5) are in flight) -- 4 in the 128-column configurations, whose LDS
 // then lets two workgroups share a CU (one's epilogue under the other's K loop); 4 (3 for the widest tiles: LDS) for the plain 1x1
 // loop, which then has its DMA two or three K-steps ahead instead of one -- its K-steps took 0.7 us each, the DMA latency
-template <int KS, int BN> constexpr int ra_stages() { return KS == 3 ? (BN <= 128 ? 4 : 6) : (BN <= 128 ? 4 : 3); }
+template <int KS, int BN> constexpr int ra_stages() { return KS == 3 ? (BN <= 192 ? 4 : 6) : (BN <= 128 ? 4 : 3); }
 // B buffers: two per-chunk row images for 3x3 (a chunk lasts nine K-steps); for 1x1 every K-step is a new chunk and the
 // row image rides the same ring as the weights
 template <int KS, int BN> constexpr int rb_stages() { return KS == 3 ? 2 : ra_stages<KS, BN>(); }
@@ -859,6 +859,9 @@ static int rows_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
 {
     if (bm == 128 && bn == 384) return rows_launch_cfg<128, 384, 2, 4, RS, KS>(a, st);
     if (bm == 128 && bn == 256) return rows_launch_cfg<128, 256, 2, 4, RS, KS>(a, st);
+    if constexpr (KS == 3) {
+        if (bm == 128 && bn == 192) return rows_launch_cfg<128, 192, 2, 2, RS, KS>(a, st);  // four waves of 64 x 96 (round 5)
+    }
     if (bm == 128 && bn == 128) return rows_launch_cfg<128, 128, 2, 2, RS, KS>(a, st);
     if (bm == 64 && bn == 256) return rows_launch_cfg<64, 256, 1, 4, RS, KS>(a, st);
     if (bm == 64 && bn == 128) return rows_launch_cfg<64, 128, 1, 4, RS, KS>(a, st);

@@ -49,7 +49,7 @@ extern "C" int mi355_debug_read_ts16(long long *host)
 // (round 3: the K loop also takes FIVE stages -- a slab issued three K-steps ahead instead of two; measured on the 128-column tiles,
 // 80 448 bytes of LDS on 13-wide maps, two workgroups per CU still: L12 44.6 vs 44.2-45.3 us per launch with three batches in flight,
 // 360 parity tests green -- the 128 x 128 K loop at 58 % of the matrix pipe is not waiting for its DMA.  Back to four.)
-template <int KS, int BN> constexpr int ra16_stages() { return KS == 3 ? (BN <= 128 ? 4 : 6) : (BN <= 128 ? 4 : 3); }
+template <int KS, int BN> constexpr int ra16_stages() { return KS == 3 ? (BN <= 192 ? 4 : 6) : (BN <= 128 ? 4 : 3); }
 // B buffers: two per-chunk row images for 3x3 (a chunk lasts nine K-steps); for 1x1 every K-step is a new chunk and the
 // row image rides the same ring as the weights
 template <int KS, int BN> constexpr int rb16_stages() { return KS == 3 ? 2 : ra16_stages<KS, BN>(); }
@@ -743,6 +743,7 @@ static int rows16_launch_tile(ConvArgs &a, hipStream_t st, int bm, int bn)
 {
     if (bm == 128 && bn == 384) return rows16_launch_cfg<128, 384, 2, 4, RS, 3>(a, st);
     if (bm == 128 && bn == 256) return rows16_launch_cfg<128, 256, 2, 4, RS, 3>(a, st);
+    if (bm == 128 && bn == 192) return rows16_launch_cfg<128, 192, 2, 2, RS, 3>(a, st);  // four waves of 64 x 96: 0.42 fragment reads per MFMA instead of 0.5 (round 5)
     if (bm == 128 && bn == 128) return rows16_launch_cfg<128, 128, 2, 2, RS, 3>(a, st);
     if (bm == 64 && bn == 256) return rows16_launch_cfg<64, 256, 1, 4, RS, 3>(a, st);
     if (bm == 64 && bn == 128) return rows16_launch_cfg<64, 128, 1, 4, RS, 3>(a, st);

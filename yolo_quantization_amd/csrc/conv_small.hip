@@ -73,6 +73,18 @@ extern "C" int mi355_debug_read_smph(long long *host)
 #define SMP_STORE() do { } while (0)
 #endif
 
+#ifdef MI355_ABLATE
+// conv_mid_pool_kernel: phase timestamps (100 MHz wall clock) of thread 0 of every workgroup (tools/conv_microbench.py --timelinem)
+__device__ long long g_mid_ts[6][4096];
+#define TSM(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_mid_ts[k][blockIdx.x] = wall_clock64(); } while (0)
+extern "C" int mi355_debug_read_tsm(long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mid_ts), sizeof(long long) * 6 * 4096) == hipSuccess ? 0 : -5;
+}
+#else
+#define TSM(k) do { } while (0)
+#endif
+
 constexpr int SM_PPB = 128;  // pooled pixels per workgroup tile (4 waves x 32 lanes)
 constexpr int SM_GMAX = 8;    // conv_mid_pool_kernel: groups of 32 pooled pixels per tile (tile <= 256 pooled pixels)
 constexpr int SM_KMAX = 6;    // DMA instructions per wave and piece per tile image (image <= 4 * 6 * 64 cells)
@@ -624,6 +636,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
     int *ldsM0 = ldsHI + N, *ldsSH = ldsM0 + N;                           // integer requantisation: M0, s - 1 (common.h intrq_make)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
+    TSM(0);
     const int tid = threadIdx.x, NT = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = NT >> 6;
@@ -680,6 +693,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
             }
         }
     }
+    TSM(1);
     // ---- per-channel parameters, wrap-safe ranges, this wave's A fragments (overlap the DMA)
     // (POOL: accumulators biased by the safe range's lower end, window maxima requantised with two integer instructions where every channel
     // qualifies -- pool_requant_quad_biased, as in conv_small_pool_kernel)
@@ -759,8 +773,10 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
                                   : MODE == 2 ? (long)a.out_lead + ((long)b * (OH + 1) + (prow + 1)) * (OW + 1) + pcol
                                               : (long)a.out_lead + ((long)b * (a.H + 1) + (2 * prow + 1)) * W1 + 2 * pcol;
     }
+    TSM(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // image, parameters, pixel tables
+    TSM(3);
 
     // ---- per-cell channel sums, then the 3x3 box sum of every pre-pool pixel
     const char *X = smem;
@@ -792,6 +808,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
     }
     __syncthreads();
 
+    TSM(4);
     // ---- this wave's 32 channels over the tile's four pixel groups
     const int chw = 32 * wq;
 #pragma unroll 1
@@ -890,6 +907,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
             }
         }
     }
+    TSM(5);
 }
 
 template <int ACT>
