@@ -185,6 +185,14 @@ if __name__ == "__main__":
             d = t[i + 1] - t[i]
             if (t[i + 1] > 0).all() and (t[i] > 0).all():
                 print(f"  {nm:46s} p50 {np.median(d):6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us")
+        if hasattr(S, "mi355_debug_read_acc3"):
+            ac = np.zeros((8, 4096), np.int64)
+            S.mi355_debug_read_acc3.argtypes = [C.c_void_p]
+            if S.mi355_debug_read_acc3(ac.ctypes.data) == 0 and ac[6, :nb].max() > 0:
+                av = ac[:, :nb].astype(np.float64) / 100.0
+                print(f"  persistent form, sums over a workgroup's {av[6].mean() * 100:.1f} tiles (us, thread 0): top-of-tile wait + barrier / staging pass {av[0].mean():.2f} | "
+                      f"next tile's DMA issue {av[1].mean():.2f} | cell sums {av[2].mean():.2f} | parameters + tables + barrier {av[3].mean():.2f} | box sums + barrier {av[4].mean():.2f} | "
+                      f"group loops {av[5].mean():.2f} | before the first tile {av[7].mean():.2f}")
         print("  phase 4->7:", f"p50 {np.median(t[7] - t[4]):6.2f}  max {(t[7] - t[4]).max():6.2f}")
         d47 = (t[7] - t[4]).mean(axis=1)
         print("  4->7 mean per workgroup, by blockIdx % 8 (XCD):", [round(float(d47[k::8].mean()), 2) for k in range(8)])

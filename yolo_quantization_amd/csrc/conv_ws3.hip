@@ -50,7 +50,20 @@ extern "C" int mi355_debug_read_wp3(long long *host)
 {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws3_wp), sizeof(long long) * 4096 * 8 * 4) == hipSuccess ? 0 : -5;
 }
+// per-tile phase sums (wall clock, thread 0 of every workgroup) of the persistent form: [0] wait + barrier at the top of a tile (non-DB: the staging pass),
+// [1] DMA issue of the next tile, [2] cell sums, [3] parameters + pixel tables + barrier, [4] box sums + barrier, [5] group loops, [6] tiles
+__device__ long long g_ws3_acc[8][4096];
+#define ACC3_DECL long long acc3[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long acc3_t = wall_clock64()
+#define ACC3(k) do { const long long n_ = wall_clock64(); acc3[k] += n_ - acc3_t; acc3_t = n_; } while (0)
+#define ACC3_STORE() do { if (threadIdx.x == 0 && blockIdx.x < 4096) for (int k = 0; k < 8; ++k) g_ws3_acc[k][blockIdx.x] = acc3[k]; } while (0)
+extern "C" int mi355_debug_read_acc3(long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws3_acc), sizeof(long long) * 8 * 4096) == hipSuccess ? 0 : -5;
+}
 #else
+#define ACC3_DECL do { } while (0)
+#define ACC3(k) do { } while (0)
+#define ACC3_STORE() do { } while (0)
 #define TS3(k) do { } while (0)
 #define WP3_DECL do { } while (0)
 #define WP3_START() do { } while (0)
@@ -70,6 +83,12 @@ __host__ __device__ constexpr int ws3_pm2_lane(int row, int col)  // inverse
 {
     return row == 0 ? (col < 4 ? col : col < 8 ? col + 8 : col + 12) : (col < 8 ? col + 4 : col < 12 ? col + 8 : col + 16);
 }
+// LDS-DMA in its "scalar 64-bit base + 32-bit lane offset" form (see conv_rows16.hip): M0 carries the LDS destination of lane 0, lane i lands 16 i
+// bytes further on; nothing else in this kernel uses M0
+#define WS3_DMA(ldsdst_u32, sbase_ptr, voff_u32)                                                                  \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst_u32), "v"(voff_u32), \
+                 "s"(sbase_ptr)                                                                                  \
+                 : "memory")
 constexpr int WS3_GMAX = 8;    // groups of 32 pixels per tile
 constexpr int WS3_UB = 8;      // 16-byte staging loads in flight per thread
 
@@ -100,6 +119,14 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
     char *ldsPT = smem + a.sm_pt_off;                                     // PM: staged bytes, slot (set, quad, group) = [32 px][36 B]
     int *ldsPCell = ldsCell + G * 32;                                     // PM == 2: [G * 8] pooled cell of window w, -1: none
 
+    // Round 5 -- double-buffered DMA staging (DB): the persistent 128-channel form (several tiles per workgroup: YOLOv3-608's 128 -> 256 @76 layers)
+    // staged a tile's image through registers, waited, computed, and nothing of tile t + 1 was on its way meanwhile: 35 of 83 us per launch
+    // (profiles/r04_conv_ws3_608_ablation.log).  The skewed cell-major layout IS writable by the LDS-DMA after all: the image is a linear array of
+    // 16-byte units, nine per cell (eight pieces + the skew unit), and an instruction writes 64 consecutive units -- the lanes that fall on a skew
+    // unit fetch the cell's first piece again (1/9 of the DMA's bytes).  With two image buffers (a.sm_hc = their byte distance, 0: single buffer) a
+    // tile's image is fetched while the previous tile computes; the per-cell channel sums then come from LDS instead of the staging registers.
+    const bool DB = KP == 1 && PM == 0 && a.sm_hc != 0;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,11 +214,72 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
             }
         }
     };
-    if (wg < a.ntiles_n) stage(wg, std::true_type{});
-    for (int tile = wg, first = 1; tile < a.ntiles_n; tile += nwg, first = 0) {
-    if (!first) {
+    // DB: fetch a tile's image into buffer `b` (asynchronous; counted in vmcnt like any load)
+    auto dma_tile = [&](int tile, int b) {
+        const int p0 = tile * TP, p1 = min(p0 + TP, total_u);
+        int gr_first, nrows;
+        tile_rows(p0, p1, gr_first, nrows);
+        const long org = (long)a.in_lead + (long)(gr_first - 1) * W1 - 1;
+        const int units = min(nrows, RS) * ncell * (PIECES + 1);  // 16-byte units of the image, skew units included
+        const int ninstr = (units + 63) >> 6;                     // (the buffer is a whole number of KiB: the launcher rounds it up)
+        const unsigned dst0 = lds0 + (unsigned)b * (unsigned)a.sm_hc;
+        const long maxcell = (long)a.in_cells - 1;
+        for (int k = wave; k < ninstr; k += 8) {
+            const int q = min(k * 64 + lane, units - 1);
+            const int cell = q / (PIECES + 1), piece = q - cell * (PIECES + 1);
+            const int r = fd_div(cell, a.fd_w), c = cell - r * ncell;  // (fd_w: the launcher's division by ncell)
+            long f = org + (long)r * W1 + c;
+            f = f < 0 ? 0 : (f > maxcell ? maxcell : f);
+            const unsigned voff = (unsigned)(f * a.in_cs) + (unsigned)(piece < PIECES ? piece : 0) * 16u;  // < 2^32: the launcher checks
+            const unsigned d = dst0 + (unsigned)k * 1024u;
+            WS3_DMA(d, a.x, voff);
+        }
+    };
+    if (DB) {
+        if (wg < a.ntiles_n) dma_tile(wg, 0);
+        // this wave's A fragments queue behind the first image
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+            wf[s] = *reinterpret_cast<const v4i *>(a.ws + ((size_t)(((f0 >> 5) + wq) * KP + kp) * KST + s) * 1024 + lane * 16);
+    } else if (wg < a.ntiles_n) {
+        stage(wg, std::true_type{});
+    }
+    int dbuf = 0;
+    ACC3_DECL;
+    for (int tile = wg, first = 1; tile < a.ntiles_n; tile += nwg, first = 0, dbuf ^= 1) {
+    ACC3(7);
+    if (DB) {
+        // this tile's image has landed (every wave's share: barrier) and every wave is done with the previous tile, whose buffer the next
+        // tile's image may now overwrite.  As a builtin, so that the compiler's wait-count pass knows nothing is pending (the A fragments, first time round)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __syncthreads();
+        ACC3(0);
+        if (tile + nwg < a.ntiles_n) dma_tile(tile + nwg, dbuf ^ 1);
+        ACC3(1);
+        // per-cell channel sums of this tile's image, from LDS
+        {
+            int gr_first, nrows;
+            tile_rows(tile * TP, min(tile * TP + TP, total_u), gr_first, nrows);
+            const int cells = min(nrows, RS) * ncell;
+            const char *img = smem + (size_t)dbuf * a.sm_hc;
+            for (int id = tid; id < cells; id += 512) {
+                int t = 0;
+#pragma unroll
+                for (int pc = 0; pc < PIECES; ++pc) {
+                    const v4i v = *reinterpret_cast<const v4i *>(img + id * CELLB + pc * 16);
+                    t = __builtin_amdgcn_sdot4(v[0], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(v[1], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(v[2], 0x01010101, t, false);
+                    t = __builtin_amdgcn_sdot4(v[3], 0x01010101, t, false);
+                }
+                ldsS[id] = t;
+            }
+        }
+        ACC3(2);
+    } else if (!first) {
         __syncthreads();  // every wave is done with the previous tile's image, tables and parked partial sums
         stage(tile, std::false_type{});
+        ACC3(0);
     }
     const int p0 = tile * TP, p1 = min(p0 + TP, total_u);  // this tile's pixels (PM == 2: windows) [p0, p1)
 
@@ -235,6 +323,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
         }
     }
     __syncthreads();
+    ACC3(3);
     TS3(2);
     // first cell of image row rr + dy (rows past RS alias row 0: whole-image tiles)
     auto row_cell = [&](int rr, int dy) {
@@ -251,17 +340,18 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
         ldsSX[idx] = t;
     }
     __syncthreads();
+    ACC3(4);
     TS3(3);
     // All A fragments have to be in before the group loops: with the waits inside the (shared) loop body every group
     // would end on an s_waitcnt vmcnt(0), and vmcnt also counts the previous group's stores -- a store round trip per
     // group.  As a builtin, so that the compiler's wait-count pass knows nothing is pending any more.
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (!DB) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)   (DB: waited at the top of the tile; here the NEXT tile's image is in flight, on purpose)
     TS3(4);
 
     // K-step s of this wave: tap s / 4, channels 128 kp + 32 (s % 4) + 16 kh .. + 15 = bytes [128 kp + 32 (s % 4) + 16 kh, +16)
     // of the tap's cell.  The lane's k-half and the wave's K part go into its three row bases; the tap column and the
     // channel block are immediates of the ds_read: no address arithmetic inside the K loop.
-    const char *X = smem;
+    const char *X = smem + (DB ? (size_t)dbuf * a.sm_hc : 0);
     const int lane_off = (8 * kp + kh) * 16;
     const int lw = 32 * wq;  // first filter of the wave within the workgroup's parameter tables
     const int Gs = (G - wset + nset - 1) / nset;      // groups of this wave set: wset, wset + nset, ..
@@ -485,7 +575,12 @@ __global__ __launch_bounds__(512, 2) void conv_ws3_kernel(const ConvArgs a)
                 if (u0 + u * PPI < nu) *reinterpret_cast<uint32_t *>(pout + __umul24((unsigned)pc[u], pcs)) = m[u];
         }
     }
+    ACC3(5);
+#ifdef MI355_ABLATE
+    acc3[6] += 1;
+#endif
     }  // tiles
+    ACC3_STORE();
     TS3(7);
     WP3_STORE();
 }
@@ -559,7 +654,7 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
     const int upx = pm == 2 ? 4 : 1;                             // pixels per unit
     const int want = 256 / mtiles > 0 ? 256 / mtiles : 1;  // workgroups per filter tile: one round of the chip
     // LDS need of a plan with tiles of tp pixels (0: does not fit); fills the geometry fields of `a`
-    auto plan = [&](int tp, size_t &lds_out) {
+    auto plan = [&](int tp, size_t &lds_out, bool db = false) {
         const int ntiles = (int)((total + tp - 1) / tp);
         const int G = (tp * upx + 31) / 32;
         int rows_cap = 0;
@@ -579,6 +674,10 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
         if (S == 1 && pm != 2 && tp == hw && total % hw == 0 && rows_cap == a.H + 2) rows_cap = a.H + 1;  // whole-image tiles: the two pad rows alias
         const int cells = rows_cap * (a.W + 2);
         size_t lds = (size_t)cells * (pieces + 1) * 16;
+        // db: two image buffers, each a whole number of KiB (the LDS-DMA writes 1 KiB per instruction), the next tile's image lands in one
+        // while the other is computed on
+        const size_t imgstride = db ? ((lds + 1023) & ~(size_t)1023) : 0;
+        if (db) lds = 2 * imgstride;
         const size_t imgb = lds;
         lds += (size_t)((cells + 3) & ~3) * 4 + (size_t)G * 32 * 12 + (pm == 2 ? (size_t)G * 8 * 4 : 0);
         lds = (lds + 15) & ~(size_t)15;
@@ -600,6 +699,7 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
         a.sm_ncell = a.W + 2;
         a.rows_cap = rows_cap;
         a.sm_pieceb = (int)imgb;
+        a.sm_hc = (int)imgstride;  // (a conv_small field: here the distance of the two image buffers, 0 = one buffer, staged through registers)
         a.lds_param_off = (int)poff;
         a.sm_red_off = (int)roff;
         lds_out = lds;
@@ -627,6 +727,17 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
         // several tiles per (persistent) workgroup: the largest tile that fits LDS, the tile count rounded up to whole
         // rounds of the `want` workgroups and the tile size shrunk to match, so that every workgroup walks as many tiles
         bool ok = false;
+        // the 128-channel form first tries tiles of which TWO images fit (double-buffered DMA staging, see the kernel): smaller tiles, more of
+        // them per workgroup, each fetched under the previous one's compute
+        if (kp == 1 && !pm && !(mi355_debug_flags_get() & (1 << 29)) && (size_t)a.in_cells * (size_t)a.in_cs < ((size_t)1 << 32)) {
+            for (int tpm = WS3_GMAX * 32; tpm >= 96 && !ok; tpm -= 32) {
+                const long per = (total + (long)want * tpm - 1) / ((long)want * tpm);
+                const int tp = (int)((total + per * want - 1) / (per * want));
+                ok = tp >= 64 && per >= 2 && plan(tp, lds, true);
+            }
+            for (int k = (WS3_GMAX * 32) / OWd; k >= 1 && !ok; --k)
+                if (OHd % k == 0 && k * OWd >= 64 && (long)a.B * (OHd / k) >= 2L * want) ok = plan(k * OWd, lds, true);
+        }
         for (int tpm = WS3_GMAX * 32; tpm >= 64 && !ok; tpm -= 32) {
             const long per = (total + (long)want * tpm - 1) / ((long)want * tpm);  // tiles per workgroup
             const int tp = (int)((total + per * want - 1) / (per * want));
@@ -642,5 +753,6 @@ int conv_ws3_launch(ConvArgs &a, hipStream_t st)
     a.debug = mi355_debug_flags_get();
     a.sm_nq = nq;
     a.mtiles = mtiles;
+    a.fd_w = fastdiv_make((uint32_t)(a.W + 2));  // cells per LDS image row (the DMA staging's unit -> (row, column))
     return kp == 1 ? w3_launch_pm<1>(a, st, mtiles * nwg, lds) : w3_launch_pm<2>(a, st, mtiles * nwg, lds);
 }
