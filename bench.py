@@ -59,6 +59,11 @@ def parse_args():
                     help="CPU dry run of the multi-rank start-up (no GPU needed): the same launcher, rendezvous, packed-weights broadcast, image "
                          "sharding and max-over-ranks timing code on the gloo backend, host-only prep; rank 0 prints one JSON line and the "
                          "exit code is 0 only when every rank ends up with byte-identical packed state")
+    ap.add_argument("--preroll", type=int, default=160,
+                    help="untimed in-flight steps queued in front of the W warmup steps (0: none).  The device's power management needs ~100 steps (25 ms) of THIS "
+                         "load to settle its clocks after any idle or lightly loaded phase -- the host-side set-up and the self-check passes (whose checksum kernels "
+                         "leave the chip mostly idle) are such phases: a 20-step region right behind them measures 0.259-0.265 ms per step where the same region after "
+                         "100+ plain steps measures 0.244 (profiles/r05_warmup_curve.log); reported as `preroll_steps`")
     ap.add_argument("--selfcheck-passes", type=int, default=48,
                     help="determinism self-check before the warmup steps: that many passes over the input, yolo-output checksums compared (0: off)")
     return ap.parse_args()
@@ -427,6 +432,8 @@ def main():
     if args.selfcheck_passes > 0 and not args.graph:
         for nk in nets:  # every instance checks itself; with several in flight their passes overlap on the device like the timed steps
             nk.selfcheck(args.selfcheck_passes)
+    for i in range(max(args.preroll, 0)):  # untimed, unsynchronised: the same in-flight load as the timed steps (see --preroll)
+        nets[i % len(nets)].forward()
     for i in range(args.warmup):
         nets[i % len(nets)].forward()
     barrier()
@@ -781,7 +788,8 @@ def main():
     if rank == 0:
         out = {"metric": METRICS.get(os.path.basename(args.cfg), f"images/sec {os.path.basename(args.cfg)} INT8"), "value": round(value, 1), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "warmup_passes_effective": args.warmup + (ninfl * args.selfcheck_passes if selfcheck else 0),  # the self-check passes are queued right in front of the warmup steps
+               "warmup_passes_effective": args.warmup + max(args.preroll, 0) + (ninfl * args.selfcheck_passes if selfcheck else 0),  # self-check passes and pre-roll steps are queued right in front of the warmup steps
+               "preroll_steps": max(args.preroll, 0),  # untimed steps of the same load that let the device's clocks settle (--preroll; the timed region is exactly `steps` steps)
                "ms_per_step": round(ms_per_step, 4),
                "host_issue_ms": round(t_issued * 1e3, 3),  # host time to queue the K steps of the timed region (its total is ms_per_step * steps)
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x s8 -> int32 (f64 or exact-integer requant, bit-identical)",
