@@ -381,8 +381,8 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
         } else {
             const int p0 = tile * SM_PPB;
             const int p1 = min(p0 + SM_PPB, total_p) - 1;
-            const int b0 = p0 / ohw, r0 = (p0 - b0 * ohw) / OW;
-            const int b1 = p1 / ohw, r1 = (p1 - b1 * ohw) / OW;
+            const int b0 = fd_div(p0, a.fd_hw), r0 = fd_div(p0 - b0 * ohw, a.fd_w);  // (launch constants: common.h FastDiv, set by the launcher)
+            const int b1 = fd_div(p1, a.fd_hw), r1 = fd_div(p1 - b1 * ohw, a.fd_w);
             gr_first = b0 * (a.H + 1) + 2 * r0 + 1;
             const int gr_last = b1 * (a.H + 1) + 2 * r1 + 2;
             col0 = -1;
@@ -457,9 +457,9 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
             const int pp = tile * SM_PPB + wave * 32 + lj;
             valid = pp < total_p;
             const int ppc = valid ? pp : total_p - 1;
-            b = ppc / ohw;
+            b = fd_div(ppc, a.fd_hw);
             const int prem = ppc - b * ohw;
-            prow = prem / OW;
+            prow = fd_div(prem, a.fd_w);
             pcol = prem - prow * OW;
         }
         const int lrow = b * (a.H + 1) + 2 * prow + 1 - gr_first;  // image row of the window's top row's top tap
@@ -667,8 +667,8 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
     } else {
         const int p0 = tile * TP;
         const int p1 = min(p0 + TP, total_p) - 1;
-        const int b0 = p0 / ohw, r0 = (p0 - b0 * ohw) / OW;
-        const int b1 = p1 / ohw, r1 = (p1 - b1 * ohw) / OW;
+        const int b0 = fd_div(p0, a.fd_hw), r0 = fd_div(p0 - b0 * ohw, a.fd_w);
+        const int b1 = fd_div(p1, a.fd_hw), r1 = fd_div(p1 - b1 * ohw, a.fd_w);
         gr_first = b0 * (a.H + 1) + 2 * r0 + 1;
         col0 = -1;
         nrows = b1 * (a.H + 1) + 2 * r1 + 2 - gr_first + 3;
@@ -759,9 +759,9 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
             const int pp = tile * TP + g * 32 + l;
             valid = pp < total_p && g * 32 + l < TP;
             const int ppc = valid ? pp : min(tile * TP + TP, total_p) - 1;  // idle lanes shadow the tile's last pixel
-            b = ppc / ohw;
+            b = fd_div(ppc, a.fd_hw);
             const int prem = ppc - b * ohw;
-            prow = prem / OW;
+            prow = fd_div(prem, a.fd_w);
             pcol = prem - prow * OW;
         }
         const int rr = b * (a.H + 1) + 2 * prow + 1 - gr_first + (j >> 1);
@@ -996,6 +996,9 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
     if ((size_t)a.in_cells * (size_t)a.in_cs >= ((size_t)1 << 32)) return MI355_EINVAL;  // 32-bit DMA lane offsets
     const int OH = a.H / 2, OW = a.W / 2;
     const long total_p = (long)a.B * OH * OW;
+    if (total_p + 256 >= (1L << 31)) return MI355_EINVAL;
+    a.fd_hw = fastdiv_make((uint32_t)(OH * OW));  // the kernels' flat-tile geometry: pooled pixel -> (image, row, column)
+    a.fd_w = fastdiv_make((uint32_t)OW);
     int ntiles;
     if (OW >= 64) {  // wide map: 8 x 16 pooled patches (a flat run of 128 would load two mostly unused rows)
         a.tiles_x = (OW + 15) / 16;
