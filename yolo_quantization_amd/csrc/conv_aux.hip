@@ -442,8 +442,10 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
             const uint64_t tb = reinterpret_cast<uint64_t>(xm1) + (uint64_t)org;
             const uint64_t tbs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tb);
             auto load3 = [&]() {
+                // ("+v": under a lane mask the loads leave the other lanes' registers alone -- the border path's pad value sits in the SAME registers,
+                // no merge behind the loads that could read them before they land)
                 asm volatile("global_load_dword %0, %3, %6\n\tglobal_load_dword %1, %4, %6\n\tglobal_load_dword %2, %5, %6"
-                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])
                              : "v"(offk[0]), "v"(offk[1]), "v"(offk[2]), "s"(tbs)
                              : "memory");
             };
