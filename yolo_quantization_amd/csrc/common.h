@@ -184,9 +184,11 @@ __device__ __forceinline__ void requant_values(const int32_t (&accb)[4][NS], con
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
+                // (selects, not branches: as exec-masked regions these sixteen cold values were most of the s_*_saveexec of the pooled kernels' loops)
                 const int32_t q = requant_q_exact(accb[r][ns], mp[r]);
                 const uint32_t x = (0u - (uint32_t)q) + 5u;
-                v[r][ns] = q < 0 ? zp_act - (int32_t)(x / 10u) : q + zp_act;
+                const int32_t neg = zp_act - (int32_t)(__umulhi(x, 0xCCCCCCCDu) >> 3), pos = q + zp_act, m = q >> 31;  // x / 10 for every 32-bit x
+                v[r][ns] = (neg & m) | (pos & ~m);
             }
     }
     if (SAT) {
@@ -237,7 +239,8 @@ __device__ __forceinline__ void requant_values_mp(const int32_t (&accb)[NV], con
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const uint32_t x = (0u - (uint32_t)q[i]) + 5u;
-            v[i] = q[i] < 0 ? zp_act - (int32_t)(x / 10u) : q[i] + zp_act;
+            const int32_t neg = zp_act - (int32_t)(__umulhi(x, 0xCCCCCCCDu) >> 3), pos = q[i] + zp_act, m = q[i] >> 31;
+            v[i] = (neg & m) | (pos & ~m);
         }
     }
     if (SAT) {
