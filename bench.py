@@ -424,14 +424,9 @@ def main():
             dist.barrier(group=tgroup) if tgroup is not None else dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- determinism self-check (a race detector for kernels scheduled by hand: counted waits, registers reloaded in place): N passes
-    # over the resident input, a device-side checksum of the yolo outputs after each; compared after the timed region, a mismatch
-    # fails the run.  Nothing is synchronised here, so the passes also leave the device at its steady clocks when the warmup steps
-    # start: after any idle phase of >= 20 ms (the host-side set-up above is one) the first ~40 steps of the net run up to 8 %
-    # slower (tools/step_curve.py) -- without this a `--warmup 5 --steps 20` region measures mostly that.
-    if args.selfcheck_passes > 0 and not args.graph:
-        for nk in nets:  # every instance checks itself; with several in flight their passes overlap on the device like the timed steps
-            nk.selfcheck(args.selfcheck_passes)
+    # (the determinism self-check used to run HERE, in front of the warm-up; it now runs after the timed region and its legs -- see below: its passes,
+    # with their single-workgroup checksum kernels, leave the device in a state from which a 20-step region still measures 0.256-0.258 ms per step
+    # after 165 plain steps, where the same region without them measures 0.246: profiles/r05_warmup_curve.log)
     for i in range(max(args.preroll, 0)):  # untimed, unsynchronised: the same in-flight load as the timed steps (see --preroll)
         nets[i % len(nets)].forward()
     for i in range(args.warmup):
@@ -587,8 +582,13 @@ def main():
                           "note": f"{e_steps} in-flight steps after the timed region, amdgpu hwmon power1_input / freq1_input every 5 ms (second half of the samples); "
                                   "the chip's cap is 1 400 W: at the cap a step costs its energy, not its instruction count (DESIGN.md 4.4)"}
 
+    # ---- determinism self-check (a race detector for kernels scheduled by hand: counted waits, registers reloaded in place): N passes over the
+    # resident input on every instance at once (their passes overlap on the device like the timed steps), a device-side order-independent checksum
+    # of the yolo outputs after each pass; a pass that differs from the first fails the run.  After the timed region and its legs, never inside them.
     selfcheck = None
     if args.selfcheck_passes > 0 and not args.graph:
+        for nk in nets:
+            nk.selfcheck(args.selfcheck_passes)
         bad = sum(nk.selfcheck_result() for nk in nets)
         selfcheck = {"passes": args.selfcheck_passes, "instances": ninfl, "passes_differing_from_the_first": bad}
         if bad:
@@ -788,7 +788,7 @@ def main():
     if rank == 0:
         out = {"metric": METRICS.get(os.path.basename(args.cfg), f"images/sec {os.path.basename(args.cfg)} INT8"), "value": round(value, 1), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "warmup_passes_effective": args.warmup + max(args.preroll, 0) + (ninfl * args.selfcheck_passes if selfcheck else 0),  # self-check passes and pre-roll steps are queued right in front of the warmup steps
+               "warmup_passes_effective": args.warmup + max(args.preroll, 0),  # the pre-roll steps are queued right in front of the warmup steps
                "preroll_steps": max(args.preroll, 0),  # untimed steps of the same load that let the device's clocks settle (--preroll; the timed region is exactly `steps` steps)
                "ms_per_step": round(ms_per_step, 4),
                "host_issue_ms": round(t_issued * 1e3, 3),  # host time to queue the K steps of the timed region (its total is ms_per_step * steps)
