@@ -152,6 +152,10 @@ typedef struct mi355_conv_desc {
     uint8_t zp_in, zp_act;        /* input / activation zero points */
     float s_act;                  /* activation scale (only for y_f32) */
     int plan;                     /* MI355_PLAN_*: which kernel / tile the launcher should prefer (results are identical) */
+    int epilogue_packed;          /* 1: the caller finished `blob` with mi355_conv_pack_epilogue(activation, zp_act) of THIS desc.  A hint for the
+                                   * kernel choice only (results are identical): kernels that live off the table (conv + maxpool with 16 / 32
+                                   * input channels on 16 x 16 x 64 tiles) are picked when it is set; a blob that does not carry the promised
+                                   * table still yields the right bytes, slowly (every window takes the reference's order) */
 } mi355_conv_desc;
 /* MI355_PLAN_LATENCY (0, default): one batch at a time -- every launch is sized to fill the whole chip on its own (one big
  * workgroup per CU: 128 x 384 row-image tiles, the weights-stationary 3x3 kernel with up to 160 KB of LDS).

@@ -59,6 +59,7 @@ static void forward_conv_mi355(layer l, network net)
     memset(&d, 0, sizeof(d));
     d.n = l.n; d.c = l.c; d.ksize = l.size; d.stride = l.stride; d.pad = l.pad;
     d.activation = l.activation; d.store_mode = G.store_mode; d.accum_mode = G.accum_mode;
+    d.epilogue_packed = 1;  /* mi355_bind_network finished the blob with mi355_conv_pack_epilogue */
     d.zp_in = l.input_data_uint8_zero_point[0];
     d.zp_act = l.activ_data_uint8_zero_point[0];
     d.s_act = l.activ_data_uint8_scales[0];

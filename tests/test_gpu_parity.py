@@ -465,6 +465,47 @@ def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain, ept):
     assert np.array_equal(yp2.to_nchw(), want_pool)
 
 
+@pytest.mark.parametrize("B,c,n,H,W,act", [(3, 16, 32, 22, 64, "leaky"), (3, 32, 64, 14, 70, "leaky"), (2, 16, 32, 18, 30, "relu6"),
+                                           (2, 32, 64, 34, 34, "linear"), (1, 16, 32, 208, 208, "leaky"), (1, 32, 64, 104, 104, "leaky"),
+                                           (5, 16, 32, 2, 2, "leaky"), (2, 32, 64, 16, 32, "relu6"), (1, 16, 32, 40, 300, "linear")])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+@pytest.mark.parametrize("gain", ["no-wrap", "some-wrap", "much-wrap"])
+@pytest.mark.parametrize("table", ["match", "other-zero-point", "shift-not-pow2"])
+def test_conv_pool16_kernel(B, c, n, H, W, act, store, gain, table):
+    """conv_pool16.hip (16 -> 32 channels + maxpool on 16 x 16 x 64 tiles, chosen when the desc says the blob carries the
+    epilogue table; the 32 -> 64 cases check that the hint changes nothing for shapes outside its domain): the oracle's conv -> requant -> maxpool bytes in the three wrap regimes (margin test + per-wave redo in the
+    reference's order), ragged 8 x 16 pooled patches, maps smaller than a patch, weight zero points 0 / 255; a table made for another zero
+    point (key mismatch: every window takes the exact path); the same call without the hint is served by conv_small.hip with the same bytes."""
+    import ctypes as C
+    rng = np.random.default_rng(c * 1000 + n * 10 + H + W + len(gain))
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    lo, hi = {"no-wrap": (2.0 ** -17, 2.0 ** -16), "some-wrap": (2.0 ** -14, 2.0 ** -12), "much-wrap": (2.0 ** -11, 2.0 ** -7)}[gain]
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3, lo, hi)
+    zp_w[0], zp_w[1], zp_w[2] = 0, 255, 1
+    if gain != "much-wrap":
+        bias = (bias // 16).astype(np.int32)
+    if table == "shift-not-pow2":  # the reference's two-step form has no one-multiplier equivalent: the exact path, every window
+        sv = sv * 0.75
+    zp_in, zp_act = 9, (23 if act != "linear" else 128)
+    xt = binding.DevTensor.from_nchw(x, zp_in)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv, binding.ACT[act], zp_act + (table == "other-zero-point")))
+    acc, u8 = _oracle_layer(x, wq, zp_w, 3, zp_in, bias, mv, sv, zp_act, oracle.ACT[act], store, oracle.ACC_EXACT)
+    want_pool = np.stack([oracle.maxpool_u8(u8.reshape(B, n, H, W)[b], 2, 2, 1) for b in range(B)])
+    for hint, kernel in ((1, 7), (0, 2)):
+        yp = binding.DevTensor(B, H // 2, W // 2, n, zp_act)
+        d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT[act], store, binding.ACC_EXACT, zp_in, zp_act, 1.0)
+        d.epilogue_packed = hint
+        binding.check(binding.shim().mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, None, yp.ref(), None), "conv_pool")
+        want_kernel = 7 if hint and c == 16 else (2 if min(H, W) >= 4 else 5)  # (32 -> 64 stays with conv_small.hip, which leaves 2 x 2 maps to the generic kernel)
+        assert binding.shim().mi355_last_conv_kernel() == want_kernel
+        got = yp.to_nchw()
+        assert np.array_equal(got, want_pool), f"hint {hint}: {int((got != want_pool).sum())} of {got.size} pooled bytes differ"
+        # pad cells of the pooled tensor are untouched (ragged patches mask their stores)
+        raw = yp.buf.to_numpy(np.uint8, yp.buf.nbytes).reshape(-1, yp.t.cs)
+        OW = W // 2
+        assert (raw[yp.t.lead + OW] == (zp_act ^ 0x80)).all() and (raw[yp.t.lead + (OW + 1) + OW] == (zp_act ^ 0x80)).all()
+
+
 @pytest.mark.parametrize("B,c,n,H,W,act", [(2, 32, 64, 76, 76, "leaky"),      # flat tiles of 128 window blocks
                                            (1, 32, 64, 152, 152, "leaky"),    # 8 x 16 patches (wide map), YOLOv3's 32->64 layer shape
                                            (1, 16, 32, 40, 300, "relu6"),     # very wide rows, ragged patches

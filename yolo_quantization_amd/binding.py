@@ -32,7 +32,7 @@ class Tensor(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("c", C.c_int), ("ksize", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
                 ("activation", C.c_int), ("store_mode", C.c_int), ("accum_mode", C.c_int),
-                ("zp_in", C.c_uint8), ("zp_act", C.c_uint8), ("s_act", C.c_float), ("plan", C.c_int)]
+                ("zp_in", C.c_uint8), ("zp_act", C.c_uint8), ("s_act", C.c_float), ("plan", C.c_int), ("epilogue_packed", C.c_int)]
 
 
 _shim = None

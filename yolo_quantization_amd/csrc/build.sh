@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
 pids=()
-for f in conv_igemm conv_rows conv_rows16 conv_rows_k1 conv_small conv1x1 conv_ws3 conv_aux glue comm shim; do
+for f in conv_igemm conv_rows conv_rows16 conv_rows_k1 conv_small conv_pool16 conv1x1 conv_ws3 conv_aux glue comm shim; do
   if [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ "$HERE/conv_rows.hip" -nt "$OUT/$f.o" -a "$f" = conv_rows_k1 ] || [ "$HERE/kargs.h" -nt "$OUT/$f.o" ] || \
      [ "$HERE/common.h" -nt "$OUT/$f.o" ] || [ "$HERE/../../include/mi355_yolo_int8.h" -nt "$OUT/$f.o" ]; then
     # conv_rows16: its 128-row wave tiles unroll past clang's default pragma-unroll budget; a loop left rolled indexes the accumulator
@@ -21,5 +21,5 @@ done
 fail=0
 for p in "${pids[@]:-}"; do if [ -n "$p" ]; then wait "$p" || fail=1; fi; done
 if [ "$fail" != 0 ]; then echo "build.sh: a translation unit failed to compile" >&2; exit 1; fi
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmi355yolo.so" "$OUT"/conv_igemm.o "$OUT"/conv_rows.o "$OUT"/conv_rows16.o "$OUT"/conv_rows_k1.o "$OUT"/conv_small.o "$OUT"/conv1x1.o "$OUT"/conv_ws3.o "$OUT"/conv_aux.o "$OUT"/glue.o "$OUT"/comm.o "$OUT"/shim.o -ldl
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmi355yolo.so" "$OUT"/conv_igemm.o "$OUT"/conv_rows.o "$OUT"/conv_rows16.o "$OUT"/conv_rows_k1.o "$OUT"/conv_small.o "$OUT"/conv_pool16.o "$OUT"/conv1x1.o "$OUT"/conv_ws3.o "$OUT"/conv_aux.o "$OUT"/glue.o "$OUT"/comm.o "$OUT"/shim.o -ldl
 echo "built $OUT/libmi355yolo.so"

@@ -417,6 +417,38 @@ __device__ __forceinline__ uint32_t pack4_biased(int32_t v0, int32_t v1, int32_t
     return __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;
 }
 
+// The 16 x 16 x 64 pooled kernels' (conv_aux.hip first layer, conv_pool16.hip) exact path: every value of the 2x2 window requantised, then the maximum of the BYTES (the reference's
+// order: src/convolutional_layer.c:737-749 then src/maxpool_layer.c:134-146).  Only taken by waves that see an accumulator outside the
+// wrap-safe range.  acc[j][r]: window position j, channel r, biased by lo[r].
+template <int ACT, bool SAT>
+__device__ __forceinline__ uint32_t first_pool_exact_path(const v4i (&acc)[4], const v4i &lo, const double (&mp)[4], const double *mval4,
+                                                       const double *sval4, int zp_act, bool pow2)
+{
+    int32_t accb[4][4], m[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accb[r][j] = (int32_t)((uint32_t)acc[j][r] + (uint32_t)lo[r]);  // true accumulators
+    if (pow2) {
+        int32_t v[4][4];
+        requant_values<ACT, SAT, 4>(accb, mp, zp_act, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
+    } else {  // (a rolled loop: unrolled, these sixteen two-step requantisations size the whole kernel's registers -- conv_small.hip)
+        int32_t tmp[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tmp[4 * r + j] = accb[r][j];
+#pragma unroll 1
+        for (int idx = 0; idx < 16; ++idx)
+            tmp[idx] = (int32_t)requant_u8(tmp[idx], 0, mval4[idx >> 2], sval4[idx >> 2], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = max(max(tmp[4 * r], tmp[4 * r + 1]), max(tmp[4 * r + 2], tmp[4 * r + 3]));
+    }
+    return pack4_biased(m[0], m[1], m[2], m[3]);
+}
+
 // Quantized residual add on four packed (biased) bytes: a = this conv's requantised bytes, b = the `from` tensor's
 //     q = (Ka*a + Kb*b + k0) >> 16, clamp(0, 255)          k0 = 2^15 + (zp_out << 16) - Ka*zp_a - Kb*zp_b
 // (oracle.c:orc_shortcut_u8).  The empty asm keeps shift and clamp apart: fused, hipcc (ROCm 7.2) pairs

@@ -263,38 +263,6 @@ int conv_ref_f32_launch(AuxArgs &a, hipStream_t st)
 // that is a multiple of 32 dwords the staged rows all start in the same bank as well: 2.8 M conflict cycles, 32.9 -> 36 us.)
 __host__ __device__ constexpr int first_stage_rowc(bool planar) { return planar ? 42 : 34; }
 
-// The first-layer pooled kernels' exact path: every value of the 2x2 window requantised, then the maximum of the BYTES (the reference's
-// order: src/convolutional_layer.c:737-749 then src/maxpool_layer.c:134-146).  Only taken by waves that see an accumulator outside the
-// wrap-safe range.  acc[j][r]: window position j, channel r, biased by lo[r].
-template <int ACT, bool SAT>
-__device__ __forceinline__ uint32_t first_pool_exact_path(const v4i (&acc)[4], const v4i &lo, const double (&mp)[4], const double *mval4,
-                                                       const double *sval4, int zp_act, bool pow2)
-{
-    int32_t accb[4][4], m[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) accb[r][j] = (int32_t)((uint32_t)acc[j][r] + (uint32_t)lo[r]);  // true accumulators
-    if (pow2) {
-        int32_t v[4][4];
-        requant_values<ACT, SAT, 4>(accb, mp, zp_act, v);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = max(max(v[r][0] & 0xFF, v[r][1] & 0xFF), max(v[r][2] & 0xFF, v[r][3] & 0xFF));
-    } else {  // (a rolled loop: unrolled, these sixteen two-step requantisations size the whole kernel's registers -- conv_small.hip)
-        int32_t tmp[16];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) tmp[4 * r + j] = accb[r][j];
-#pragma unroll 1
-        for (int idx = 0; idx < 16; ++idx)
-            tmp[idx] = (int32_t)requant_u8(tmp[idx], 0, mval4[idx >> 2], sval4[idx >> 2], zp_act, ACT, SAT ? MI355_STORE_SATURATE : MI355_STORE_WRAP);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = max(max(tmp[4 * r], tmp[4 * r + 1]), max(tmp[4 * r + 2], tmp[4 * r + 3]));
-    }
-    return pack4_biased(m[0], m[1], m[2], m[3]);
-}
-
 #ifdef MI355_ABLATE
 // per-wave shader-clock sums of the first-layer kernel's phases (tools/l0_phases.py): [0] barrier, [1] deferred stores + prefetch issue,
 // [2] / [4] B reads + MFMA chain of pooled row 0 / 1, [3] / [5] their epilogues, [6] staging wait + LDS writes, [7] tiles

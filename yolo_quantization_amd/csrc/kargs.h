@@ -130,6 +130,8 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st);
 // one lane (8 grp + 4 kh + r in the 32 x 32 MFMA's D layout) are sixteen consecutive filters 16 kh + 4 grp + r
 __host__ __device__ constexpr int ws_row_filter(int R) { return 16 * ((R >> 2) & 1) + 4 * (R >> 3) + (R & 3); }
 bool conv_small_eligible(int n, int c, int ksize);
+bool conv_pool16_eligible(int n, int c, int ksize);
+int conv_pool16_launch(ConvArgs &a, hipStream_t st);  // conv_pool16.hip: c 16 | 32 + maxpool on 16 x 16 x 64 tiles (needs the blob's epilogue table)
 int conv1x1_ws_launch(ConvArgs &a, hipStream_t st);
 bool conv1x1_ws_eligible(int n, int c, int ksize);
 int conv_ws3_launch(ConvArgs &a, hipStream_t st);

@@ -363,8 +363,9 @@ static int blob_layout(int n, int c, int ksize, ConvBlobHeader *h)
     }
     if (h->first || conv_small_eligible(n, c, ksize)) {  // the conv + maxpool kernels' epilogue table (common.h EptHeader)
         h->off_ept = off;
-        off = align16(off + sizeof(EptHeader) + (size_t)h->mpad * sizeof(EptEntry) +
-                      (h->first ? (size_t)LUTQ_N + (size_t)((n + 15) / 16) * 64 * sizeof(L0Lane) : 0));
+        // header, entries, the 4 KiB LEAKY byte table (conv_first_mfma_pool, conv_pool16), first layer: the kernel's per-lane state
+        off = align16(off + sizeof(EptHeader) + (size_t)h->mpad * sizeof(EptEntry) + (size_t)LUTQ_N +
+                      (h->first ? (size_t)((n + 15) / 16) * 64 * sizeof(L0Lane) : 0));
     }
     h->total = off;
     return MI355_OK;
@@ -517,13 +518,16 @@ static void ept_fill(const ConvBlobHeader &h, char *base, int zp_act)
         e[oc].pad_ = 0;
     }
     for (int oc = h.n; oc < h.mpad; ++oc) memset(&e[oc], 0, sizeof(EptEntry));
-    if (h.first) {  // the first layer's LEAKY byte table (common.h leaky_lut_build / leaky_lutf_build): indexed by f (integer form) or by q
-        uint8_t *lut = (uint8_t *)(e + h.mpad);
+    // the LEAKY byte table (common.h leaky_lut_build / leaky_lutf_build): indexed by f (integer form) or by q
+    uint8_t *lut = (uint8_t *)(e + h.mpad);
+    {
         const bool by_floor = !(flags & EPT_NOINT);
         for (int i = 0; i < LUTQ_N; ++i) {
             const int f = i - LUTQ_OFF;
             lut[i] = ACT == MI355_ACT_LEAKY ? (uint8_t)leaky_byte_biased<false>(by_floor && f < 0 ? f + 1 : f, zp_act) : 0;
         }
+    }
+    if (h.first) {
         // the first-layer MFMA kernel's per-lane state (common.h L0Lane)
         L0Lane *ll = (L0Lane *)(lut + LUTQ_N);
         const uint32_t *wfirst = (const uint32_t *)(base + h.off_wp);
@@ -709,7 +713,9 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
         if (rc != MI355_OK) return hip_fail(hipGetLastError(), "conv_ws3 launch");
         return rc;
     }
-    if (ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) { rc = conv_small_pool_launch(a, st); g_last_kernel = 2; }  // few-channel layers
+    // few-channel layers with the epilogue table: the 16 x 16 x 64 form (conv_pool16.hip; debug bit 2^30 sends them back to conv_small.hip for A/B runs)
+    if (ypool && !y && d->epilogue_packed && a.ept && !(mi355_debug_flags_get() & (1024 | (1 << 30)))) { rc = conv_pool16_launch(a, st); if (rc != MI355_EINVAL) g_last_kernel = 7; }
+    if (rc == MI355_EINVAL && ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) { rc = conv_small_pool_launch(a, st); g_last_kernel = 2; }  // few-channel layers
     // the same kernel without the pool: few-channel 3x3 layers of the non-tiny nets (even maps, no dumps)
     if (rc == MI355_EINVAL && !ypool && y && a.ws && d->ksize == 3 && up == 1 && !acc_out && !y_f32 && !yolo_out &&
         (d->c == 16 || d->c == 32 || d->c == 64) && !(mi355_debug_flags_get() & 1024)) { rc = conv_small_pool_launch(a, st); g_last_kernel = 2; }

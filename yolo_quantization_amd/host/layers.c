@@ -38,6 +38,7 @@ static void forward_convolutional_layer_quant_gpu(layer l, network net)
     d.n = l.n; d.c = l.c; d.ksize = l.size; d.stride = l.stride; d.pad = l.pad;
     d.activation = l.activation;
     d.plan = net.plan;
+    d.epilogue_packed = 1;  /* quantization_weights_and_activations finishes every blob with mi355_conv_pack_epilogue(l->activation, zp_act) */
     d.store_mode = net.store_mode;
     d.accum_mode = net.accum_mode;
     d.zp_in = l.input_data_uint8_zero_point[0];
