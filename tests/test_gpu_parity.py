@@ -770,10 +770,10 @@ def test_yolov3_tiny_batch64_properties(cfg_dir, tmp_path):
     # L0, L2, L4, L6, L10 (stride-1 pool) fused with their maxpools, L18 with its upsample: own tensor not stored; L8 + L9 fused too, but
     # L8's tensor is stored as well (the route to layer 20 reads it); the two heads carry their yolo layers
     assert sum(inf["fused"] for inf in info) == 6 and [i for i, inf in enumerate(info) if inf["fuses_next"]] == [0, 2, 4, 6, 8, 10, 15, 18, 22]
-    # every specialised kernel is exercised by the batch-64 net: first layer, conv + pool (16 / 32 / 64 channels), the
+    # every specialised kernel is exercised by the batch-64 net: first layer, conv + pool (16 channels: conv_pool16 = 7, 32 / 64: conv_small = 2), the
     # weights-stationary 3x3 (conv_ws3) and 1x1 (conv1x1) kernels, the row-image kernel on the two deep 3x3 layers
     assert {i: inf["kernel"] for i, inf in enumerate(info) if inf["type"] == binding.T_CONV} == \
-        {0: 1, 2: 2, 4: 2, 6: 2, 8: 4, 10: 4, 12: 5, 13: 3, 14: 4, 15: 3, 18: 3, 21: 5, 22: 3}
+        {0: 1, 2: 7, 4: 2, 6: 2, 8: 4, 10: 4, 12: 5, 13: 3, 14: 4, 15: 3, 18: 3, 21: 5, 22: 3}
     for i, inf in enumerate(info):
         if inf["type"] == binding.T_YOLO or inf["fused"]:
             continue  # a fused conv's own (pre-pool) tensor is not stored
