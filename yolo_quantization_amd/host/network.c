@@ -755,7 +755,7 @@ void network_yolo_detections_gpu(network *net, int i, int imw, int imh, float th
 typedef struct { uint32_t magic; int32_t nlayers; float in_scale; int32_t in_zp; uint64_t total; uint64_t l0_bytes; } pack_head;
 typedef struct { float s_act, s_in; int32_t zp_act, zp_in; uint64_t blob_bytes; } pack_rec;
 typedef struct { int32_t n, c, size, batch_normalize; } pack_l0;
-#define PACK_MAGIC 0x34444B4Eu /* "NKD4": round 5 added the epilogue table to the blobs of the conv + maxpool shapes (common.h EptHeader); NKD3: permuted A rows (kargs.h ws_row_filter) */
+#define PACK_MAGIC 0x35444B4Eu /* "NKD5": the LEAKY byte table in every epilogue table (conv_pool16.hip); NKD4: round 5 added the epilogue table to the blobs of the conv + maxpool shapes (common.h EptHeader); NKD3: permuted A rows (kargs.h ws_row_filter) */
 
 static size_t l0_record_bytes(const layer *l)
 {
