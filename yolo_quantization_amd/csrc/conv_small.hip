@@ -535,12 +535,43 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
             // ---- epilogue: window max, one requantisation per (pixel, channel), biased packed store
             uint32_t po[POOL ? 1 : NJ][4];  // no-pool / stride-2 modes: the packed bytes of the four channel groups, stored together
             (void)po;
+            // POOL: the per-channel constants of a group of four channels are read while the group before it is requantised (the first group's
+            // behind the MFMA chain's issue) -- read where they are used, every group waited for three LDS round trips with one other wave on the
+            // SIMD to cover them (conv_pool16.hip has the measurement)
+            struct GroupConst { int4 dz, lo, hi, m0, sh; };
+            auto group_const = [&](int grp) {
+                const int ch0 = 32 * mt + 16 * kh + 4 * grp;
+                GroupConst g;
+                g.dz = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
+                g.lo = *reinterpret_cast<const int4 *>(ldsLO + ch0);
+                g.hi = *reinterpret_cast<const int4 *>(ldsHI + ch0);
+                g.m0 = *reinterpret_cast<const int4 *>(ldsM0 + ch0);
+                g.sh = *reinterpret_cast<const int4 *>(ldsSH + ch0);
+                return g;
+            };
+            constexpr bool AHEAD = POOL && C == 32;  // (c = 16 sits at its three-workgroups-per-CU register edge: the 20 registers of a group in flight would cost a workgroup)
+            GroupConst gnext = {};
+            if constexpr (AHEAD) {
+                gnext = group_const(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
                 const int ch0 = 32 * mt + 16 * kh + 4 * grp;  // accumulator rows 8 grp + 4 kh + r hold filters 16 kh + 4 grp + r (ws_row_filter)
-                const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
-                const int4 lo4 = *reinterpret_cast<const int4 *>(ldsLO + ch0);
-                const int4 hi4 = *reinterpret_cast<const int4 *>(ldsHI + ch0);
+                GroupConst gc = gnext;
+                if constexpr (AHEAD) {
+                    if (grp < 3) gnext = group_const(grp + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    gc.dz = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
+                    gc.lo = *reinterpret_cast<const int4 *>(ldsLO + ch0);
+                    gc.hi = *reinterpret_cast<const int4 *>(ldsHI + ch0);
+                    if constexpr (POOL) {
+                        gc.m0 = *reinterpret_cast<const int4 *>(ldsM0 + ch0);
+                        gc.sh = *reinterpret_cast<const int4 *>(ldsSH + ch0);
+                    }
+                }
+                const int4 dz4 = gc.dz, lo4 = gc.lo, hi4 = gc.hi;
                 const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
                 const int lov[4] = {lo4.x, lo4.y, lo4.z, lo4.w}, hiv[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
                 int32_t accb[4][4];  // [channel r][window position j]
@@ -552,8 +583,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
                     for (int j = 0; j < 4; ++j) accb[r][j] = j >= NJ ? 0 : (DZM ? acc[j][grp * 4 + r] : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]));
                 }
                 if constexpr (POOL) {
-                    const int4 m04 = *reinterpret_cast<const int4 *>(ldsM0 + ch0);
-                    const int4 sh4 = *reinterpret_cast<const int4 *>(ldsSH + ch0);
+                    const int4 m04 = gc.m0, sh4 = gc.sh;
                     const int m0v[4] = {m04.x, m04.y, m04.z, m04.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
                     uint32_t ub[4][4];
 #pragma unroll
@@ -853,12 +883,36 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         uint32_t pk4[4] = {0, 0, 0, 0};
         uint32_t pj[POOL ? 1 : NJ][4];  // no-pool / stride-2 modes: packed bytes of the four channel groups, stored together
         (void)pj; (void)pk4;
+        // POOL: a group's constants are read while the group before it is requantised (see conv_small_pool_kernel)
+        struct GroupConst { int4 dz, lo, hi, m0, sh; };
+        auto group_const = [&](int grp) {
+            const int ch0 = chw + 16 * kh + 4 * grp;
+            GroupConst g;
+            g.dz = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
+            g.lo = *reinterpret_cast<const int4 *>(ldsLO + ch0);
+            g.hi = *reinterpret_cast<const int4 *>(ldsHI + ch0);
+            g.m0 = *reinterpret_cast<const int4 *>(ldsM0 + ch0);
+            g.sh = *reinterpret_cast<const int4 *>(ldsSH + ch0);
+            return g;
+        };
+        GroupConst gnext = {};
+        if constexpr (POOL) {
+            gnext = group_const(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
             const int ch0 = chw + 16 * kh + 4 * grp;  // (ws_row_filter)
-            const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
-            const int4 lo4 = *reinterpret_cast<const int4 *>(ldsLO + ch0);
-            const int4 hi4 = *reinterpret_cast<const int4 *>(ldsHI + ch0);
+            GroupConst gc = gnext;
+            if constexpr (POOL) {
+                if (grp < 3) gnext = group_const(grp + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                gc.dz = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
+                gc.lo = *reinterpret_cast<const int4 *>(ldsLO + ch0);
+                gc.hi = *reinterpret_cast<const int4 *>(ldsHI + ch0);
+            }
+            const int4 dz4 = gc.dz, lo4 = gc.lo, hi4 = gc.hi;
             const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
             const int lov[4] = {lo4.x, lo4.y, lo4.z, lo4.w}, hiv[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
             int32_t accb[4][4];
@@ -870,8 +924,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
                 for (int j = 0; j < 4; ++j) accb[r][j] = j >= NJ ? 0 : acc[j][grp * 4 + r] + __mul24(dzv[r], sx[j]);
             }
             if constexpr (POOL) {
-                const int4 m04 = *reinterpret_cast<const int4 *>(ldsM0 + ch0);
-                const int4 sh4 = *reinterpret_cast<const int4 *>(ldsSH + ch0);
+                const int4 m04 = gc.m0, sh4 = gc.sh;
                 const int m0v[4] = {m04.x, m04.y, m04.z, m04.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
                 uint32_t ub[4][4];
 #pragma unroll
