@@ -59,6 +59,53 @@ __global__ __launch_bounds__(256, 3) void conv_pool16_kernel(const ConvArgs a)
     const int ntiles = a.B * tpi;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)img;
 
+    // ---- image DMA: instruction k of a plane fills slots [64 k, 64 k + 64); wave w issues k = w, w + 4, w + 8.  The lane's cell offset from the patch
+    //      origin (image row 16 ty - 1, column 32 tx - 1) does not depend on the tile
+    int relc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int q = 64 * (wave + 4 * i) + lane;
+        const int r = min(q / P16_PITCH, 17), sl = q % P16_PITCH;
+        const int half = sl >= P16_HC ? 1 : 0, ci = min(2 * (sl - P16_HC * half) + half, 33);
+        relc[i] = r * W1 + ci;
+    }
+    const int maxcell = a.in_cells - 1;
+    auto issue_tile = [&](unsigned org, int buf) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f = min(max((int)org + relc[i], 0), maxcell);
+            const unsigned voff = (unsigned)f * (unsigned)C;  // in_cs == C (launcher); < 2^32 (launcher)
+            const unsigned d = lds0 + (unsigned)buf * BUFB + (unsigned)(wave + 4 * i) * 1024u;
+            P16_DMA(d, a.x, voff);
+        }
+    };
+
+    // ---- the workgroup's tiles, one lane per tile (see conv_first_mfma_pool_kernel): input origin (cell), output offset (bytes), flags
+    const bool xcd_walk = (gridDim.x & 7) == 0 && !(a.debug & 2048);
+    const int per_x = xcd_walk ? (ntiles + 7) >> 3 : ntiles;
+    const int tstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int tbase_x = xcd_walk ? (int)(blockIdx.x & 7) * per_x : 0;
+    const int tend = min(tbase_x + per_x, ntiles);
+    const int tile0 = tbase_x + (xcd_walk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+    unsigned T_in, T_out, T_fl;
+    int nt;
+    {
+        const int t = tile0 + lane * tstride;
+        nt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(t < tend));  // <= 64 (launcher)
+        const int tc = min(t, ntiles - 1);
+        const int b = fd_div(tc, a.fd_hw);  // (fd_hw / fd_w: the launcher's divisions by tiles per image / tiles per row)
+        const int r = tc - b * tpi;
+        const int ty = fd_div(r, a.fd_w), tx = r - ty * tiles_x;
+        T_in = (unsigned)(a.in_lead + (b * (a.H + 1) + 16 * ty) * W1 + 32 * tx - 1);
+        T_out = (unsigned)(a.pool_lead + (b * (OH + 1) + 8 * ty + 1) * (OW + 1) + 16 * tx) * (unsigned)a.pool_cs;
+        const bool tall = 16 * tx + 16 <= OW && 8 * ty + 8 <= OH;
+        T_fl = (tall ? 2u : 0u) | ((unsigned)tx << 2) | ((unsigned)ty << 12);
+    }
+    auto tile_word = [&](unsigned v, int k) { return (unsigned)__builtin_amdgcn_readlane((int)v, k); };
+
+    // (the first tile's image is requested BEFORE the constants, the byte table and the A fragments are fetched: their latencies overlap)
+    if (nt > 0) issue_tile(tile_word(T_in, 0), 0);
+
     // ---- per-channel constants (LDS), byte table, A fragments (registers)
     const bool ept_ok = a.ept != nullptr && a.ept->key == ept_key(ACT, a.zp_act);  // workgroup-uniform
     const uint32_t eflags = ept_ok ? a.ept->flags : (EPT_NEVER | EPT_NOINT);
@@ -106,52 +153,6 @@ __global__ __launch_bounds__(256, 3) void conv_pool16_kernel(const ConvArgs a)
             baddr[ks][jx] = (unsigned)(((4 * wave + dy) * P16_PITCH + pc + (e & 1) * P16_HC + (e >> 1)) * 16);
         }
     }
-
-    // ---- image DMA: instruction k of a plane fills slots [64 k, 64 k + 64); wave w issues k = w, w + 4, w + 8.  The lane's cell offset from the patch
-    //      origin (image row 16 ty - 1, column 32 tx - 1) does not depend on the tile
-    int relc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int q = 64 * (wave + 4 * i) + lane;
-        const int r = min(q / P16_PITCH, 17), sl = q % P16_PITCH;
-        const int half = sl >= P16_HC ? 1 : 0, ci = min(2 * (sl - P16_HC * half) + half, 33);
-        relc[i] = r * W1 + ci;
-    }
-    const int maxcell = a.in_cells - 1;
-    auto issue_tile = [&](unsigned org, int buf) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int f = min(max((int)org + relc[i], 0), maxcell);
-            const unsigned voff = (unsigned)f * (unsigned)C;  // in_cs == C (launcher); < 2^32 (launcher)
-            const unsigned d = lds0 + (unsigned)buf * BUFB + (unsigned)(wave + 4 * i) * 1024u;
-            P16_DMA(d, a.x, voff);
-        }
-    };
-
-    // ---- the workgroup's tiles, one lane per tile (see conv_first_mfma_pool_kernel): input origin (cell), output offset (bytes), flags
-    const bool xcd_walk = (gridDim.x & 7) == 0 && !(a.debug & 2048);
-    const int per_x = xcd_walk ? (ntiles + 7) >> 3 : ntiles;
-    const int tstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-    const int tbase_x = xcd_walk ? (int)(blockIdx.x & 7) * per_x : 0;
-    const int tend = min(tbase_x + per_x, ntiles);
-    const int tile0 = tbase_x + (xcd_walk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
-    unsigned T_in, T_out, T_fl;
-    int nt;
-    {
-        const int t = tile0 + lane * tstride;
-        nt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(t < tend));  // <= 64 (launcher)
-        const int tc = min(t, ntiles - 1);
-        const int b = fd_div(tc, a.fd_hw);  // (fd_hw / fd_w: the launcher's divisions by tiles per image / tiles per row)
-        const int r = tc - b * tpi;
-        const int ty = fd_div(r, a.fd_w), tx = r - ty * tiles_x;
-        T_in = (unsigned)(a.in_lead + (b * (a.H + 1) + 16 * ty) * W1 + 32 * tx - 1);
-        T_out = (unsigned)(a.pool_lead + (b * (OH + 1) + 8 * ty + 1) * (OW + 1) + 16 * tx) * (unsigned)a.pool_cs;
-        const bool tall = 16 * tx + 16 <= OW && 8 * ty + 8 <= OH;
-        T_fl = (tall ? 2u : 0u) | ((unsigned)tx << 2) | ((unsigned)ty << 12);
-    }
-    auto tile_word = [&](unsigned v, int k) { return (unsigned)__builtin_amdgcn_readlane((int)v, k); };
-
-    if (nt > 0) issue_tile(tile_word(T_in, 0), 0);
 
     // ---- deferred stores (one tile late, behind the next tile's DMA): hand-written, scalar base + lane offset
     const unsigned rowpitch = (unsigned)(OW + 1) * (unsigned)a.pool_cs;
