@@ -6,7 +6,8 @@
 // the whole K (C / 32 K-steps, up to 128 VGPRs at C = 1024), `sets` such wave sets deal the tile's groups of 32 pixels
 // between them.  The tile's input cells are DMAed once (global_load_lds) into LDS in the rows kernel's chunk layout
 // [64-channel chunk][16 pixels x 4 pieces x 16 B]; there is no K loop, no barrier besides the one after the load, and
-// the receptive field of a 1x1 tap is the pixel itself, so sum(x') comes from the B fragments in registers.
+// the receptive field of a 1x1 tap is the pixel itself: sum(x') is the pixel's channel sum, taken once per tile by all waves together
+// (one filter quad: by the wave from its B fragments).
 // Same mathematics and the same bytes as conv_rows.hip (signed-operand decomposition: see conv_igemm.hip); optional
 // float tail of a quant_stop head, fused yolo activations (byte -> logistic table) and nearest-neighbour upsample store.
 #include "kargs.h"
@@ -33,7 +34,7 @@ extern "C" int mi355_debug_read_ts1(long long *host)
 // (HIP's second launch-bound is WAVES PER SIMD, not workgroups per CU: with (512, 2) the LEAKY instantiations took 131-138 registers,
 // three waves per SIMD, i.e. ONE 8-wave workgroup per CU -- every multi-round launch (YOLOv3's 1x1 layers) ran its tile loads with
 // nothing beside them.  Four waves per SIMD = two workgroups per CU wherever the stationary weights leave room: C <= 256.)
-template <int KST, int ACT, bool SAT>
+template <int KST, int ACT, bool SAT, bool COOP>  // COOP: the per-pixel channel sums are taken once per tile by all waves (more than one filter quad)
 __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(con
     // the DMA loop below (which divides for its input cell anyway) instead of twice per group by every wave of the tile
     int *ldsCell = reinterpret_cast<int *>(ldsYL + 256);                  // [chunks * 16]
     int *ldsImg = ldsCell + chunks * 16, *ldsRem = ldsImg + chunks * 16;  // [chunks * 16] each
+    int *ldsSX = ldsRem + chunks * 16;                                     // [chunks * 16] sum of x' over the pixel's channels (the 1x1 tap's receptive field)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
     const int tid = threadIdx.x, NT = blockDim.x;
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(con
                 ldsCell[pi] = n0 + pi < n1 ? (int)oc : -1;  // output cells fit an int: the launcher checks
                 ldsImg[pi] = b;
                 ldsRem[pi] = rem;
+                ldsSX[pi] = 0;
             }
             if (ck < nck)
                 for (int Q = 0; Q < nQ; ++Q) {
@@ -111,6 +114,25 @@ __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     TS1(2);
+    // ---- sum of x' per pixel, ONCE per tile by all waves together (round 5).  Every wave used to sum its B fragments with four V_DOT4 per
+    //      K-step -- the same pixels in each of the workgroup's (up to eight) filter quads: 128 of a 1024 -> 256 wave's ~480 VALU instructions per
+    //      group of 32 pixels, in a kernel whose VALU clocks are twice its MFMA clocks.  The tile image is a run of 16-byte slots
+    //      [chunk Q][16-pixel chunk][piece][pixel]: a wave takes 64 consecutive slots = the four pieces of 16 pixels of one chunk.
+    // (one quad -- the 30-filter heads: nobody to share with, the wave sums its own fragments as before: COOP = false)
+    if constexpr (COOP) {
+        const int nslot64 = (KST >> 1) * chunks;  // runs of 64 slots
+        for (int q = wave; q < nslot64; q += nwave) {
+            const v4i b = *reinterpret_cast<const v4i *>(smem + ((size_t)q * 64 + lane) * 16);
+            int t = __builtin_amdgcn_sdot4(b[0], 0x01010101, 0, false);
+            t = __builtin_amdgcn_sdot4(b[1], 0x01010101, t, false);
+            t = __builtin_amdgcn_sdot4(b[2], 0x01010101, t, false);
+            t = __builtin_amdgcn_sdot4(b[3], 0x01010101, t, false);
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (lane < 16) atomicAdd(&ldsSX[(q % chunks) * 16 + lane], t);
+        }
+        __syncthreads();
+    }
 
     const char *X = smem;
     const int chw = 32 * wq;
@@ -124,18 +146,29 @@ __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(con
             const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + chw + 16 * kh + 4 * grp);  // accumulator rows 8 grp + 4 kh + r hold filters 16 kh + 4 grp + r (kargs.h ws_row_filter)
             acc[grp * 4 + 0] = c4.x; acc[grp * 4 + 1] = c4.y; acc[grp * 4 + 2] = c4.z; acc[grp * 4 + 3] = c4.w;
         }
-        int sxr = 0;
+        int sx;
+        if constexpr (COOP) {
 #pragma unroll
-        for (int s = 0; s < KST; ++s) {
-            const v4i bf = *reinterpret_cast<const v4i *>(X + base + (s >> 1) * qb + (s & 1) * 512);
-            sxr = __builtin_amdgcn_sdot4(bf[0], 0x01010101, sxr, false);
-            sxr = __builtin_amdgcn_sdot4(bf[1], 0x01010101, sxr, false);
-            sxr = __builtin_amdgcn_sdot4(bf[2], 0x01010101, sxr, false);
-            sxr = __builtin_amdgcn_sdot4(bf[3], 0x01010101, sxr, false);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s], bf, acc, 0, 0, 0);
-            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the number of B fragments in flight (registers)
+            for (int s = 0; s < KST; ++s) {
+                const v4i bf = *reinterpret_cast<const v4i *>(X + base + (s >> 1) * qb + (s & 1) * 512);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s], bf, acc, 0, 0, 0);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the number of B fragments in flight (registers)
+            }
+            sx = ldsSX[g * 32 + lj];
+        } else {
+            int sxr = 0;
+#pragma unroll
+            for (int s = 0; s < KST; ++s) {
+                const v4i bf = *reinterpret_cast<const v4i *>(X + base + (s >> 1) * qb + (s & 1) * 512);
+                sxr = __builtin_amdgcn_sdot4(bf[0], 0x01010101, sxr, false);
+                sxr = __builtin_amdgcn_sdot4(bf[1], 0x01010101, sxr, false);
+                sxr = __builtin_amdgcn_sdot4(bf[2], 0x01010101, sxr, false);
+                sxr = __builtin_amdgcn_sdot4(bf[3], 0x01010101, sxr, false);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s], bf, acc, 0, 0, 0);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            sx = sxr + __shfl_xor(sxr, 32);  // the two 16-byte k-halves of every K-step
         }
-        const int sx = sxr + __shfl_xor(sxr, 32);  // the two 16-byte k-halves of every K-step
 
         // ---- this lane's pixel (tables filled by the DMA loop)
         const int ocell = ldsCell[g * 32 + lj];
@@ -209,7 +242,9 @@ __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(con
 template <int KST, int ACT, bool SAT>
 static int c1_launch_kern(ConvArgs &a, hipStream_t st, int grid, int threads, size_t lds)
 {
-    return launch_big_lds<conv1x1_ws_kernel<KST, ACT, SAT>>(grid, threads, lds, st, a);
+    const int n32 = (a.n + 31) & ~31;
+    if (n32 > 32) return launch_big_lds<conv1x1_ws_kernel<KST, ACT, SAT, true>>(grid, threads, lds, st, a);
+    return launch_big_lds<conv1x1_ws_kernel<KST, ACT, SAT, false>>(grid, threads, lds, st, a);
 }
 
 template <int KST, int ACT>
@@ -271,7 +306,7 @@ int conv1x1_ws_launch(ConvArgs &a, hipStream_t st)
     size_t lds = (size_t)(c / 64) * a.sm_ncell * 1024;
     a.lds_param_off = (int)lds;
     const int nfw = n32 < 256 ? n32 : 256;  // filters of a workgroup
-    lds += (size_t)nfw * 16 + 1024 + (size_t)a.sm_ncell * 16 * 12;  // parameters, logistic table, the three per-pixel tables
+    lds += (size_t)nfw * 16 + 1024 + (size_t)a.sm_ncell * 16 * 16;  // parameters, logistic table, the four per-pixel tables
     // two workgroups per CU when a layer needs more than one round; a single round may take the whole LDS
     if (lds > (rounds == 1 && (long)ntiles * mtiles <= 256 ? 160 : 96) * 1024) return MI355_EINVAL;
     if (mtiles > 1 && (a.y_f32 || a.yolo_out || a.up != 1)) return MI355_EINVAL;  // (heads / fused upsample: single filter tile only)
