@@ -176,16 +176,39 @@ __global__ __launch_bounds__(512, (KST <= 8 ? 4 : 2)) void conv1x1_ws_kernel(con
         const int b = ldsImg[g * 32 + lj], rem = ldsRem[g * 32 + lj];
         const int up = a.up;
         uint32_t pk[4];  // the lane's sixteen consecutive filters 16 kh .. + 15 of its quad, stored together
+        // a group's constants are read while the group before it is requantised (conv_small.hip has the measurement: read where they are used,
+        // every group waits for its LDS round trips with one other wave on the SIMD to cover them)
+        struct GroupConst { int4 dz; double mp[4]; };
+        auto group_const = [&](int grp) {
+            const int ch0 = chw + 16 * kh + 4 * grp;
+            GroupConst gc;
+            gc.dz = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gc.mp[r] = ldsMP[ch0 + r];
+            return gc;
+        };
+        constexpr bool AHEAD = KST == 32;  // (measured: c = 1024 -0.3 us in flight; c = 512 (the 30-filter head) +1 us; c <= 256 runs four waves per SIMD at 128 registers and would spill)
+        GroupConst gnext = {};
+        if constexpr (AHEAD) {
+            gnext = group_const(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
             const int ch0 = chw + 16 * kh + 4 * grp;
-            const int4 dz4 = *reinterpret_cast<const int4 *>(ldsDZ + ch0);
-            const int dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
+            GroupConst gc = gnext;
+            if constexpr (AHEAD) {
+                if (grp < 3) gnext = group_const(grp + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                gc = group_const(grp);
+            }
+            const int dzv[4] = {gc.dz.x, gc.dz.y, gc.dz.z, gc.dz.w};
             int32_t accb[4][1], v[4][1];
             double mp[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                mp[r] = ldsMP[ch0 + r];
+                mp[r] = gc.mp[r];
                 accb[r][0] = acc[grp * 4 + r] + __mul24(dzv[r], sx);
             }
             if (pow2) {
