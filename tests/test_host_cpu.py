@@ -40,6 +40,29 @@ def test_host_exports_every_declared_symbol():
     assert "forward_network_gpu" in names and "quantization_weights_and_activations" in names
 
 
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The Python mirror of the C-ABI's structs (binding.ConvDesc / Tensor) has the header's layout: a field added to one side only (round 5:
+    mi355_conv_desc.epilogue_packed) would shift every call's arguments silently."""
+    import subprocess
+    fields = {"mi355_conv_desc": [f[0] for f in binding.ConvDesc._fields_], "mi355_tensor": [f[0] for f in binding.Tensor._fields_]}
+    src = "#include <stddef.h>\n#include <stdio.h>\n#include \"mi355_yolo_int8.h\"\nint main(void) {\n"
+    for st, names in fields.items():
+        src += f'    printf("{st} %zu", sizeof({st}));\n'
+        for n in names:
+            src += f'    printf(" %zu", offsetof({st}, {n}));\n'
+        src += '    printf("\\n");\n'
+    src += "    return 0;\n}\n"
+    c = tmp_path / "layout.c"
+    c.write_text(src)
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    for line, (st, cls) in zip(out, [("mi355_conv_desc", binding.ConvDesc), ("mi355_tensor", binding.Tensor)]):
+        vals = [int(v) for v in line.split()[1:]]
+        assert vals[0] == C.sizeof(cls), st
+        assert vals[1:] == [getattr(cls, f[0]).offset for f in cls._fields_], st
+
+
 def test_no_device_fails_loudly():
     """On a box without a gfx950 the product must refuse, not fall back."""
     L = binding.shim()
