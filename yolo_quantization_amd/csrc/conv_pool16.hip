@@ -25,6 +25,7 @@
 // are six registers instead of LDS reads, + a 4 x 4 byte transpose per quad before the store: bit-identical, 29.8-30.0 us at two waves per
 // SIMD, 40 us at three with spills).
 #include "kargs.h"
+#include <cstdlib>
 #include <type_traits>
 
 constexpr int P16_PITCH = 40;              // 16-byte slots per LDS image row: even cells 0, 2, .. in slots 0 .., odd cells in slots P16_HC ..
@@ -355,7 +356,10 @@ int conv_pool16_launch(ConvArgs &a, hipStream_t st)
     a.fd_hw = fastdiv_make((uint32_t)(tx * ty));
     a.debug = mi355_debug_flags_get();
     // persistent: three workgroups per CU, never more than 64 tiles per workgroup (one lane per tile)
-    long g = 768;
+    // (measured: 384 / 512 workgroups are 1.0-1.5 us faster when the layer floods the chip with itself, 3-9 us slower alone, and the in-flight STEP is 1.5-2 us
+    // slower with them: 768 stays)
+    static const int grid_cap = getenv("MI355_P16_GRID") ? atoi(getenv("MI355_P16_GRID")) : 768;  // (A/B runs)
+    long g = grid_cap;
     if (ntiles < g) g = ntiles;
     const long need = (((ntiles + 7) / 8 + 63) / 64) * 8;
     if (g < need) g = need;
