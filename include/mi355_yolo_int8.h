@@ -60,6 +60,12 @@ extern "C" {
 
 /* ---- runtime (replaces ref src/cuda.c: cuda_set_device :9, cuda_make_array :90-104, cuda_push/pull_array
  *      :151-167, cuda_free :144-149, check_error :27-49) ---------------------------------------------------- */
+/* ABI version of this header.  Structs that cross the boundary (mi355_conv_desc, mi355_tensor) carry no size field: a field is only ever
+ * APPENDED, and every append bumps this number (6: mi355_conv_desc.epilogue_packed).  A caller compares MI355_ABI_VERSION (what it was built
+ * against) with mi355_abi_version() (what it loaded) once at start-up -- the darknet host, integration/mi355_glue.c and the Python binding
+ * all do -- so that a caller built against an older, shorter struct fails loudly instead of having the shim read past its end. */
+#define MI355_ABI_VERSION 6
+int mi355_abi_version(void);
 int mi355_init(int device);                       /* select device, verify gfx950 */
 const char *mi355_last_error(void);
 int mi355_device_count(void);

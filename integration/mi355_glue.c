@@ -115,6 +115,7 @@ static void forward_yolo_mi355(layer l, network net)
 /* ---- bind / run / unbind ------------------------------------------------------------------------------------------ */
 void mi355_bind_network(network *net, int gpu, int accum_mode, int store_mode)
 {
+    if (mi355_abi_version() != MI355_ABI_VERSION) error("libmi355yolo.so and mi355_yolo_int8.h disagree on the ABI version");
     chk(mi355_init(gpu), "mi355_init");
     memset(&G, 0, sizeof(G));
     G.net = net;

@@ -41,16 +41,22 @@ def _planar_tensor(x):
     return t, buf
 
 
-@pytest.mark.parametrize("n,act,store", [(16, "leaky", binding.STORE_WRAP), (32, "relu6", binding.STORE_SATURATE), (16, "linear", binding.STORE_WRAP)])
+# (round 6, ADVICE r05: every activation x store instantiation of the 32-filter planar kernels -- the ones that spill -- is exercised, with and
+# without the packed epilogue table; rounds 2-5 ran three of the twelve)
+@pytest.mark.parametrize("n,act,store", [(16, "leaky", binding.STORE_WRAP), (32, "relu6", binding.STORE_SATURATE), (16, "linear", binding.STORE_WRAP),
+                                         (32, "linear", binding.STORE_WRAP), (32, "leaky", binding.STORE_WRAP), (32, "leaky", binding.STORE_SATURATE),
+                                         (32, "relu6", binding.STORE_WRAP), (32, "linear", binding.STORE_SATURATE), (16, "relu6", binding.STORE_WRAP),
+                                         (16, "leaky", binding.STORE_SATURATE)])
 @pytest.mark.parametrize("B,H,W,zp_in", [(2, 32, 64, 0), (1, 48, 100, 37), (3, 18, 36, 255), (1, 416, 416, 0)])
-def test_first_layer_reads_nchw_planes_in_place(n, act, store, B, H, W, zp_in):
+@pytest.mark.parametrize("ept", [False, True], ids=["derive", "table"])
+def test_first_layer_reads_nchw_planes_in_place(n, act, store, B, H, W, zp_in, ept):
     """The first-layer MFMA kernels fed the reference's colour planes directly (no nchw -> 4-byte-cell conversion pass):
     with and without the fused 2x2/2 maxpool, bytes equal the oracle's conv (+ maxpool); ragged tile edges, non-zero input
     zero point in the pad, every W % 4 == 0."""
     rng = np.random.default_rng(n + B + H + W)
     x = rng.integers(0, 256, (B, 3, H, W), dtype=np.uint8)
     wq, zp_w, bias, mv, sv = _rand_layer(rng, n, 3, 3, 2.0 ** -8, 2.0 ** -5)
-    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, 3, 3, bias, mv, sv))
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, 3, 3, bias, mv, sv, *((binding.ACT[act], 23) if ept else ())))
     xt, keep = _planar_tensor(x)
     d = binding.ConvDesc(n, 3, 3, 1, 1, binding.ACT[act], store, binding.ACC_EXACT, zp_in, 23, 0.05)
     S = binding.shim()

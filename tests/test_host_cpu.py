@@ -463,3 +463,27 @@ def test_first_layer_tile_loop_has_no_memory_wait_inside_its_mfma_chains():
         pytest.skip("no hipcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_l0_waits.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_no_register_of_a_hand_written_load_is_touched_before_its_wait(tmp_path):
+    """tools/check_asm_loads.py: a load issued from inline asm is invisible to the compiler's wait-count model, so the register
+    allocator may spill or copy its destination before the hand-written wait -- silently wrong bytes, and only in the instantiations that
+    happen to spill.  The checker walks every kernel's control-flow graph with the hardware's vmcnt semantics.  (1) it finds the hazard in a
+    unit written to have it; (2) every kernel of conv_aux.hip -- the one unit that ever carried such loads -- is clean."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    tool = os.path.join(ROOT, "tools", "check_asm_loads.py")
+    bad = tmp_path / "bad.hip"
+    bad.write_text('#include <hip/hip_runtime.h>\n'
+                   '__global__ void k(const unsigned *p, unsigned *o) {\n'
+                   '    unsigned v = 7, off = threadIdx.x * 4;\n'
+                   '    asm volatile("global_load_dword %0, %1, %2" : "+v"(v) : "v"(off), "s"(p) : "memory");\n'
+                   '    o[threadIdx.x] = v;                       // read with the load in flight, as far as the compiler knows a plain register\n'
+                   '    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");\n'
+                   '    o[threadIdx.x + 64] = v;\n'
+                   '}\n')
+    r = subprocess.run([sys.executable, tool, "--src", str(bad)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "still in flight" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -105,7 +105,13 @@ def check(rc, what=""):
         raise MI355Error(f"{what}: code {rc}: {shim().mi355_last_error().decode()}")
 
 
+ABI_VERSION = 6  # include/mi355_yolo_int8.h MI355_ABI_VERSION: the struct mirrors above are this version's
+
+
 def init(device=0):
+    got = shim().mi355_abi_version()
+    if got != ABI_VERSION:
+        raise MI355Error(f"libmi355yolo.so speaks ABI {got}, binding.py mirrors ABI {ABI_VERSION}")
     check(shim().mi355_init(device), "mi355_init")
 
 

@@ -82,6 +82,9 @@ struct L0Lane {
     int32_t pad_[4];
 };
 static_assert(sizeof(L0Lane) == 256, "L0Lane is one 256-byte record");
+// (the store mode is not part of the key: the table's ranges are derived for the WRAPPING store, under which they are the tightest; a saturating
+// store is monotone everywhere, so a user may only ever NARROW a table range for it, never widen it -- today every saturating launch ignores the
+// table altogether: `have_ept = !SAT && ...` in the kernels)
 __host__ __device__ inline uint32_t ept_key(int act, int zp_act) { return 0x45500000u | ((uint32_t)(act & 0xFF) << 8) | (uint32_t)(zp_act & 0xFF); }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -259,6 +262,17 @@ __device__ __forceinline__ void requant_values_mp(const int32_t (&accb)[NV], con
 // safe-range test that no byte of the window wraps, i.e. zp + q <= 255 and 10 zp + 4 >= -q: always inside the table.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LUTQ_OFF = 3072, LUTQ_N = 4096;
+// Index of floor-form value f in the table.  The pooled kernels look the byte up BEFORE they know whether the window lay inside the wrap-safe
+// range (a window outside it is redone in the reference's order and the byte discarded), so f may be any int32: the index is clamped into the
+// table with one v_med3_i32 -- an unclamped index is an out-of-bounds array access in C++ even though the hardware read is harmless.
+// -DMI355_LUT_NOCLAMP restores round 5's unclamped read for A/B timing only.
+__device__ __forceinline__ int lutq_index(int f) {
+#ifdef MI355_LUT_NOCLAMP
+    return f + LUTQ_OFF;
+#else
+    return min(max(f, -LUTQ_OFF), LUTQ_N - LUTQ_OFF - 1) + LUTQ_OFF;
+#endif
+}
 template <bool SAT>
 __host__ __device__ __forceinline__ uint32_t leaky_byte_biased(int32_t q, int zp_act)
 {

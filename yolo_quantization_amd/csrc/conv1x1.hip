@@ -15,7 +15,7 @@
 #define DMA_S(ldsdst_u32, sbase_ptr, voff_u32)                                                                   \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst_u32), "v"(voff_u32), \
                  "s"(sbase_ptr)                                                                                  \
-                 : "memory")
+                 : "memory", "m0")
 
 constexpr int P1_GMAX = 8;  // groups of 32 pixels per tile
 

@@ -365,6 +365,8 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
 #pragma unroll
     for (int k = 0; k < 3; ++k) offk[k] = (unsigned)(planar_off + (int)plane_sz) + (unsigned)k * (unsigned)plane_sz;
     const uint8_t *const xm1 = a.x - plane_sz;  // (only ever dereferenced one plane or more further on)
+    // raw buffer descriptor over the planes (stride 0, no range to speak of: the launcher refuses inputs of 2 GiB and more; word 3 = 32-bit data format)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(xm1), 0, (int)0xFFFFFFFFu, 0x00020000);
 
     // ---- The workgroup's tiles, ONE LANE PER TILE (round 5).  Rounds 1-4 carried the tile position (b, ty, tx) in scalar registers and advanced it
     // with carries, then derived the input origin, the "interior tile" test, the output offset and the "whole patch inside the map" test from it:
@@ -402,21 +404,29 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
 
     auto fetch = [&](unsigned org, unsigned fl, uint32_t(&v)[3]) {
         if constexpr (PLANAR) {
-            // wave-uniform base on the scalar unit + the thread's loop-invariant 32-bit offsets, in the instruction's scalar-base form.  Written by
-            // hand: the compiler widens the loop-invariant offsets to 64 bits outside the loop and then adds base and offset on the VALU (three
-            // v_lshl_add_u64 per tile, six registers) -- and like the deferred stores these loads are invisible to its wait-count model, which
-            // therefore never has a reason to put a vmcnt wait into the tile loop (see `run`); `land` below is the one wait, right in front of
-            // the staging that consumes the three dwords.
+            // wave-uniform tile origin in the instruction's SCALAR offset + the thread's loop-invariant 32-bit offsets in its vector offset: a raw
+            // buffer load (descriptor = the input one plane early, built once per kernel), so no 64-bit address arithmetic per tile (the compiler
+            // widens a pointer + loop-invariant offset to 64 bits outside the loop and adds base and offset on the VALU: three v_lshl_add_u64 per
+            // tile, six registers).  Round 5 wrote these loads as inline asm (`global_load_dword v, voff, s[base]`) with one hand-written wait in
+            // front of the staging; a load the compiler cannot see is a load whose destination it may spill or copy BEFORE the wait -- the 32-filter
+            // instantiations did exactly that (`global_load_dword v6 ...` followed by `scratch_store_dword v6`), silently wrong bytes.
+            // The builtin is visible to the wait-count model: a spill waits first.  MI355_L0_ASM_PREFETCH keeps the old form for A/B runs only.
+#ifdef MI355_L0_ASM_PREFETCH
             const uint64_t tb = reinterpret_cast<uint64_t>(xm1) + (uint64_t)org;
             const uint64_t tbs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tb);
             auto load3 = [&]() {
-                // ("+v": under a lane mask the loads leave the other lanes' registers alone -- the border path's pad value sits in the SAME registers,
-                // no merge behind the loads that could read them before they land)
                 asm volatile("global_load_dword %0, %3, %6\n\tglobal_load_dword %1, %4, %6\n\tglobal_load_dword %2, %5, %6"
                              : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])
                              : "v"(offk[0]), "v"(offk[1]), "v"(offk[2]), "s"(tbs)
                              : "memory");
             };
+#else
+            const int so = __builtin_amdgcn_readfirstlane((int)org);
+            auto load3 = [&]() {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)offk[k], so, 0);
+            };
+#endif
             if (fl & 1u) {
                 if (tid < 180) load3();
             } else {  // out-of-image groups are the input zero point
@@ -455,9 +465,11 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
         }
     };
 
-    // the prefetched dwords have landed (PLANAR: hand-written loads, so this is the wait; the operands tie every later use of the registers to it)
+    // the prefetched dwords have landed: the compiler places that wait itself in front of the staging (A/B build with hand-written loads: this is the wait)
     auto land = [&](uint32_t(&v)[3]) {
+#ifdef MI355_L0_ASM_PREFETCH
         if constexpr (PLANAR) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])::"memory");
+#endif
     };
     uint32_t nxt[3] = {0, 0, 0};
     unsigned fl_cur = tile_word(T_fl, 0);
@@ -682,7 +694,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
 #ifndef MI355_L0_LEAKY_ARITH
                                 uint32_t bt[4];
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) bt[r] = lut[f[r] + LUTQ_OFF];  // (a window beyond the range may index anywhere: an LDS read outside the
+                                for (int r = 0; r < 4; ++r) bt[r] = lut[lutq_index(f[r])];  // (a window beyond the range may index anywhere: an LDS read outside the
                                                                                               // workgroup's allocation returns 0, and the tile is redone below)
                                 packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
 #else  // A/B build: LEAKY in four VALU instructions on the floor form instead of the table's LDS round trip
@@ -770,7 +782,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                                 if constexpr (LUT) {
                                     uint32_t bt[4];
 #pragma unroll
-                                    for (int r = 0; r < 4; ++r) bt[r] = lut[f[r] + LUTQ_OFF];
+                                    for (int r = 0; r < 4; ++r) bt[r] = lut[lutq_index(f[r])];
                                     packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
                                 } else {  // RELU6: zp + max(q, 0) == zp + max(f, 0); SAT clamps
                                     int32_t v[4];
@@ -800,7 +812,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_pool_kernel(const AuxA
                                 for (int r = 0; r < 4; ++r) qq[r] = (int32_t)dd[r];
                                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) bt[r] = lut[qq[r] + LUTQ_OFF];
+                                for (int r = 0; r < 4; ++r) bt[r] = lut[lutq_index(qq[r])];
                                 packed = pack4_bytes(bt[0], bt[1], bt[2], bt[3]);
                             } else {
                                 int32_t amax[4][1], v1[4][1];

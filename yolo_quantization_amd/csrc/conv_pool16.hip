@@ -36,7 +36,7 @@ constexpr int P16_PLANEB = P16_NDMA * 1024;
 #define P16_DMA(ldsdst_u32, sbase_ptr, voff_u32)                                                                  \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst_u32), "v"(voff_u32), \
                  "s"(sbase_ptr)                                                                                  \
-                 : "memory")
+                 : "memory", "m0")
 
 template <int ACT, bool SAT>
 __global__ __launch_bounds__(256, 3) void conv_pool16_kernel(const ConvArgs a)
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 3) void conv_pool16_kernel(const ConvArgs a)
                     for (int r = 0; r < 4; ++r) f[r] = __mulhi((int32_t)(umax[r] + (uint32_t)lo[r]), m0[r]) >> sh[r];
                     if constexpr (LUT) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) bt[q & 1][r] = lut[f[r] + LUTQ_OFF];  // (beyond the range: anywhere, even outside the allocation -> 0; redone below)
+                        for (int r = 0; r < 4; ++r) bt[q & 1][r] = lut[lutq_index(f[r])];  // (beyond the range: anywhere, even outside the allocation -> 0; redone below)
                     } else {  // RELU6: zp + max(q, 0) == zp + max(f, 0); SAT clamps
                         int32_t v[4];
 #pragma unroll

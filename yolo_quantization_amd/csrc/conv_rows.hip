@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, 2) void conv_rows_i8_kernel(const C
 #define DMA_S(ldsdst_u32, sbase_ptr, voff_u32)                                                                   \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst_u32), "v"(voff_u32), \
                  "s"(sbase_ptr)                                                                                  \
-                 : "memory")
+                 : "memory", "m0")
     // Channel-chunk rotation: workgroup `ntile` walks the chunks in the order rot, rot+1, .., nchunks-1, 0, .., rot-1
     // (exact int32 accumulation does not care).  All workgroups run in lockstep, and a chunk is the same 64 bytes of
     // every in_cs-byte cell: without the rotation the whole chip reads one quarter of the tensor's cache lines -- a few

@@ -38,7 +38,7 @@
 #define DMA_S(ldsdst_u32, sbase_ptr, voff_u32)                                                                   \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst_u32), "v"(voff_u32), \
                  "s"(sbase_ptr)                                                                                  \
-                 : "memory")
+                 : "memory", "m0")
 
 #ifdef MI355_ABLATE
 // per-wave shader-clock sums of conv_small_pool_kernel's phases (tools/small_phases.py): [0] image wait + barrier, [1] deferred stores + next

@@ -88,7 +88,7 @@ __host__ __device__ constexpr int ws3_pm2_lane(int row, int col)  // inverse
 #define WS3_DMA(ldsdst_u32, sbase_ptr, voff_u32)                                                                  \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsdst_u32), "v"(voff_u32), \
                  "s"(sbase_ptr)                                                                                  \
-                 : "memory")
+                 : "memory", "m0")
 constexpr int WS3_GMAX = 8;    // groups of 32 pixels per tile
 constexpr int WS3_UB = 8;      // 16-byte staging loads in flight per thread
 

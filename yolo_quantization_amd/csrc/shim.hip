@@ -38,6 +38,8 @@ int mi355_device_count(void)
     return n;
 }
 
+int mi355_abi_version(void) { return MI355_ABI_VERSION; }
+
 int mi355_init(int device)
 {
     int n = 0;

@@ -251,6 +251,10 @@ static void plan_views(network *net)
 
 static void alloc_network_device(network *net)
 {
+    if (mi355_abi_version() != MI355_ABI_VERSION) {
+        fprintf(stderr, "libmi355yolo.so speaks ABI %d, this host was built against %d\n", mi355_abi_version(), MI355_ABI_VERSION);
+        error("mi355 ABI mismatch");
+    }
     check_mi355(mi355_init(net->gpu_index), "mi355_init");
     if (!net->stream && !net->on_default_stream) check_mi355(mi355_stream_acquire(&net->stream), "stream");
     if (net->input_uint8_gpu) mi355_free(net->input_uint8_gpu);
