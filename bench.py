@@ -59,6 +59,12 @@ def parse_args():
                     help="CPU dry run of the multi-rank start-up (no GPU needed): the same launcher, rendezvous, packed-weights broadcast, image "
                          "sharding and max-over-ranks timing code on the gloo backend, host-only prep; rank 0 prints one JSON line and the "
                          "exit code is 0 only when every rank ends up with byte-identical packed state")
+    ap.add_argument("--small-m-channels", type=int, default=0,
+                    help="unfriendly model (VERDICT r05 #6): the first N filters of every conv get float weights 64x smaller, i.e. requantisation multipliers ~2e-5 "
+                         "that fall outside the kernels' integer requantisation (synth.synth_weights small_m_channels)")
+    ap.add_argument("--input", choices=["synthetic", "realimg"], default="synthetic",
+                    help="realimg: the real-image fixture tests/golden/realimg_416.npz (network input bytes of a photograph) in every slot of the batch instead of uniform random bytes")
+    ap.add_argument("--no-preroll-leg", action="store_true", help="skip the rounds 1-4 style region (W warm-up + K timed steps, no pre-roll) that is timed once ahead of the pre-roll")
     ap.add_argument("--preroll", type=int, default=160,
                     help="untimed in-flight steps queued in front of the W warmup steps (0: none).  The device's power management needs ~100 steps (25 ms) of THIS "
                          "load to settle its clocks after any idle or lightly loaded phase -- the host-side set-up and the self-check passes (whose checksum kernels "
@@ -130,12 +136,16 @@ def pmc_traffic_per_launch():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))  # rNN_vM_...: the name orders them (mtimes do not survive a snapshot)
     if not files:
         return None, None
-    rows = [r for r in json.load(open(files[-1])) if "conv_rows_i8_kernel" in r["kernel"] or "conv_rows16_i8_kernel" in r["kernel"]]
-    n = sum(r["launches"] for r in rows)
-    if not n:
-        return None, None
-    tot = sum(((r["hbm_read_bytes_per_launch"] or 0) + (r["hbm_write_bytes_per_launch"] or 0)) * r["launches"] for r in rows)
-    return tot / n, os.path.relpath(files[-1], ROOT)
+    def avg(names):
+        rows = [r for r in json.load(open(files[-1])) if any(nm in r["kernel"] for nm in names)]
+        n = sum(r["launches"] for r in rows)
+        if not n:
+            return None
+        return sum(((r["hbm_read_bytes_per_launch"] or 0) + (r["hbm_write_bytes_per_launch"] or 0)) * r["launches"] for r in rows) / n
+    rows_only = avg(("conv_rows_i8_kernel", "conv_rows16_i8_kernel"))
+    # the north-star layer set's kernels (every 3x3 stride-1 conv with c > 3 under the throughput plan)
+    ns = avg(("conv_rows_i8_kernel", "conv_rows16_i8_kernel", "conv_pool16_kernel", "conv_small32_kernel", "conv_small_pool_kernel<32", "conv_mid_pool_kernel"))
+    return (ns, rows_only), os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(cfg, wts, nimg, omp=False, threads=None):
@@ -187,6 +197,45 @@ def cpu_baseline(cfg, wts, nimg, omp=False, threads=None):
         kind = "port"
     return {"value": nimg / dt, "unit": "images/s", "cores": ((threads or os.cpu_count()) if omp and kind == "reference" else 1), "kind": kind,
             "sample": f"{nimg} x {os.path.basename(cfg)} {shapes[0].h}x{shapes[0].w} image, whole net, batch 1, {os.cpu_count()} host cores present"}
+
+
+def microbench_config1(binding, iters=30):
+    """BASELINE config[1]: ONE 3x3 s1 conv 256 -> 256 @52x52, batch 32 (uint8 in / int8 w), launched back to back on one stream through the
+    C-ABI; HIP events on that stream around `iters` launches.  No epilogue / HBM excuse here: 102 GOP against ~5 MB of operands."""
+    import ctypes as C
+    import numpy as np
+    S = binding.shim()
+    c = n = 256; hw = 52; batch = 32; k = 3
+    x = np.random.default_rng(1).integers(0, 256, (batch, c, hw, hw), dtype=np.uint8)
+    wq = np.random.default_rng(2).integers(0, 256, (n, c * k * k), dtype=np.uint8)
+    zp_w = np.random.default_rng(3).integers(100, 157, n, dtype=np.uint8)
+    xt = binding.DevTensor.from_nchw(x, 0)
+    y = binding.DevTensor(batch, hw, hw, n, 23)
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, k, np.zeros(n, np.int32), np.full(n, 0.75), np.full(n, 2.0 ** -13)))
+    d = binding.ConvDesc(n, c, k, 1, 1, binding.ACT["leaky"], 0, 0, 0, 23, 1.0)
+    st = C.c_void_p(); binding.check(S.mi355_stream_create(C.byref(st)), "stream")
+    e0 = C.c_void_p(); e1 = C.c_void_p()
+    S.mi355_event_create(C.byref(e0)); S.mi355_event_create(C.byref(e1))
+
+    def launch():
+        binding.check(S.mi355_conv_forward(C.byref(d), xt.ref(), blob.ptr, None, None, y.ref(), None, None, st), "conv (config[1])")
+    for _ in range(5):
+        launch()
+    S.mi355_stream_sync(st)
+    S.mi355_event_record(e0, st)
+    for _ in range(iters):
+        launch()
+    S.mi355_event_record(e1, st)
+    ms = C.c_float()
+    binding.check(S.mi355_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
+    fam = S.mi355_last_conv_kernel()
+    S.mi355_event_destroy(e0); S.mi355_event_destroy(e1); S.mi355_stream_destroy(st)
+    t = ms.value / iters * 1e-3
+    ops = 2.0 * n * c * k * k * hw * hw * batch
+    return {"workload": "BASELINE config[1]: single 3x3 s1 conv 256->256 ch, 52x52, batch 32, uint8 in / int8 w (random uint8 operands), one kernel per launch",
+            "us_per_launch": round(t * 1e6, 2), "achieved": round(ops / t / 1e12, 1), "unit": "TOP/s", "peak": round(PEAK_INT8_TOPS, 1),
+            "frac": round(ops / t / 1e12 / PEAK_INT8_TOPS, 4), "ops_per_launch": ops, "launches": iters, "kernel_family": fam,
+            "note": "HIP events on the launch stream around back-to-back launches, alone on the device, after the timed region; never part of `value`"}
 
 
 def flush_c_stdio():
@@ -369,7 +418,7 @@ def main():
 
     # ---- model: rank 0 reads the weights file, preps and packs; the packed bytes travel by RCCL broadcast
     if rank == 0:
-        synth.synth_weights(args.cfg, wts, seed=1234)
+        synth.synth_weights(args.cfg, wts, seed=1234, small_m_channels=args.small_m_channels)
         net = binding.Net(args.cfg, wts, batch=B, gpu=local_rank, use_graph=args.graph, keep_head_float=False)
         net.prepare_fixed(1.0 / 255.0, 0)
         packed = net.export_packed()
@@ -393,6 +442,11 @@ def main():
     in_c, in_h, in_w = net.info[0]["c"], net.info[0]["h"], net.info[0]["w"]  # 3 x 416 x 416 for the headline cfg
     img0, img1 = image_shard(rank, world, B)  # this rank's images of the global batch (weak scaling: B per rank)
     x = synth.synth_image_u8(in_c, in_h, in_w, seed=1000 + img0 // max(B, 1), batch=img1 - img0)
+    real = None
+    if args.input == "realimg":  # (timing on real-image statistics: the same photograph in every slot of every instance's batch)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "realimg_416.npz"))
+        real = np.ascontiguousarray(np.broadcast_to(g["input_u8"].reshape(1, in_c, in_h, in_w), (img1 - img0, in_c, in_h, in_w)))
+        x = real
     net.push_input(x)
     net.sync()
 
@@ -402,7 +456,7 @@ def main():
         # the fourth instance runs on the device's default stream: HIP maps every created stream onto three of the device's four
         # hardware queues and keeps the fourth for that one (a fourth created stream shares a queue: 0.272 -> 0.30 ms per step)
         nk = net.replica(default_stream=(k == 3 and not args.graph))
-        nk.push_input(synth.synth_image_u8(in_c, in_h, in_w, seed=1000 + rank + 7919 * k, batch=B))
+        nk.push_input(real if real is not None else synth.synth_image_u8(in_c, in_h, in_w, seed=1000 + rank + 7919 * k, batch=B))
         nk.sync()
         nets.append(nk)
 
@@ -427,6 +481,25 @@ def main():
     # (the determinism self-check used to run HERE, in front of the warm-up; it now runs after the timed region and its legs -- see below: its passes,
     # with their single-workgroup checksum kernels, leave the device in a state from which a 20-step region still measures 0.256-0.258 ms per step
     # after 165 plain steps, where the same region without them measures 0.246: profiles/r05_warmup_curve.log)
+    # (round 6, ADVICE r05 / VERDICT r05 #5: the rounds 1-4 protocol -- W warm-up steps, then K timed steps, nothing in front of them -- once, BEFORE the
+    # pre-roll, so that the line carries both figures of the same run: `no_preroll` is comparable with BENCH_r01-r04, `value` with r05 on)
+    no_preroll = None
+    if args.preroll > 0 and not args.no_preroll_leg:
+        for i in range(args.warmup):
+            nets[i % len(nets)].forward()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            nets[i % len(nets)].forward()
+        barrier()
+        np_dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([np_dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            np_dt = float(t.item())
+        no_preroll = {"ms_per_step": round(np_dt / args.steps * 1e3, 4), "value": round(world * B * args.steps / np_dt, 1), "steps": args.steps, "warmup": args.warmup,
+                      "note": "the same K steps timed the way rounds 1-4 timed them (W warm-up steps on a device that has just been set up, no pre-roll), "
+                              "run BEFORE the pre-roll of this line's `value`; a short region on a device whose clocks are still settling (DESIGN.md 4.6)"}
     for i in range(max(args.preroll, 0)):  # untimed, unsynchronised: the same in-flight load as the timed steps (see --preroll)
         nets[i % len(nets)].forward()
     for i in range(args.warmup):
@@ -582,6 +655,14 @@ def main():
                           "note": f"{e_steps} in-flight steps after the timed region, amdgpu hwmon power1_input / freq1_input every 5 ms (second half of the samples); "
                                   "the chip's cap is 1 400 W: at the cap a step costs its energy, not its instruction count (DESIGN.md 4.4)"}
 
+    # ---- BASELINE config[1] microbench leg (rank 0, one GPU): the one-kernel MFMA-I8 shape with its own roofline fraction
+    microbench = None
+    if extra_legs and os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg":
+        try:
+            microbench = microbench_config1(binding)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] config[1] microbench leg failed ({e})", file=sys.stderr)
+
     # ---- determinism self-check (a race detector for kernels scheduled by hand: counted waits, registers reloaded in place): N passes over the
     # resident input on every instance at once (their passes overlap on the device like the timed steps), a device-side order-independent checksum
     # of the yolo outputs after each pass; a pass that differs from the first fails the run.  After the timed region and its legs, never inside them.
@@ -656,24 +737,33 @@ def main():
         nlaunch = sum(1 for i, inf in enumerate(net.info) if on_rows_kernel(i, inf))
         nconv = sum(1 for inf in net.info if inf["type"] == binding.T_CONV)
         achieved = mf_ops / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
-        traffic, traffic_src = pmc_traffic_per_launch()
-        roof = {"bound": "mfma", "kernel": f"conv_rows16_i8_kernel / conv_rows_i8_kernel (row-image MFMA implicit GEMM on 64-channel chunks, 3x3 on V_MFMA_I32_16X16X64_I8: {nlaunch} of the step's {nconv} conv launches, "
-                          f"{100 * mf_ms / all_ms:.0f}% of its time and {100 * mf_ops / all_ops:.0f}% of its operations)",
-                "achieved": round(achieved, 2), "peak": round(PEAK_INT8_TOPS, 1), "unit": "TOP/s",
-                "frac": round(achieved / PEAK_INT8_TOPS, 4),
+        (traffic, traffic_rows), traffic_src = pmc_traffic_per_launch() if pmc_traffic_per_launch()[0] else ((None, None), None)
+        # Headline (round 6): the NORTH-STAR layer set -- every 3x3 stride-1 conv with c > 3, whichever kernel serves it, fused maxpools
+        # included -- per launch alone on the device.  Rounds 1-5 put the row-image launches (the five best) here; they are `row_image_launches` now.
+        n33 = sum(1 for inf in net.info if inf["type"] == binding.T_CONV and inf["size"] == 3 and inf["stride"] == 1 and inf["c"] > 3)
+        ach33 = s33_ops / (s33_ms * 1e-3) / 1e12 if s33_ms else 0.0
+        roof = {"bound": "mfma", "kernel": f"the {n33} 3x3 stride-1 conv launches with c > 3 (BASELINE north_star's layer set: conv_pool16 / conv_small32 / conv_mid_pool / conv_rows / conv_rows16 on "
+                          f"V_MFMA_I32_*_I8, fused maxpools included: {100 * s33_ms / all_ms:.0f}% of the step's time and {100 * s33_ops / all_ops:.0f}% of its operations)",
+                "achieved": round(ach33, 2), "peak": round(PEAK_INT8_TOPS, 1), "unit": "TOP/s",
+                "frac": round(ach33 / PEAK_INT8_TOPS, 4),
+                "row_image_launches": {"kernel": f"conv_rows16_i8_kernel / conv_rows_i8_kernel (row-image MFMA implicit GEMM on 64-channel chunks: {nlaunch} of the step's {nconv} conv launches, "
+                                                 f"{100 * mf_ms / all_ms:.0f}% of its time and {100 * mf_ops / all_ops:.0f}% of its operations) -- what `roofline.frac` covered in rounds 1-5",
+                                       "achieved": round(achieved, 2), "frac": round(achieved / PEAK_INT8_TOPS, 4),
+                                       "ops_per_launch_avg": mf_ops / max(nlaunch, 1), "ms_per_launch_avg": round(mf_ms / max(nlaunch, 1), 5),
+                                       "traffic": traffic_rows if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg" else None},
                 "measured_on": ("the serial leg after the timed region (one batch at a time: the kernel alone on the device, as in rocprofv3's trace of --inflight 1)"
                                 if ninfl > 1 else "the timed region"),
                 "traffic": traffic if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg" else None,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                 "traffic_source": f"committed profile {traffic_src} -- not measured in this run" if traffic_src else None,
-                "ops_per_launch_avg": mf_ops / max(nlaunch, 1), "ms_per_launch_avg": round(mf_ms / max(nlaunch, 1), 5),
+                "ops_per_launch_avg": s33_ops / max(n33, 1), "ms_per_launch_avg": round(s33_ms / max(n33, 1), 5),
                 "conv3x3_s1_aggregate": {"tops": round(s33_ops / (s33_ms * 1e-3) / 1e12, 1) if s33_ms else None,
                                          "frac": round(s33_ops / (s33_ms * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4) if s33_ms else None,
                                          "ms": round(s33_ms, 5), "layers": "every 3x3 stride-1 conv with c > 3"},
                 # what a loop of NOTHING but V_MFMA_I32_32X32X32_I8 sustains on this chip depends on the operand bytes (power
                 # management lowers the shader clock): 4 760-4 940 TOP/s on zeros, 3 490 on uniform random bytes
                 # (tools/ubench/mfma_data_power.hip, profiles/r02_v3_ubench_mfma_data_power.log).  `peak` / `frac` stay nominal.
-                "mfma_only_loop_random_operands": {"tops": 3490.0, "frac_of_it": round(achieved / 3490.0, 4),
+                "mfma_only_loop_random_operands": {"tops": 3490.0, "frac_of_it": round(ach33 / 3490.0, 4),
                                                    "source": "profiles/r02_v3_ubench_mfma_data_power.log -- not measured in this run"},
                 "input_layout_ms": round(in_layout_ms, 5),
                 "event_overhead_ms": round(ev_cost, 5)}
@@ -725,6 +815,8 @@ def main():
                                      + f"{c33['frac']} per launch alone on the device")
         if energy:
             roof["energy"] = energy
+        if microbench:
+            roof["microbench_config1"] = microbench
         if latency_leg and latency_leg[0]:
             n_lat, lat_prof, lat_dt, lat_rows = latency_leg
             l_rows, _, _ = layer_table(lat_prof[0], lat_prof[1], lat_dt, 32)
@@ -788,12 +880,14 @@ def main():
     if rank == 0:
         out = {"metric": METRICS.get(os.path.basename(args.cfg), f"images/sec {os.path.basename(args.cfg)} INT8"), "value": round(value, 1), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "warmup_passes_effective": args.warmup + max(args.preroll, 0),  # the pre-roll steps are queued right in front of the warmup steps
+               "warmup_passes_effective": args.warmup + max(args.preroll, 0) + (no_preroll["steps"] + no_preroll["warmup"] if no_preroll else 0),  # the pre-roll steps are queued right in front of the warmup steps (and the no_preroll leg ran before them)
+               "no_preroll": no_preroll,
                "preroll_steps": max(args.preroll, 0),  # untimed steps of the same load that let the device's clocks settle (--preroll; the timed region is exactly `steps` steps)
                "ms_per_step": round(ms_per_step, 4),
                "host_issue_ms": round(t_issued * 1e3, 3),  # host time to queue the K steps of the timed region (its total is ms_per_step * steps)
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 x s8 -> int32 (f64 or exact-integer requant, bit-identical)",
-               "data": "synthetic",
+               "data": "synthetic" + ("" if args.input == "synthetic" else " weights, real-image fixture (tests/golden/realimg_416.npz) in every batch slot")
+                       + (f", unfriendly model: {args.small_m_channels} filters per conv with multipliers ~2e-5" if args.small_m_channels else ""),
                "config": {"workload": "yolov3-tiny full net (cfg/yolov3-tiny_quant.cfg, leaky, per-channel quant), "
                                       f"batch {B}/GPU synthetic uint8 {in_h}x{in_w}, inputs resident in HBM (NCHW uint8)"
                                       if os.path.basename(args.cfg) == "yolov3-tiny_quant.cfg" else

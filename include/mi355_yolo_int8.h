@@ -220,14 +220,15 @@ int mi355_conv_set_tile(int bm, int bn);
  * in only with -DMI355_ABLATE: results are WRONG when set; tools/conv_microbench.py --ablate only.  Two bits select
  * among equivalent kernels and leave results unchanged (tests use them to cross-check): 512 = conv_rows.hip walks the
  * channel chunks unrotated, 1024 = fused conv+maxpool never uses conv_small.hip / the first-layer MFMA kernel, 8192 = 1x1
- * layers never use conv1x1.hip, 16384 = 3x3 layers never use conv_ws3.hip, 2^20 = the row-image 3x3 kernel on the 32x32x32 MFMA
+ * layers never use conv1x1.hip, 4096 = 32 -> 64 conv + maxpool on conv_small32.hip (round 6: eight waves per workgroup, measured slower; conv_small.hip without the bit), 16384 = 3x3 layers never use conv_ws3.hip, 2^20 = the row-image 3x3 kernel on the 32x32x32 MFMA
  * (conv_rows.hip) instead of the 16x16x64 one (conv_rows16.hip), 2^21 = mi355_conv_pool_forward refuses the 128 / 256-channel
  * layers (the host then runs conv and maxpool separately), 2048 = plain tile walk in the first-layer kernels, 131072 = no raised
  * priority around the MFMA chains of the conv+pool kernels. */
 int mi355_debug_flags(int flags);
 /* Which kernel family served the calling thread's most recent mi355_conv_*forward call (tests assert that a shape reaches
  * the kernel it is meant to exercise): 0 none yet, 1 first layer (conv_aux.hip), 2 conv_small.hip (few-channel / 64-channel
- * conv + maxpool), 3 conv1x1.hip, 4 conv_ws3.hip, 5 conv_igemm.hip / conv_rows.hip / conv_rows16.hip, 6 fp32-accumulate emulation. */
+ * conv + maxpool), 3 conv1x1.hip, 4 conv_ws3.hip, 5 conv_igemm.hip / conv_rows.hip / conv_rows16.hip, 6 fp32-accumulate emulation,
+ * 7 conv_pool16.hip (16 -> 32 + maxpool with the packed epilogue table), 8 conv_small32.hip (32 -> 64 + maxpool). */
 int mi355_last_conv_kernel(void);
 
 /* ---- glue layers ---------------------------------------------------------------------------------------- */

@@ -465,6 +465,53 @@ def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain, ept):
     assert np.array_equal(yp2.to_nchw(), want_pool)
 
 
+@pytest.mark.parametrize("B,H,W,act", [(3, 14, 70, "leaky"), (2, 34, 34, "linear"), (1, 104, 104, "leaky"), (2, 16, 32, "relu6"), (1, 152, 152, "leaky"),
+                                       (5, 6, 10, "relu6"), (1, 40, 300, "leaky"), (16, 26, 26, "leaky")])
+@pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
+@pytest.mark.parametrize("gain", ["no-wrap", "some-wrap", "much-wrap"])
+@pytest.mark.parametrize("table", ["none", "match", "other-zero-point", "shift-not-pow2"])
+def test_conv_small32_kernel(B, H, W, act, store, gain, table):
+    """conv_small32.hip (round 6: 32 -> 64 channels + maxpool, conv_small.hip's tile on eight waves of one m-tile each, the 2x2 window in
+    two halves): the oracle's conv -> requant -> maxpool bytes in the three wrap regimes -- a half that fails its range test leaves a BYTE
+    maximum behind, a clean one an accumulator maximum, and all four combinations of the two halves must agree with the reference's order --
+    on flat tiles that cross rows and images, 8 x 16 patches (wide maps), ragged ends; with the constants derived in the kernel, from the
+    packed table, from a table made for another zero point (key mismatch), and with shifts that are no powers of two (two-step form, every
+    value); `no-wrap` multipliers are small enough that the integer requantisation does not qualify (the FP64-of-maximum fast path, which conv_small.hip's
+    32- / 64-channel kernels take as well since round 6 instead of the exact path for every window).  Debug bit 4096 selects the kernel (it measured
+    slower than conv_small.hip and is not in the default path); the same call without the bit gives the same bytes."""
+    import ctypes as C
+    c, n = 32, 64
+    rng = np.random.default_rng(H * 1000 + W + len(gain) + len(table))
+    x = rng.integers(0, 256, (B, c, H, W), dtype=np.uint8)
+    lo, hi = {"no-wrap": (2.0 ** -17, 2.0 ** -16), "some-wrap": (2.0 ** -14, 2.0 ** -12), "much-wrap": (2.0 ** -11, 2.0 ** -7)}[gain]
+    wq, zp_w, bias, mv, sv = _rand_layer(rng, n, c, 3, lo, hi)
+    zp_w[0], zp_w[1], zp_w[2] = 0, 255, 1
+    if gain != "much-wrap":
+        bias = (bias // 16).astype(np.int32)
+    if table == "shift-not-pow2":
+        sv = sv * 0.75
+    zp_in, zp_act = 9, (23 if act != "linear" else 128)
+    xt = binding.DevTensor.from_nchw(x, zp_in)
+    ept = () if table == "none" else (binding.ACT[act], zp_act + (table == "other-zero-point"))
+    blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv, *ept))
+    acc, u8 = _oracle_layer(x, wq, zp_w, 3, zp_in, bias, mv, sv, zp_act, oracle.ACT[act], store, oracle.ACC_EXACT)
+    want_pool = np.stack([oracle.maxpool_u8(u8.reshape(B, n, H, W)[b], 2, 2, 1) for b in range(B)])
+    d = binding.ConvDesc(n, c, 3, 1, 1, binding.ACT[act], store, binding.ACC_EXACT, zp_in, zp_act, 1.0)
+    for flags, kernel in ((4096, 8), (0, 2)):
+        yp = binding.DevTensor(B, H // 2, W // 2, n, zp_act)
+        binding.shim().mi355_debug_flags(flags)
+        try:
+            binding.check(binding.shim().mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, None, yp.ref(), None), "conv_pool")
+            assert binding.shim().mi355_last_conv_kernel() == kernel
+        finally:
+            binding.shim().mi355_debug_flags(0)
+        got = yp.to_nchw()
+        assert np.array_equal(got, want_pool), f"kernel {kernel}: {int((got != want_pool).sum())} of {got.size} pooled bytes differ"
+        raw = yp.buf.to_numpy(np.uint8, yp.buf.nbytes).reshape(-1, yp.t.cs)
+        OW = W // 2
+        assert (raw[yp.t.lead + OW] == (zp_act ^ 0x80)).all() and (raw[yp.t.lead + (OW + 1) + OW] == (zp_act ^ 0x80)).all()  # pad cells untouched
+
+
 @pytest.mark.parametrize("B,c,n,H,W,act", [(3, 16, 32, 22, 64, "leaky"), (3, 32, 64, 14, 70, "leaky"), (2, 16, 32, 18, 30, "relu6"),
                                            (2, 32, 64, 34, 34, "linear"), (1, 16, 32, 208, 208, "leaky"), (1, 32, 64, 104, 104, "leaky"),
                                            (5, 16, 32, 2, 2, "leaky"), (2, 32, 64, 16, 32, "relu6"), (1, 16, 32, 40, 300, "linear")])

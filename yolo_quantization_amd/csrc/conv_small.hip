@@ -33,6 +33,7 @@
 //     are monotone everywhere.  Result bytes are identical to conv + forward_maxpool_layer_quant
 //     (ref: src/maxpool_layer.c:109-172) in every case.
 #include "kargs.h"
+#include <cstdlib>
 #include <type_traits>
 
 #define DMA_S(ldsdst_u32, sbase_ptr, voff_u32)                                                                   \
@@ -102,9 +103,12 @@ constexpr int SM_KMAX = 6;    // DMA instructions per wave and piece per tile im
 // that the common path tests nothing else per group of four channels (the kernels are close to instruction-issue bound, DESIGN.md 4.5;
 // such launches requantise every window value: slower, same bytes).
 template <int ACT, bool SAT>
+// `use_int` (round 6): a channel that fails the integer form's conditions (intrq_make: multipliers below ~5e-4 widen the
+// wrap-safe range beyond 2^53 / M0) used to be folded into `never` -- ONE such channel sent every window of the launch down the exact path.  It
+// now only selects the FP64-of-maximum form of the fast path (one FP64 requantisation per pooled output instead of two integer instructions).
 __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)[4][4], const int (&lo)[4], const int (&rg)[4], bool never,
                                                              const int (&m0)[4], const int (&sh)[4], const double *ldsMP4,
-                                                             int zp_act, bool pow2, const double *mval4, const double *sval4)
+                                                             int zp_act, bool pow2, const double *mval4, const double *sval4, bool use_int = true)
 {
     uint32_t umax[4];
     bool bad = never;
@@ -117,7 +121,7 @@ __device__ __forceinline__ uint32_t pool_requant_quad_biased(const uint32_t (&u)
         int32_t amax[4][1], v[4][1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) amax[r][0] = (int32_t)(umax[r] + (uint32_t)lo[r]);
-        if ((ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT) {
+        if ((ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT && use_int) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int32_t f = intrq_floor(amax[r][0], m0[r], sh[r]);
@@ -270,12 +274,17 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
     }
     // one wave-uniform flag for "this launch requantises every window value" (see pool_requant_quad_biased)
     constexpr bool INTRQC = (ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT;
-    bool never_any;
+    // (the 16-channel kernels sit at their three-workgroups-per-CU register edge and keep round 4's folding: a channel outside the integer form's
+    // conditions counts as `never` there; layer 2 of the nets runs conv_pool16.hip anyway)
+    constexpr bool SPLIT_NOINT = C != 16;
+    bool never_any, use_int = true;
     if (ept_ok) {
-        never_any = (a.ept->flags & (EPT_NEVER | (INTRQC ? EPT_NOINT : 0u))) != 0;
+        never_any = (a.ept->flags & (EPT_NEVER | ((INTRQC && !SPLIT_NOINT) ? EPT_NOINT : 0u))) != 0;
+        if (SPLIT_NOINT) use_int = (a.ept->flags & EPT_NOINT) == 0;
         __syncthreads();
     } else {
-        never_any = __syncthreads_or(never_l | (INTRQC ? noint_l : 0)) != 0;
+        never_any = __syncthreads_or(never_l | ((INTRQC && !SPLIT_NOINT) ? noint_l : 0)) != 0;
+        if (SPLIT_NOINT) use_int = __syncthreads_or(noint_l) == 0;
     }
     const bool never = POOL && (never_any || !pow2);
 
@@ -591,7 +600,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ub[r][j] = (uint32_t)accb[r][j];
                     pk[mt][grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, m0v, shv, ldsMP + ch0, a.zp_act, pow2,
-                                                                     a.mval + ch0, a.sval + ch0);
+                                                                     a.mval + ch0, a.sval + ch0, use_int);
                 } else if constexpr (MODE == 2) {  // stride 2: one value per (pixel, channel), plain requantisation
                     int32_t a1[4][1], v1[4][1];
 #pragma unroll
@@ -735,7 +744,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
     // (POOL: accumulators biased by the safe range's lower end, window maxima requantised with two integer instructions where every channel
     // qualifies -- pool_requant_quad_biased, as in conv_small_pool_kernel)
     constexpr bool INTRQC = (ACT == MI355_ACT_LEAKY || ACT == MI355_ACT_RELU6) && !SAT;
-    int never_l = 0;
+    int never_l = 0, noint_l = 0;
     const bool ept_ok = POOL && !SAT && a.ept != nullptr && a.ept->key == ept_key(ACT, a.zp_act);  // the host's epilogue table (common.h)
     for (int i = tid; i < N; i += NT) {
         const double mp = a.mprime[i];
@@ -754,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
             if constexpr (POOL) {
                 int32_t lb = 0; uint32_t rg = 0;
                 if (!biased_safe_range(lo, hi, lb, rg)) never_l = 1;
-                if (INTRQC && !(pow2 && intrq_make(a.mval[i], a.shift[i], lb, (int32_t)((uint32_t)lb + rg), m0, sh, ACT == MI355_ACT_RELU6))) never_l = 1;
+                if (INTRQC && !(pow2 && intrq_make(a.mval[i], a.shift[i], lb, (int32_t)((uint32_t)lb + rg), m0, sh, ACT == MI355_ACT_RELU6))) noint_l = 1;
                 ldsCB[i] = (int32_t)((uint32_t)a.cwb[i] - (uint32_t)lb);
                 ldsLO[i] = lb;
                 ldsHI[i] = (int32_t)rg;
@@ -767,12 +776,14 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
         ldsM0[i] = m0;
         ldsSH[i] = sh;
     }
-    bool never_any;
+    bool never_any, use_int;  // (`noint` apart from `never`: see pool_requant_quad_biased)
     if (ept_ok) {
-        never_any = (a.ept->flags & (EPT_NEVER | (INTRQC ? EPT_NOINT : 0u))) != 0;
+        never_any = (a.ept->flags & EPT_NEVER) != 0;
+        use_int = (a.ept->flags & EPT_NOINT) == 0;
         __syncthreads();
     } else {
         never_any = __syncthreads_or(never_l) != 0;
+        use_int = __syncthreads_or(noint_l) == 0;
     }
     const bool never = POOL && (never_any || !pow2);
     v4i wf[KST];
@@ -931,7 +942,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ub[r][j] = (uint32_t)accb[r][j];
-                pk4[grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, m0v, shv, ldsMP + ch0, a.zp_act, pow2, a.mval + ch0, a.sval + ch0);
+                pk4[grp] = pool_requant_quad_biased<ACT, SAT>(ub, lov, hiv, never, m0v, shv, ldsMP + ch0, a.zp_act, pow2, a.mval + ch0, a.sval + ch0, use_int);
                 if (grp == 3 && pcell >= 0)  // the lane's sixteen consecutive filters 16 kh .. + 15 (ws_row_filter): one store
                     *reinterpret_cast<uint4 *>(a.ypool + (size_t)pcell * a.pool_cs + chw + 16 * kh) = uint4{pk4[0], pk4[1], pk4[2], pk4[3]};
             } else if constexpr (MODE == 2) {  // stride 2: window position 0 is the output pixel
@@ -1114,6 +1125,8 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
     // persistent workgroups per CU: LDS permitting; the c = 16, n = 32 variant needs few enough registers for three
     int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
     if (c == 16 && a.n == 32 && 3 * lds <= 160 * 1024) per_cu = 3;
+    static const int per_cu_env = getenv("MI355_SMALL_PER_CU") ? atoi(getenv("MI355_SMALL_PER_CU")) : 0;  // (A/B runs)
+    if (per_cu_env > 0 && per_cu_env < per_cu) per_cu = per_cu_env;
     const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
     if (c == 16 && a.n == 32) return small_launch_act<16, 1>(a, st, grid, lds);
     if (c == 16 && a.n == 64) return small_launch_act<16, 2>(a, st, grid, lds);

@@ -132,6 +132,8 @@ __host__ __device__ constexpr int ws_row_filter(int R) { return 16 * ((R >> 2) &
 bool conv_small_eligible(int n, int c, int ksize);
 bool conv_pool16_eligible(int n, int c, int ksize);
 int conv_pool16_launch(ConvArgs &a, hipStream_t st);  // conv_pool16.hip: c 16 | 32 + maxpool on 16 x 16 x 64 tiles (needs the blob's epilogue table)
+bool conv_small32_eligible(int n, int c, int ksize);
+int conv_small32_launch(ConvArgs &a, hipStream_t st);  // conv_small32.hip: c 32 -> n 64 + maxpool, eight waves per workgroup at four per SIMD (round 6)
 int conv1x1_ws_launch(ConvArgs &a, hipStream_t st);
 bool conv1x1_ws_eligible(int n, int c, int ksize);
 int conv_ws3_launch(ConvArgs &a, hipStream_t st);

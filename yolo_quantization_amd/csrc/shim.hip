@@ -717,6 +717,9 @@ static int conv_forward_impl(const mi355_conv_desc *d, const mi355_tensor *x, co
     }
     // few-channel layers with the epilogue table: the 16 x 16 x 64 form (conv_pool16.hip; debug bit 2^30 sends them back to conv_small.hip for A/B runs)
     if (ypool && !y && d->epilogue_packed && a.ept && !(mi355_debug_flags_get() & (1024 | (1 << 30)))) { rc = conv_pool16_launch(a, st); if (rc != MI355_EINVAL) g_last_kernel = 7; }
+    // 32 -> 64 + maxpool: the occupancy cut of conv_small.hip (conv_small32.hip, round 6).  Measured slower than conv_small.hip alone and in flight
+    // (profiles/r06_small32_*): NOT in the default path; debug bit 4096 selects it (A/B runs, parity tests)
+    if (rc == MI355_EINVAL && ypool && !y && a.ws && (mi355_debug_flags_get() & (1024 | 4096)) == 4096) { rc = conv_small32_launch(a, st); if (rc != MI355_EINVAL) g_last_kernel = 8; }
     if (rc == MI355_EINVAL && ypool && !y && a.ws && !(mi355_debug_flags_get() & 1024)) { rc = conv_small_pool_launch(a, st); g_last_kernel = 2; }  // few-channel layers
     // the same kernel without the pool: few-channel 3x3 layers of the non-tiny nets (even maps, no dumps)
     if (rc == MI355_EINVAL && !ypool && y && a.ws && d->ksize == 3 && up == 1 && !acc_out && !y_f32 && !yolo_out &&

@@ -134,10 +134,13 @@ def _quantize_per_channel(wf: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.nd
     return q, scale, zp
 
 
-def synth_weights(cfg_path: str, out_path: str, seed: int = 1234, act_gain: float = 1.0) -> dict:
+def synth_weights(cfg_path: str, out_path: str, seed: int = 1234, act_gain: float = 1.0, small_m_channels: int = 0) -> dict:
     """Write a seeded synthetic `.weights` file for `cfg_path`. Returns {'sha256': ..., 'layers': [...]}.
     act_gain > 1 divides every activation scale by that factor so that requantised values overflow 0..255 and
-    exercise the reference's wrap-on-store behaviour (src/convolutional_layer.c:737-749)."""
+    exercise the reference's wrap-on-store behaviour (src/convolutional_layer.c:737-749).
+    small_m_channels > 0 shrinks the float weights of the first that many filters of every convolution by 64: their per-channel weight
+    scale -- and with it the requantisation multiplier M = s_in * s_w / s_out (src/blas.c:313) -- falls to ~2e-5, below what the kernels'
+    integer requantisation accepts (common.h intrq_make): the 'unfriendly model' of bench.py --small-m-channels."""
     rng = np.random.default_rng(seed)
     _, layers = layer_shapes(read_cfg(cfg_path))
     act_q: list[tuple[np.float32, int]] = []
@@ -148,6 +151,8 @@ def synth_weights(cfg_path: str, out_path: str, seed: int = 1234, act_gain: floa
         if L.type == "conv":
             K = L.c * L.size * L.size
             w = (rng.standard_normal((L.n, K)) * np.sqrt(2.0 / K)).astype(np.float32)
+            if small_m_channels > 0:
+                w[:min(small_m_channels, L.n)] *= np.float32(1.0 / 64.0)
             bias = rng.uniform(-0.1, 0.1, L.n).astype(np.float32)
             blob += bias.tobytes()
             if L.batch_normalize:
