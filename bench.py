@@ -721,7 +721,8 @@ def main():
                 ops, _ = conv_layer_work(inf, B)
                 # gbs: algorithmic bytes of the launch that runs (fused launches: input + weights + the tensors it STORES)
                 row.update(tops=round(ops / (t_ms * 1e-3) / 1e12, 2), gbs=round((rd_b + wr_b) / (t_ms * 1e-3) / 1e9, 1), bytes=rd_b + wr_b,
-                           fused_next=bool(net.fuses_next(i)), k=inf["size"], c=inf["c"], n=inf["n"], hw=inf["out_h"], ops=ops)
+                           fused_next=bool(net.fuses_next(i)), k=inf["size"], c=inf["c"], n=inf["n"], hw=inf["out_h"], ops=ops,
+                           kernel_family=int(net.conv_kernel(i)))  # mi355_last_conv_kernel's code of the launch that served the layer
             elif launches and t_ms > 1e-3:
                 row.update(gbs=round((rd_b + wr_b) / (t_ms * 1e-3) / 1e9, 1), bytes=rd_b + wr_b)
             rows.append(row)

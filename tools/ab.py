@@ -77,7 +77,9 @@ for rnd in range(a.rounds):
                 d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
                 r = d.get("roofline") or {}
                 print(f"round {rnd} {name:12s} ms/step {d['ms_per_step']} img/s {d['value']} serial {(d.get('serial') or {}).get('ms_per_step')} frac {r.get('frac')} "
-                      f"s33 {(r.get('conv3x3_s1_aggregate') or {}).get('frac')} sustained {(r.get('sustained') or {}).get('frac')} lat {(r.get('latency_plan') or {}).get('frac')}", flush=True)
+                      f"s33 {(r.get('conv3x3_s1_aggregate') or {}).get('frac')} sustained {(r.get('sustained') or {}).get('frac')} lat {(r.get('latency_plan') or {}).get('frac')} "
+                      f"s33-sustained {((r.get('conv3x3_s1_aggregate') or {}).get('sustained') or {}).get('frac')} "
+                      + " ".join(f"L{x['layer']}:{x['us_per_launch']}" for x in ((r.get('conv3x3_s1_aggregate') or {}).get('sustained') or {}).get('launches', [])), flush=True)
             except Exception as e:  # noqa: BLE001
                 print(f"round {rnd} {name}: no result ({e})")
         else:

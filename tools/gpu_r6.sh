@@ -26,7 +26,7 @@ sq)
     for plan in 0 1; do
       rm -rf $O/pmc_$pass
       ( cd /tmp && BENCH_PLAN=$plan timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$R/$O/pmc_$pass" -o p -- \
-          python "$R/bench.py" --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-ref-f32 --selfcheck-passes 0 > "$R/$O/pmc_$pass.out" 2> "$R/$O/pmc_$pass.err" )
+          python "$R/bench.py" --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-ref-f32 --selfcheck-passes 0 --no-preroll-leg > "$R/$O/pmc_$pass.out" 2> "$R/$O/pmc_$pass.err" )
       f=$(find $O/pmc_$pass -name "*counter_collection.csv" | head -1)
       [ -n "$f" ] && python tools/pmc_summary.py "$f" > $O/pmc_${pass}_plan$plan.txt
       rm -rf $O/pmc_$pass
@@ -52,7 +52,7 @@ pmc)
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/pmc_$ctr
     ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$R/$O/pmc_$ctr" -o p -- \
-        python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-ref-f32 --selfcheck-passes 0 --serial-steps 2 --no-extra-legs > "$R/$O/pmc_$ctr.json" 2> "$R/$O/pmc_$ctr.err" )
+        python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-ref-f32 --selfcheck-passes 0 --serial-steps 2 --no-extra-legs --no-preroll-leg > "$R/$O/pmc_$ctr.json" 2> "$R/$O/pmc_$ctr.err" )
   done
   python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_traffic.json | head -12
   rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE ;;

@@ -208,6 +208,11 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
     // kernel is bound by its VALU stream and the MFMA form is faster (layer 2: 37.6 vs 38.7 us); with other batches in flight what
     // counts is the sum of both pipes' time, and the second MFMA pass costs 0.16 clk per output against 0.06 (flood 34.9 -> 33.1 us)
     constexpr bool DZM = (C == 16) && !VDZ;
+#ifdef MI355_SMALL_BSHARE  // (A/B builds: see BSH below; measured slower, off)
+    constexpr bool BSH = C == 32 && NM == 2 && MODE == 0;
+#else
+    constexpr bool BSH = false;
+#endif
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ncell = a.sm_ncell;     // slots of an LDS image row = its pitch (>= the image cells: flat tiles W + 2, x = -1 .. W; patches 34)
@@ -502,10 +507,39 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
         uint8_t *outp = a.ypool + pcell * a.pool_cs;
 
         SMP_MARK_V(3, sx[3]);
+        // BSH (round 6 experiment, -DMI355_SMALL_BSHARE builds only): 32 -> 64 + maxpool keeps the accumulators of BOTH m-tiles (128 registers)
+        // and issues the two MFMAs of a B fragment back to back -- one 1 KiB ds_read_b128 per two MFMAs instead of one per MFMA.  Bit-identical
+        // and SLOWER: layer 4 in flight 18.8-19.2 -> 20.5-20.6 us, the whole in-flight step 0.2403-0.2409 -> 0.2428-0.2434 ms
+        // (profiles/r06_bshare_ab_flood.log, r06_l4_variants_ab_bench.log): LDS reads are not what this kernel waits for.
+        v16i accs[BSH ? NM : 1][4];
+        if constexpr (BSH) {
+#pragma unroll
+            for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + 32 * mt + 16 * kh + 4 * grp);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        accs[mt][j][grp * 4 + 0] = c4.x; accs[mt][j][grp * 4 + 1] = c4.y;
+                        accs[mt][j][grp * 4 + 2] = c4.z; accs[mt][j][grp * 4 + 3] = c4.w;
+                    }
+                }
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int s = 0; s < KST; ++s)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const v4i bf = *reinterpret_cast<const v4i *>(X + base[j >> 1] + toff[j & 1][s]);
+#pragma unroll
+                    for (int mt = 0; mt < NM; ++mt) accs[mt][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[mt][s], bf, accs[mt][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+        }
 #pragma unroll
         for (int mt = 0; mt < NM; ++mt) {
             // accumulators start at cw + bias: register grp*4+r of a 32x32 tile is channel row 8*grp + 4*kh + r
-            v16i acc[4];
+            v16i (&acc)[4] = accs[BSH ? mt : 0];
+            if constexpr (!BSH) {
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
                 const int4 c4 = *reinterpret_cast<const int4 *>(ldsCB + 32 * mt + 16 * kh + 4 * grp);
@@ -540,6 +574,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
                     }
                 }
             __builtin_amdgcn_s_setprio(0);
+            }
             SMP_MARK_V(4, acc[NJ - 1][15]);
             // ---- epilogue: window max, one requantisation per (pixel, channel), biased packed store
             uint32_t po[POOL ? 1 : NJ][4];  // no-pool / stride-2 modes: the packed bytes of the four channel groups, stored together
@@ -558,7 +593,7 @@ __global__ __launch_bounds__(256, (C == 16 && NM == 1 && VDZ) ? 3 : 2) void conv
                 g.sh = *reinterpret_cast<const int4 *>(ldsSH + ch0);
                 return g;
             };
-            constexpr bool AHEAD = POOL && C == 32;  // (c = 16 sits at its three-workgroups-per-CU register edge: the 20 registers of a group in flight would cost a workgroup)
+            constexpr bool AHEAD = POOL && C == 32 && !BSH;  // (c = 16 sits at its three-workgroups-per-CU register edge: the 20 registers of a group in flight would cost a workgroup)
             GroupConst gnext = {};
             if constexpr (AHEAD) {
                 gnext = group_const(0);
