@@ -596,12 +596,14 @@ def main():
         def flood(lo, hi):
             for nk in nets:
                 nk.set("range_lo", lo); nk.set("range_hi", hi)
-            for _ in range(4):
+            for _ in range(20):
                 for nk in nets:
                     nk.forward()
             for nk in nets:
                 nk.sync()
-            reps = 40
+            # (round 6: 200 launches per instance instead of 40 -- a 3 ms burst right after a synchronisation still sees the device settle its
+            # clocks: the same layers read 3-5 % longer at 60 launches than at 1 000, profiles/r06_flood_reps_60_vs_1000.log)
+            reps = 200
             t0 = time.perf_counter()
             for _ in range(reps):
                 for nk in nets:
@@ -639,12 +641,12 @@ def main():
                     "frac_with_standalone_maxpool_launches": round(o / u5 / 1e6 / PEAK_INT8_TOPS, 4), "us_with_standalone_maxpool_launches": round(u5, 2),
                     "layer_set": "L" + ", L".join(str(r["layer"]) for r in rows),
                     "launches": [{k: v for k, v in r.items() if k != "ops"} for r in rows], "note": note}
-        sustained = agg(rows_layers, f"the row-image launches of the step ONLY (not the north-star layer set: see conv3x3_s1_aggregate.sustained), each repeated 40 times on all "
+        sustained = agg(rows_layers, f"the row-image launches of the step ONLY (not the north-star layer set: see conv3x3_s1_aggregate.sustained), each repeated 200 times on all "
                                      f"{ninfl} instances at once; host wall time / launches (no events: the launches overlap).  `frac` above is the strict per-launch figure "
                                      "(one launch alone on the device, launch gap, fill and tail included); this is the rate the kernel sustains when the chip is kept full of it, "
                                      "as in the timed region")
         sustained33 = agg(s33_layers, f"EVERY 3x3 stride-1 conv with c > 3 (the north-star target's layer set), whichever kernel serves it, its FUSED maxpool included: each launch "
-                                      f"repeated 40 times on all {ninfl} instances at once, host wall time / launches.  A maxpool that runs as a launch of its own behind the conv "
+                                      f"repeated 200 times on all {ninfl} instances at once, host wall time / launches.  A maxpool that runs as a launch of its own behind the conv "
                                       "(L8 / L10 under the throughput plan: the row-image kernel has no fused pool) is a byte kernel, not part of the conv: timed apart "
                                       "(`us_with_its_standalone_maxpool_launch`; `frac_with_standalone_maxpool_launches` is the aggregate the way BENCH_r05 counted it)")
 
