@@ -700,16 +700,17 @@ __global__ __launch_bounds__(512, 2) void conv_mid_pool_kernel(const ConvArgs a)
 {
     constexpr bool POOL = MODE == 0;
     constexpr int NJ = MODE == 2 ? 1 : 4;
-    constexpr int KST = 18, PIECES = 4, GMAX = SM_GMAX;
+    constexpr int KST = 18, PIECES = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ncell = a.sm_ncell, rowb = ncell * 16, pieceb = a.sm_pieceb;  // ncell: slots per LDS row (pitch)
     const int lcell = a.sm_lcell, hc = a.sm_hc, hcb = hc * 16;              // image cells per row; rows de-interleaved by column parity (see the file header)
     const bool patch = a.tiles_x > 0;
     const int N = a.n;
+    const int GT = (a.sm_tp + 31) >> 5;                                   // groups of 32 pooled pixels per tile: the tables are sized by it (round 6: was GMAX)
     int *ldsS = reinterpret_cast<int *>(smem + PIECES * pieceb);          // [rows_cap * ncell] per-cell channel sums
     int *ldsSX = ldsS + ((a.rows_cap * ncell + 1) & ~1);                  // [G][4][32] 3x3 box sums per pre-pool pixel
-    int *ldsBase = ldsSX + GMAX * 128;                                    // [G][4][32] image byte offset of tap (0,0)
-    long *ldsCell = reinterpret_cast<long *>(ldsBase + GMAX * 128);       // [G][32] pooled output cell, -1: no pixel
+    int *ldsBase = ldsSX + GT * 128;                                      // [G][4][32] image byte offset of tap (0,0)
+    long *ldsCell = reinterpret_cast<long *>(ldsBase + GT * 128);         // [G][32] pooled output cell, -1: no pixel
     double *ldsMP = reinterpret_cast<double *>(smem + a.lds_param_off);   // [N] folded multiplier
     int *ldsDZ = reinterpret_cast<int *>(ldsMP + N);
     int *ldsCB = ldsDZ + N;
@@ -1140,13 +1141,40 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
             ntiles = (int)((total_p + tp - 1) / tp);
         }
         a.sm_tp = tp;
+        // Round 6: HALF workgroups -- one wave set (n / 32 waves) instead of two -- wherever two of them fit a CU and something can run beside a
+        // workgroup: launches of several rounds, and every launch under the throughput plan (other batches' launches).  The kernel's 213-219
+        // VGPRs allow two waves per SIMD = eight waves per CU: ONE eight-wave workgroup, whose load phase (A fragments, image DMA, tables: 5.3 of
+        // 17.9 us, tools/wg_timeline.py) and tail nothing covered -- or TWO four-wave workgroups that run them under each other's group loops.
+        // Flat tiles drop the bank-alignment padding of their row pitch for it (layer 6: 93.4 -> 79.6 KB of LDS).  Layer 6 with four batches in
+        // flight 18.2 -> 15.2 us per launch, whole in-flight step 242.3 -> 239.3 us, bench 0.2423 -> 0.2381 ms per step; alone the layer is slower
+        // (21.6 -> 27.4 us: half the waves per CU), which is the latency plan's concern and why one-round launches keep whole workgroups there
+        // (profiles/r06_mid_half_*; MI355_MID_FULL=1 restores whole workgroups everywhere for A/B runs).
+        static const bool mid_full = getenv("MI355_MID_FULL") != nullptr;
+        const bool want_half = !mid_full && (a.plan == MI355_PLAN_THROUGHPUT || ntiles > 256);
+        const int gt = (tp + 31) / 32;
+        auto lds_need = [&]() {
+            size_t l = 4 * (size_t)a.sm_pieceb + (size_t)((a.rows_cap * a.sm_ncell + 1) & ~1) * 4 + (size_t)gt * 128 * 8 + (size_t)gt * 32 * 8;
+            l = (l + 15) & ~(size_t)15;
+            a.lds_param_off = (int)l;
+            return l + (size_t)a.n * 32;
+        };
+        const int ncell_padded = a.sm_ncell;
+        bool half = false;
+        if (want_half) {
+            if (a.tiles_x == 0) {  // flat tiles: the unpadded pitch (a wave whose pixels wrap into the next pooled row then takes a bank conflict there)
+                a.sm_ncell = a.sm_lcell;
+                a.sm_pieceb = a.rows_cap * a.sm_ncell * 16;
+            }
+            half = 2 * lds_need() <= 160 * 1024 && a.rows_cap * a.sm_ncell >= 64;
+            if (!half) {
+                a.sm_ncell = ncell_padded;
+                a.sm_pieceb = a.rows_cap * a.sm_ncell * 16;
+            }
+        }
         if (a.rows_cap * a.sm_ncell < 64) return MI355_EINVAL;
-        size_t l64 = 4 * (size_t)a.sm_pieceb + (size_t)((a.rows_cap * a.sm_ncell + 1) & ~1) * 4 + SM_GMAX * 128 * 8 + SM_GMAX * 32 * 8;
-        l64 = (l64 + 15) & ~(size_t)15;
-        a.lds_param_off = (int)l64;
-        l64 += (size_t)a.n * 32;
+        const size_t l64 = lds_need();
         if (l64 > 160 * 1024) return MI355_EINVAL;
-        const int threads = 2 * (a.n / 32) * 64;
+        const int threads = (half ? 1 : 2) * (a.n / 32) * 64;
         if (a.act == MI355_ACT_LEAKY) return mid_launch_sat<MI355_ACT_LEAKY>(a, st, ntiles, threads, l64);
         if (a.act == MI355_ACT_RELU6) return mid_launch_sat<MI355_ACT_RELU6>(a, st, ntiles, threads, l64);
         return mid_launch_sat<MI355_ACT_LINEAR>(a, st, ntiles, threads, l64);
