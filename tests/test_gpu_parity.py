@@ -465,11 +465,10 @@ def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain, ept):
     assert np.array_equal(yp2.to_nchw(), want_pool)
 
 
-@pytest.mark.parametrize("B,H,W,act", [(3, 14, 70, "leaky"), (2, 34, 34, "linear"), (1, 104, 104, "leaky"), (2, 16, 32, "relu6"), (1, 152, 152, "leaky"),
-                                       (5, 6, 10, "relu6"), (1, 40, 300, "leaky"), (16, 26, 26, "leaky")])
+@pytest.mark.parametrize("B,H,W,act", [(3, 14, 70, "leaky"), (2, 34, 34, "linear"), (1, 104, 104, "leaky"), (5, 6, 10, "relu6"), (1, 40, 300, "leaky")])
 @pytest.mark.parametrize("store", [binding.STORE_WRAP, binding.STORE_SATURATE], ids=["wrap", "saturate"])
 @pytest.mark.parametrize("gain", ["no-wrap", "some-wrap", "much-wrap"])
-@pytest.mark.parametrize("table", ["none", "match", "other-zero-point", "shift-not-pow2"])
+@pytest.mark.parametrize("table", ["none", "match", "shift-not-pow2"])
 def test_conv_small32_kernel(B, H, W, act, store, gain, table):
     """conv_small32.hip (round 6: 32 -> 64 channels + maxpool, conv_small.hip's tile on eight waves of one m-tile each, the 2x2 window in
     two halves): the oracle's conv -> requant -> maxpool bytes in the three wrap regimes -- a half that fails its range test leaves a BYTE
@@ -492,7 +491,7 @@ def test_conv_small32_kernel(B, H, W, act, store, gain, table):
         sv = sv * 0.75
     zp_in, zp_act = 9, (23 if act != "linear" else 128)
     xt = binding.DevTensor.from_nchw(x, zp_in)
-    ept = () if table == "none" else (binding.ACT[act], zp_act + (table == "other-zero-point"))
+    ept = () if table == "none" else (binding.ACT[act], zp_act + (1 if (table == "match" and H == 34) else 0))  # (34 x 34: a table made for another zero point)
     blob = binding.DevBuf.from_numpy(binding.conv_pack(wq, zp_w, c, 3, bias, mv, sv, *ept))
     acc, u8 = _oracle_layer(x, wq, zp_w, 3, zp_in, bias, mv, sv, zp_act, oracle.ACT[act], store, oracle.ACC_EXACT)
     want_pool = np.stack([oracle.maxpool_u8(u8.reshape(B, n, H, W)[b], 2, 2, 1) for b in range(B)])
