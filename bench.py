@@ -763,7 +763,7 @@ def main():
         # included -- per launch alone on the device.  Rounds 1-5 put the row-image launches (the five best) here; they are `row_image_launches` now.
         n33 = sum(1 for inf in net.info if inf["type"] == binding.T_CONV and inf["size"] == 3 and inf["stride"] == 1 and inf["c"] > 3)
         ach33 = s33_ops / (s33_ms * 1e-3) / 1e12 if s33_ms else 0.0
-        roof = {"bound": "mfma", "kernel": f"the {n33} 3x3 stride-1 conv launches with c > 3 (BASELINE north_star's layer set: conv_pool16 / conv_small32 / conv_mid_pool / conv_rows / conv_rows16 on "
+        roof = {"bound": "mfma", "kernel": f"the {n33} 3x3 stride-1 conv launches with c > 3 (BASELINE north_star's layer set: conv_pool16 / conv_small_pool / conv_mid_pool / conv_rows / conv_rows16 on "
                           f"V_MFMA_I32_*_I8, fused maxpools included: {100 * s33_ms / all_ms:.0f}% of the step's time and {100 * s33_ops / all_ops:.0f}% of its operations)",
                 "achieved": round(ach33, 2), "peak": round(PEAK_INT8_TOPS, 1), "unit": "TOP/s",
                 "frac": round(ach33 / PEAK_INT8_TOPS, 4),
