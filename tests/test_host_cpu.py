@@ -487,3 +487,19 @@ def test_no_register_of_a_hand_written_load_is_touched_before_its_wait(tmp_path)
     assert r.returncode == 1 and "still in flight" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_no_hand_written_register_loads_outside_the_ab_switch():
+    """The product build issues no vector-memory load with a REGISTER destination from inline asm (the compiler cannot order such a load's
+    register against its wait: test above).  The one historical site lives behind -DMI355_L0_ASM_PREFETCH (A/B builds of conv_aux.hip only);
+    LDS-DMA instructions (`global_load_lds_*`: no destination register) are fine and everywhere."""
+    import re
+    src_dir = os.path.join(ROOT, "yolo_quantization_amd", "csrc")
+    pat = re.compile(r'asm\s+volatile\s*\(\s*"[^"]*\b(global|buffer|flat|scratch)_load_(?!lds)', re.S)
+    for fn in sorted(os.listdir(src_dir)):
+        if not fn.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(src_dir, fn)).read()
+        # drop the A/B-only block
+        text = re.sub(r"#ifdef MI355_L0_ASM_PREFETCH.*?#(else|endif)", "", text, flags=re.S)
+        assert not pat.search(text), f"{fn}: inline-asm load with a register destination outside the A/B switch"
