@@ -1136,6 +1136,17 @@ int conv_small_pool_launch(ConvArgs &a, hipStream_t st)
             const long rounds = (total_p + 256L * SM_GMAX * 32 - 1) / (256L * SM_GMAX * 32);
             tp = (int)((total_p + 256 * rounds - 1) / (256 * rounds));
             if (tp < 32) tp = 32;
+            // Round 6, throughput plan (half workgroups, see below): tiles of WHOLE groups of 32 pooled pixels, at most four -- the 169 pixels
+            // that fill one round of the chip are five groups and nine lanes of a sixth, and nothing about a half workgroup that shares its CU
+            // asks for one round.  Layer 6 in flight, same box: 169 pixels 14.7 us, 160 13.8, 128 13.9 (and 25.9 instead of 29.5 us alone),
+            // 96 15.0, 64 15.8 (profiles/r06_mid_tile_sizes_flood.log).  MI355_MID_TP=<pixels> overrides for A/B runs.
+            static const int tp_env = getenv("MI355_MID_TP") ? atoi(getenv("MI355_MID_TP")) : 0;
+            static const bool mid_full_tp = getenv("MI355_MID_FULL") != nullptr;
+            if (a.plan == MI355_PLAN_THROUGHPUT && !mid_full_tp) {
+                if (tp_env > 0) tp = tp_env;
+                else if (tp > 128) tp = 128;
+                else if (tp >= 32) tp = (tp / 32) * 32;
+            }
             a.rows_cap = 2 * ((tp - 2 + OW) / OW + 1) + (tp - 2 + OH * OW) / (OH * OW) + 2;
             a.sm_pieceb = a.rows_cap * a.sm_ncell * 16;
             ntiles = (int)((total_p + tp - 1) / tp);
