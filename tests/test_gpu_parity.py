@@ -463,6 +463,14 @@ def test_conv_small_channel_pool_kernel(c, n, H, W, act, store, gain, ept):
     finally:
         binding.shim().mi355_debug_flags(0)
     assert np.array_equal(yp2.to_nchw(), want_pool)
+    if c == 64:
+        # round 6: under the throughput plan the 64-channel kernel runs as HALF workgroups (one wave set, tiles of whole pixel groups, unpadded
+        # LDS pitch: conv_small.hip conv_small_pool_launch) -- same bytes
+        d.plan = 1
+        yp3 = binding.DevTensor(B, H // 2, W // 2, n, zp_act)
+        binding.check(binding.shim().mi355_conv_pool_forward(C.byref(d), xt.ref(), blob.ptr, None, yp3.ref(), None), "conv_pool (throughput plan)")
+        assert binding.shim().mi355_last_conv_kernel() == 2
+        assert np.array_equal(yp3.to_nchw(), want_pool), "throughput plan (half workgroups)"
 
 
 @pytest.mark.parametrize("B,H,W,act", [(3, 14, 70, "leaky"), (2, 34, 34, "linear"), (1, 104, 104, "leaky"), (5, 6, 10, "relu6"), (1, 40, 300, "leaky")])
